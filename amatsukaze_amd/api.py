@@ -1,0 +1,375 @@
+"""Python mirror of the reference's interface for the logo / CM / KFM analysis path, on top of the C ABI.
+
+Class names, argument meaning and error behaviour follow the reference (Amatsukaze/LogoScan.hpp):
+``LogoFrame(ctx, logofiles, maskratio)`` + ``scanFrames`` / ``selectLogo`` / ``writeResult`` /
+``getBestLogo`` / ``getLogoRatio``; ``AMTAnalyzeLogo(clip, logopath, maskratio)``;
+``AMTEraseLogo(clip, analyzeclip, logopath, logofpath, mode, maxfade)``; ``ScanLogo(...)``.
+A "clip" here is a :class:`DeviceClip`: planar 4:2:0 frames resident in HBM as torch tensors
+(torch is plumbing for device memory and streams only).  Failures raise :class:`AmtError` with the
+message the C ABI keeps on its context -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import binding
+
+
+class AmtError(RuntimeError):
+    pass
+
+
+def _p(t):
+    """device pointer of a torch tensor / host pointer of a numpy array / None"""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """AMTContext stand-in bound to one GPU (StreamUtils.hpp:343-511)."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        self.lib = binding.load()
+        self.h = self.lib.amtgpu_context_create(device)
+        if not self.h:
+            raise AmtError(f"amtgpu_context_create({device}) failed: no usable HIP device")
+        self.device = device
+        if use_torch_stream:
+            import torch
+            self.lib.amtgpu_context_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+
+    def check(self, ok, what=""):
+        if not ok:
+            raise AmtError((what + ": " if what else "") + self.lib.amtgpu_last_error(self.h).decode(errors="replace"))
+        return ok
+
+    def synchronize(self):
+        self.check(self.lib.amtgpu_context_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.amtgpu_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class DeviceClip:
+    """Frames in HBM: Y (N,H,pitchY), U/V (N,H/2,pitchUV) torch tensors (uint8, or int16/uint16 for >8 bit)."""
+    Y: object
+    U: object
+    V: object
+    width: int
+    height: int
+    bits: int = 8
+    fps_num: int = 30000
+    fps_den: int = 1001
+
+    @property
+    def num_frames(self):
+        return int(self.Y.shape[0])
+
+    @property
+    def es(self):
+        return 1 if self.bits <= 8 else 2
+
+    @property
+    def strideY(self):
+        return int(self.Y.stride(0)) * self.es
+
+    @property
+    def strideUV(self):
+        return int(self.U.stride(0)) * self.es
+
+    @property
+    def pitchY(self):
+        return int(self.Y.stride(1))
+
+    @property
+    def pitchUV(self):
+        return int(self.U.stride(1))
+
+
+class Logo:
+    """logo::LogoData + LogoHeader (AMTLogo.hpp:19-280)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.h = ctx, handle
+
+    @classmethod
+    def load(cls, ctx, path):
+        h = ctx.lib.amtgpu_logo_load(ctx.h, str(path).encode())
+        ctx.check(h, "LogoData::Load")
+        return cls(ctx, h)
+
+    @classmethod
+    def from_planes(cls, ctx, planes, w, h, imgw, imgh, imgx, imgy, logUVx=1, logUVy=1):
+        planes = np.ascontiguousarray(planes, np.float32)
+        hd = ctx.lib.amtgpu_logo_from_planes(ctx.h, w, h, logUVx, logUVy, imgw, imgh, imgx, imgy, _p(planes))
+        ctx.check(hd, "logo_from_planes")
+        return cls(ctx, hd)
+
+    def save(self, path, name="No Name", service_id=0):
+        self.ctx.check(self.ctx.lib.amtgpu_logo_save(self.ctx.h, self.h, str(path).encode(), name.encode(), service_id))
+
+    @property
+    def info(self):
+        o = np.zeros(8, np.int32)
+        self.ctx.lib.amtgpu_logo_get_info(self.h, _p(o))
+        return dict(zip(("w", "h", "logUVx", "logUVy", "imgw", "imgh", "imgx", "imgy"), map(int, o)))
+
+    @property
+    def planes(self):
+        i = self.info
+        n = (i["w"] * i["h"] + 2 * (i["w"] >> i["logUVx"]) * (i["h"] >> i["logUVy"])) * 2
+        out = np.zeros(n, np.float32)
+        self.ctx.lib.amtgpu_logo_get_planes(self.h, _p(out))
+        return out
+
+    def mask_tables(self, kind=0, maskratio=0.35):
+        i = self.info
+        w, h = i["w"], i["h"] if kind == 0 else i["h"] // 2
+        mp, cnt, black = C.c_int(), C.c_int(), C.c_float()
+        self.ctx.check(self.ctx.lib.amtgpu_logo_mask_tables(self.ctx.h, self.h, kind, maskratio, C.byref(mp), C.byref(cnt), C.byref(black), None, None, None))
+        mask = np.zeros(w * h, np.uint8)
+        ker = np.zeros(cnt.value * 25, np.float32)
+        sc = np.zeros(cnt.value * 64, np.float32)
+        self.ctx.check(self.ctx.lib.amtgpu_logo_mask_tables(self.ctx.h, self.h, kind, maskratio, None, None, None, _p(mask), _p(ker), _p(sc)))
+        return dict(maskpixels=mp.value, count=cnt.value, blackScore=black.value, mask=mask, kernels=ker, scales=sc)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.amtgpu_logo_destroy(self.h)
+        except Exception:
+            pass
+
+
+class LogoFrame:
+    """logo::LogoFrame (LogoScan.hpp:1521-1836)."""
+
+    def __init__(self, ctx: Context, logofiles, maskratio: float):
+        self.ctx = ctx
+        self.nlogos = len(logofiles)
+        if logofiles and isinstance(logofiles[0], Logo):
+            arr = (C.c_void_p * self.nlogos)(*[l.h for l in logofiles])
+            self._keep = list(logofiles)
+            self.h = ctx.lib.amtgpu_logoframe_create_from_logos(ctx.h, arr, self.nlogos, maskratio)
+        else:
+            arr = (C.c_char_p * self.nlogos)(*[str(p).encode() for p in logofiles])
+            self.h = ctx.lib.amtgpu_logoframe_create(ctx.h, arr, self.nlogos, maskratio)
+        ctx.check(self.h, "LogoFrame")
+        self.num_frames = 0
+
+    def begin(self, width, height, bits, num_frames, fps_num=30000, fps_den=1001):
+        self.ctx.check(self.ctx.lib.amtgpu_logoframe_begin(self.h, width, height, bits, num_frames, fps_num, fps_den))
+        self.num_frames = num_frames
+
+    def scan_batch(self, Y, bits, first, nframes=None):
+        es = 1 if bits <= 8 else 2
+        n = int(Y.shape[0]) if nframes is None else nframes
+        self.ctx.check(self.ctx.lib.amtgpu_logoframe_scan_batch(self.h, _p(Y), int(Y.stride(0)) * es, int(Y.stride(1)), first, n))
+
+    def scanFrames(self, clip: DeviceClip, batch: int = 4096):
+        self.begin(clip.width, clip.height, clip.bits, clip.num_frames, clip.fps_num, clip.fps_den)
+        for f0 in range(0, clip.num_frames, batch):
+            self.scan_batch(clip.Y[f0:f0 + batch], clip.bits, f0)
+
+    @property
+    def evalResults(self):
+        out = np.zeros(self.num_frames * self.nlogos * 2, np.float32)
+        self.ctx.check(self.ctx.lib.amtgpu_logoframe_get_results(self.h, _p(out)))
+        return out.reshape(self.num_frames, self.nlogos, 2)
+
+    def set_results(self, first, evals):
+        evals = np.ascontiguousarray(evals, np.float32)
+        self.ctx.check(self.ctx.lib.amtgpu_logoframe_set_results(self.h, first, evals.size // (self.nlogos * 2), _p(evals)))
+
+    def selectLogo(self, numCandidates=-1):
+        self.ctx.check(self.ctx.lib.amtgpu_logoframe_select_logo(self.h, numCandidates))
+
+    def writeResult(self, outpath, logoIndex=-1):
+        self.ctx.check(self.ctx.lib.amtgpu_logoframe_write_result(self.h, str(outpath).encode(), logoIndex))
+
+    def getBestLogo(self):
+        return self.ctx.lib.amtgpu_logoframe_best_logo(self.h)
+
+    def getLogoRatio(self):
+        return self.ctx.lib.amtgpu_logoframe_logo_ratio(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.amtgpu_logoframe_destroy(self.h)
+        except Exception:
+            pass
+
+
+class AMTAnalyzeLogo:
+    """logo::AMTAnalyzeLogo (LogoScan.hpp:1106-1236); GetFrames returns 33 floats per source frame."""
+
+    def __init__(self, ctx: Context, logo, maskratio: float = 0.35):
+        self.ctx = ctx
+        if isinstance(logo, Logo):
+            self._keep = logo
+            self.h = ctx.lib.amtgpu_analyze_create_from_logo(ctx.h, logo.h, maskratio)
+        else:
+            self.h = ctx.lib.amtgpu_analyze_create(ctx.h, str(logo).encode(), maskratio)
+        ctx.check(self.h, "AMTAnalyzeLogo")
+
+    def analyze_device(self, Y, bits, out):
+        es = 1 if bits <= 8 else 2
+        self.ctx.check(self.ctx.lib.amtgpu_analyze_batch(self.h, _p(Y), int(Y.stride(0)) * es, int(Y.stride(1)), bits, int(Y.shape[0]), _p(out)))
+
+    def analyze(self, clip: DeviceClip):
+        out = np.zeros((clip.num_frames, 33), np.float32)
+        self.ctx.check(self.ctx.lib.amtgpu_analyze_batch_host(self.h, _p(clip.Y), clip.strideY, clip.pitchY, clip.bits, clip.num_frames, _p(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.amtgpu_analyze_destroy(self.h)
+        except Exception:
+            pass
+
+
+class AMTEraseLogo:
+    """logo::AMTEraseLogo (LogoScan.hpp:1238-1519), mode 0."""
+
+    def __init__(self, ctx: Context, logo, logof="", mode: int = 0, maxfade: int = 16):
+        self.ctx = ctx
+        if isinstance(logo, Logo):
+            self._keep = logo
+            self.h = ctx.lib.amtgpu_erase_create_from_logo(ctx.h, logo.h, (logof or "").encode(), mode, maxfade)
+        else:
+            self.h = ctx.lib.amtgpu_erase_create(ctx.h, str(logo).encode(), str(logof or "").encode(), mode, maxfade)
+        ctx.check(self.h, "AMTEraseLogo")
+
+    def calc_fades(self, analysis, num_frames, first=0, nframes=None):
+        analysis = np.ascontiguousarray(analysis, np.float32)
+        n = num_frames - first if nframes is None else nframes
+        out = np.zeros((n, 2), np.float32)
+        self.ctx.check(self.ctx.lib.amtgpu_erase_calc_fades(self.h, _p(analysis), num_frames, first, n, _p(out)))
+        return out
+
+    def erase(self, clip: DeviceClip, fades):
+        fades = np.ascontiguousarray(fades, np.float32)
+        self.ctx.check(self.ctx.lib.amtgpu_erase_batch(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV,
+                                                       clip.pitchY, clip.pitchUV, clip.bits, clip.num_frames, _p(fades)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.amtgpu_erase_destroy(self.h)
+        except Exception:
+            pass
+
+
+class LogoScan:
+    """logo::LogoScan (LogoScan.hpp:398-660) with exact integer accumulators."""
+
+    def __init__(self, ctx: Context, w, h, thy, logUVx=1, logUVy=1):
+        self.ctx, self.w, self.hh = ctx, w, h
+        self.h = ctx.lib.amtgpu_logoscan_create(ctx.h, w, h, logUVx, logUVy, thy)
+        ctx.check(self.h, "LogoScan")
+
+    def add_batch(self, clip: DeviceClip, imgx, imgy, max_valid=1 << 30, use_mask=None):
+        valid = np.zeros(clip.num_frames, np.uint8)
+        n = C.c_int()
+        um = None if use_mask is None else np.ascontiguousarray(use_mask, np.uint8)
+        self.ctx.check(self.ctx.lib.amtgpu_logoscan_add_batch(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV,
+                                                              clip.pitchY, clip.pitchUV, clip.bits, imgx, imgy, clip.num_frames,
+                                                              max_valid, _p(um), _p(valid), C.byref(n)))
+        return valid, n.value
+
+    @property
+    def nframes(self):
+        return self.ctx.lib.amtgpu_logoscan_nframes(self.h)
+
+    def sums(self):
+        npx = self.w * self.hh + 2 * (self.w // 2) * (self.hh // 2)
+        s = np.zeros(npx * 3, np.int64)
+        p = np.zeros(6, np.int64)
+        self.ctx.check(self.ctx.lib.amtgpu_logoscan_get_sums(self.h, _p(s), _p(p)))
+        return s, p
+
+    def set_sums(self, s, p, nframes):
+        s = np.ascontiguousarray(s, np.int64)
+        p = np.ascontiguousarray(p, np.int64)
+        self.ctx.check(self.ctx.lib.amtgpu_logoscan_set_sums(self.h, _p(s), _p(p), nframes))
+
+    def get_logo(self, maxv, clean, imgw, imgh, imgx, imgy):
+        h = self.ctx.lib.amtgpu_logoscan_get_logo(self.h, maxv, 1 if clean else 0, imgw, imgh, imgx, imgy)
+        self.ctx.check(h, "LogoScan::GetLogo")
+        return Logo(self.ctx, h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.amtgpu_logoscan_destroy(self.h)
+        except Exception:
+            pass
+
+
+def ScanLogo(ctx: Context, clip: DeviceClip, serviceid, dstpath, imgx, imgy, w, h, thy, numMaxFrames, cb=None):
+    """The exported ScanLogo (LogoScan.hpp:1083-1098) over a device clip; returns True/False like it."""
+    cbf = binding.CB(cb) if cb else binding.CB(lambda p, a, b, c: 1)
+    ok = ctx.lib.amtgpu_scanlogo(ctx.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV, clip.pitchY, clip.pitchUV,
+                                 clip.width, clip.height, clip.num_frames, serviceid, str(dstpath).encode(), imgx, imgy, w, h, thy,
+                                 numMaxFrames, cbf)
+    return bool(ok)
+
+
+class FrameStats:
+    """Self-specified whole-frame field-difference / combing metrics."""
+
+    def __init__(self, ctx: Context, width, height, bits=8):
+        self.ctx, self.width, self.height, self.bits = ctx, width, height, bits
+        self.h = ctx.lib.amtgpu_framestats_create(ctx.h, width, height, bits, 0, 0)
+        ctx.check(self.h, "FrameStats")
+
+    def run_device(self, Y, out, prevY=None):
+        es = 1 if self.bits <= 8 else 2
+        self.ctx.check(self.ctx.lib.amtgpu_framestats_batch(self.h, _p(Y), int(Y.stride(0)) * es, int(Y.stride(1)), _p(prevY), int(Y.shape[0]), _p(out)))
+
+    def run(self, clip: DeviceClip):
+        import torch
+        out = torch.zeros((clip.num_frames, 8), dtype=torch.int64, device=clip.Y.device)
+        self.run_device(clip.Y, out)
+        self.ctx.synchronize()
+        return out.cpu().numpy().astype(np.uint64)
+
+    def scene_changes(self, metrics):
+        m = np.ascontiguousarray(metrics, np.uint64)
+        n = m.shape[0]
+        out = np.zeros(max(1, n), np.int32)
+        k = C.c_int()
+        self.ctx.lib.amtgpu_cm_scene_changes(_p(m), n, self.width, self.height, _p(out), n, C.byref(k))
+        return out[:k.value].copy()
+
+    def cadence(self, metrics):
+        m = np.ascontiguousarray(metrics, np.uint64)
+        n = m.shape[0]
+        cad = np.zeros(n, np.uint8)
+        ph = np.zeros(n, np.uint8)
+        self.ctx.lib.amtgpu_kfm_cadence(_p(m), n, self.width, self.height, _p(cad), _p(ph))
+        return cad, ph
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.amtgpu_framestats_destroy(self.h)
+        except Exception:
+            pass

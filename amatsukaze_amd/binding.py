@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI in include/amt_gpu.h (amatsukaze_amd/libamt_gpu.so).
+
+There is no CPU fallback: if the HIP library is missing or a GPU call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libamt_gpu.so")
+
+c_i, c_f, c_p, c_s = C.c_int, C.c_float, C.c_void_p, C.c_char_p
+c_i64, c_u64 = C.c_int64, C.c_uint64
+CB = C.CFUNCTYPE(c_i, c_f, c_i, c_i, c_i)
+
+# name -> (restype, argtypes); mirrors include/amt_gpu.h one to one
+SIGNATURES = {
+    "amtgpu_abi_version": (c_i, []),
+    "amtgpu_context_create": (c_p, [c_i]),
+    "amtgpu_context_destroy": (None, [c_p]),
+    "amtgpu_last_error": (c_s, [c_p]),
+    "amtgpu_context_set_stream": (c_i, [c_p, c_p]),
+    "amtgpu_context_get_stream": (c_p, [c_p]),
+    "amtgpu_context_synchronize": (c_i, [c_p]),
+    "amtgpu_device_alloc": (c_p, [c_p, c_u64]),
+    "amtgpu_device_free": (None, [c_p, c_p]),
+    "amtgpu_frames_upload": (c_i, [c_p, c_p, c_p, c_u64]),
+    "amtgpu_frames_upload_wait": (c_i, [c_p]),
+    "amtgpu_download": (c_i, [c_p, c_p, c_p, c_u64]),
+    "amtgpu_logo_load": (c_p, [c_p, c_s]),
+    "amtgpu_logo_from_planes": (c_p, [c_p] + [c_i] * 8 + [c_p]),
+    "amtgpu_logo_save": (c_i, [c_p, c_p, c_s, c_s, c_i]),
+    "amtgpu_logo_destroy": (None, [c_p]),
+    "amtgpu_logo_get_info": (c_i, [c_p, c_p]),
+    "amtgpu_logo_get_planes": (c_i, [c_p, c_p]),
+    "amtgpu_logo_mask_tables": (c_i, [c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "amtgpu_logoframe_create": (c_p, [c_p, c_p, c_i, c_f]),
+    "amtgpu_logoframe_create_from_logos": (c_p, [c_p, c_p, c_i, c_f]),
+    "amtgpu_logoframe_destroy": (None, [c_p]),
+    "amtgpu_logoframe_begin": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "amtgpu_logoframe_scan_batch": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i]),
+    "amtgpu_logoframe_get_results": (c_i, [c_p, c_p]),
+    "amtgpu_logoframe_set_results": (c_i, [c_p, c_i, c_i, c_p]),
+    "amtgpu_logoframe_select_logo": (c_i, [c_p, c_i]),
+    "amtgpu_logoframe_write_result": (c_i, [c_p, c_s, c_i]),
+    "amtgpu_logoframe_best_logo": (c_i, [c_p]),
+    "amtgpu_logoframe_logo_ratio": (c_f, [c_p]),
+    "amtgpu_analyze_create": (c_p, [c_p, c_s, c_f]),
+    "amtgpu_analyze_create_from_logo": (c_p, [c_p, c_p, c_f]),
+    "amtgpu_analyze_destroy": (None, [c_p]),
+    "amtgpu_analyze_batch": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "amtgpu_analyze_batch_host": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "amtgpu_erase_create": (c_p, [c_p, c_s, c_s, c_i, c_i]),
+    "amtgpu_erase_create_from_logo": (c_p, [c_p, c_p, c_s, c_i, c_i]),
+    "amtgpu_erase_destroy": (None, [c_p]),
+    "amtgpu_erase_calc_fades": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "amtgpu_erase_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "amtgpu_logoscan_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
+    "amtgpu_logoscan_destroy": (None, [c_p]),
+    "amtgpu_logoscan_add_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "amtgpu_logoscan_nframes": (c_i, [c_p]),
+    "amtgpu_logoscan_get_sums": (c_i, [c_p, c_p, c_p]),
+    "amtgpu_logoscan_set_sums": (c_i, [c_p, c_p, c_p, c_i]),
+    "amtgpu_logoscan_get_logo": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "amtgpu_scanlogo": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
+    "amtgpu_framestats_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
+    "amtgpu_framestats_destroy": (None, [c_p]),
+    "amtgpu_framestats_batch": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_i, c_p]),
+    "amtgpu_cm_scene_changes": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "amtgpu_kfm_cadence": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "amtgpu_kfm_write_durations": (c_i, [c_p, c_p, c_i, c_s, c_p]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """Loads the HIP library; raises if it is absent (the product has no other path)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+    lib = C.CDLL(p)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            f = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        f.restype = res
+        f.argtypes = args
+    if missing:
+        raise RuntimeError("libamt_gpu.so lacks symbols declared in include/amt_gpu.h: " + ", ".join(missing))
+    if path is None:
+        _lib = lib
+    return lib

@@ -1,0 +1,82 @@
+"""Builds the in-tree HIP library (amatsukaze_amd/libamt_gpu.so) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libamt_gpu.so")
+
+SOURCES = [
+    "amt_gpu.hip",
+    "amt_gpu_erase_scan.hip",
+    "amt_gpu_stats.hip",
+    "eval_engine.hip",
+    "eval_kernels.hip",
+    "erase_scan_kernels.hip",
+    "stats_kernels.hip",
+    "logo_model.cpp",
+    "logo_fit.cpp",
+    "decisions.cpp",
+    "stats_decisions.cpp",
+]
+
+# -ffp-contract=off: the reference is built without FMA contraction (MSVC /fp:precise) and its scores
+# feed discontinuous decisions -- the kernels must round exactly where it rounds.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build(srcs) -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [CSRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "amt_gpu.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and not needs_build(srcs):
+        return OUT
+    objs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        newest_dep = max([os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+                         + [os.path.getmtime(s), os.path.getmtime(os.path.join(HERE, "..", "include", "amt_gpu.h"))])
+        if not force and os.path.exists(o) and os.path.getmtime(o) > newest_dep:
+            continue
+        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out.decode(errors='replace')}")
+        if verbose and out:
+            print(out.decode(errors="replace"), file=sys.stderr)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

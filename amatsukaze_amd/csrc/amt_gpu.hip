@@ -1,0 +1,428 @@
+// amt_gpu.hip -- implementation of the C ABI declared in include/amt_gpu.h (part 1: context, ingest,
+// logo model, LogoFrame, AMTAnalyzeLogo).  Parts 2/3 live in amt_gpu_erase_scan.hip / amt_gpu_stats.hip.
+#include "../../include/amt_gpu.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+
+#include "api_common.hpp"
+
+using namespace amt;
+
+extern "C" {
+
+int amtgpu_abi_version(void) { return AMTGPU_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+AmtGpuContext* amtgpu_context_create(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+    AmtGpuContext* c = new AmtGpuContext;
+    c->device = device;
+    try {
+        c->bind();
+        AMT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        AMT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        AMT_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+        for (auto& e : c->slot_free) AMT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->stream = c->own_stream;
+    } catch (const std::exception&) {
+        amtgpu_context_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void amtgpu_context_destroy(AmtGpuContext* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto& e : c->slot_free) if (e) (void)hipEventDestroy(e);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* amtgpu_last_error(const AmtGpuContext* c) { return c ? c->err.c_str() : "no context"; }
+
+int amtgpu_context_set_stream(AmtGpuContext* c, void* s)
+{
+    if (!c) return 0;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 1;
+}
+void* amtgpu_context_get_stream(AmtGpuContext* c) { return c ? (void*)c->stream : nullptr; }
+int amtgpu_context_synchronize(AmtGpuContext* c)
+{
+    return guard(c, [&] { c->bind(); AMT_HIP(hipStreamSynchronize(c->stream)); });
+}
+
+// ---------------------------------------------------------------------------------------------
+// ingest
+// ---------------------------------------------------------------------------------------------
+void* amtgpu_device_alloc(AmtGpuContext* c, uint64_t bytes)
+{
+    void* p = nullptr;
+    if (!guard(c, [&] { c->bind(); AMT_HIP(hipMalloc(&p, bytes)); })) return nullptr;
+    return p;
+}
+void amtgpu_device_free(AmtGpuContext* c, void* p)
+{
+    if (c && p) { (void)hipSetDevice(c->device); (void)hipFree(p); }
+}
+
+// host -> pinned slot (memcpy) -> device (hipMemcpyAsync on the side stream); two slots so that the CPU
+// fills one while the DMA engine drains the other
+int amtgpu_frames_upload(AmtGpuContext* c, void* ddst, const void* hsrc, uint64_t bytes)
+{
+    return guard(c, [&] {
+        c->bind();
+        const size_t slot_bytes = 32u << 20;
+        if (!c->pinned) {
+            AMT_HIP(hipHostMalloc(&c->pinned, slot_bytes * 2, hipHostMallocDefault));
+            c->pinned_bytes = slot_bytes;
+        }
+        uint64_t done = 0;
+        while (done < bytes) {
+            const size_t n = (size_t)std::min<uint64_t>(slot_bytes, bytes - done);
+            const int s = c->next_slot;
+            AMT_HIP(hipEventSynchronize(c->slot_free[s]));
+            uint8_t* stage = (uint8_t*)c->pinned + (size_t)s * slot_bytes;
+            std::memcpy(stage, (const uint8_t*)hsrc + done, n);
+            AMT_HIP(hipMemcpyAsync((uint8_t*)ddst + done, stage, n, hipMemcpyHostToDevice, c->copy_stream));
+            AMT_HIP(hipEventRecord(c->slot_free[s], c->copy_stream));
+            c->next_slot ^= 1;
+            done += n;
+        }
+        AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
+        c->copies_pending = true;
+    });
+}
+
+int amtgpu_frames_upload_wait(AmtGpuContext* c)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (c->copies_pending) { AMT_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0)); c->copies_pending = false; }
+    });
+}
+
+int amtgpu_download(AmtGpuContext* c, void* hdst, const void* dsrc, uint64_t bytes)
+{
+    return guard(c, [&] {
+        c->bind();
+        AMT_HIP(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
+        AMT_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// logo model
+// ---------------------------------------------------------------------------------------------
+AmtGpuLogo* amtgpu_logo_load(AmtGpuContext* c, const char* path)
+{
+    AmtGpuLogo* l = nullptr;
+    guard(c, [&] { l = new AmtGpuLogo{load_lgd(path)}; });
+    return l;
+}
+
+AmtGpuLogo* amtgpu_logo_from_planes(AmtGpuContext* c, int w, int h, int logUVx, int logUVy, int imgw, int imgh,
+                                    int imgx, int imgy, const float* planes)
+{
+    AmtGpuLogo* l = nullptr;
+    guard(c, [&] {
+        if (w <= 0 || h <= 0 || (w & 1) || (h & 1)) throw std::runtime_error("logo size must be positive and even");
+        std::unique_ptr<AmtGpuLogo> n(new AmtGpuLogo);
+        LogoPlanes& P = n->planes;
+        P.w = w; P.h = h; P.logUVx = logUVx; P.logUVy = logUVy; P.imgw = imgw; P.imgh = imgh; P.imgx = imgx; P.imgy = imgy;
+        P.allocate();
+        if (planes) std::memcpy(P.data.data(), planes, P.data.size() * sizeof(float));
+        l = n.release();
+    });
+    return l;
+}
+
+int amtgpu_logo_save(AmtGpuContext* c, const AmtGpuLogo* l, const char* path, const char* name, int serviceId)
+{
+    return guard(c, [&] { save_lgd(l->planes, path, name ? name : "", serviceId); });
+}
+void amtgpu_logo_destroy(AmtGpuLogo* l) { delete l; }
+
+int amtgpu_logo_get_info(const AmtGpuLogo* l, int* o)
+{
+    if (!l || !o) return 0;
+    const LogoPlanes& P = l->planes;
+    o[0] = P.w; o[1] = P.h; o[2] = P.logUVx; o[3] = P.logUVy; o[4] = P.imgw; o[5] = P.imgh; o[6] = P.imgx; o[7] = P.imgy;
+    return 1;
+}
+int amtgpu_logo_get_planes(const AmtGpuLogo* l, float* out)
+{
+    if (!l || !out) return 0;
+    std::memcpy(out, l->planes.data.data(), l->planes.data.size() * sizeof(float));
+    return 1;
+}
+
+int amtgpu_logo_mask_tables(AmtGpuContext* c, const AmtGpuLogo* l, int kind, float maskratio, int* maskpixels, int* count,
+                            float* blackScore, uint8_t* mask, float* kernels, float* scales)
+{
+    return guard(c, [&] {
+        if (kind < 0 || kind > 2) throw std::runtime_error("kind must be 0 (deint), 1 (top) or 2 (bottom)");
+        LogoPlanes E = kind == 0 ? deinterlaced_logo(l->planes) : field_logo(l->planes, kind == 2);
+        MaskTables T = build_mask_tables(E, maskratio);
+        if (maskpixels) *maskpixels = T.maskpixels;
+        if (count) *count = T.count;
+        if (blackScore) *blackScore = T.blackScore;
+        if (mask) std::memcpy(mask, T.mask.data(), T.mask.size());
+        if (kernels) std::memcpy(kernels, T.kernels.data(), T.kernels.size() * sizeof(float));
+        if (scales) std::memcpy(scales, T.scales.data(), T.scales.size() * sizeof(float));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// LogoFrame
+// ---------------------------------------------------------------------------------------------
+struct AmtGpuLogoFrame {
+    AmtGpuContext* ctx;
+    float maskratio;
+    std::vector<std::unique_ptr<LogoPlanes>> logos;    // null = unreadable file
+    // clip
+    int width = 0, height = 0, bits = 8, numFrames = 0, fpsNum = 30000, fpsDen = 1001;
+    std::unique_ptr<EvalEngine> engine;
+    std::vector<int> slotOfEngineLogo;                  // engine logo -> logo index
+    DevBuf<float> dResults;                             // numFrames * nlogos * 2
+    std::vector<float> results;                         // host copy
+    bool hostValid = false;
+    LogoSelection sel;
+    bool selected = false;
+};
+
+static AmtGpuLogoFrame* logoframe_new(AmtGpuContext* c, std::vector<std::unique_ptr<LogoPlanes>> logos, float maskratio)
+{
+    AmtGpuLogoFrame* lf = new AmtGpuLogoFrame;
+    lf->ctx = c;
+    lf->maskratio = maskratio;
+    lf->logos = std::move(logos);
+    return lf;
+}
+
+AmtGpuLogoFrame* amtgpu_logoframe_create(AmtGpuContext* c, const char* const* paths, int nlogos, float maskratio)
+{
+    AmtGpuLogoFrame* lf = nullptr;
+    guard(c, [&] {
+        std::vector<std::unique_ptr<LogoPlanes>> v(nlogos);
+        for (int i = 0; i < nlogos; ++i) {
+            try { v[i].reset(new LogoPlanes(load_lgd(paths[i]))); }
+            catch (const std::exception&) { /* read errors are ignored, the slot scores {0,-1} */ }
+        }
+        lf = logoframe_new(c, std::move(v), maskratio);
+    });
+    return lf;
+}
+
+AmtGpuLogoFrame* amtgpu_logoframe_create_from_logos(AmtGpuContext* c, const AmtGpuLogo* const* logos, int nlogos, float maskratio)
+{
+    AmtGpuLogoFrame* lf = nullptr;
+    guard(c, [&] {
+        std::vector<std::unique_ptr<LogoPlanes>> v(nlogos);
+        for (int i = 0; i < nlogos; ++i) if (logos[i]) v[i].reset(new LogoPlanes(logos[i]->planes));
+        lf = logoframe_new(c, std::move(v), maskratio);
+    });
+    return lf;
+}
+
+void amtgpu_logoframe_destroy(AmtGpuLogoFrame* lf) { delete lf; }
+
+int amtgpu_logoframe_begin(AmtGpuLogoFrame* lf, int width, int height, int bits, int num_frames, int fps_num, int fps_den)
+{
+    return guard(lf->ctx, [&] {
+        if (num_frames < 0 || bits < 8 || bits > 16) throw std::runtime_error("[LogoFrame] Unsupported pixel format");
+        lf->width = width; lf->height = height; lf->bits = bits; lf->numFrames = num_frames;
+        lf->fpsNum = fps_num; lf->fpsDen = fps_den;
+        const int nl = (int)lf->logos.size();
+        std::vector<EvalLogoSpec> specs;
+        lf->slotOfEngineLogo.clear();
+        for (int i = 0; i < nl; ++i) {
+            const LogoPlanes* P = lf->logos[i].get();
+            if (!P || P->imgw != width || P->imgh != height) continue;      // scores {0,-1}
+            if (P->imgx < 0 || P->imgy < 0 || P->imgx + P->w > width || P->imgy + P->h > height)
+                throw std::runtime_error("logo rectangle outside the frame");
+            EvalLogoSpec S;
+            S.planes = deinterlaced_logo(*P);
+            S.tables = build_mask_tables(S.planes, lf->maskratio);
+            S.imgx = P->imgx; S.imgy = P->imgy; S.row0 = 0; S.row_step = 1; S.deint = 1;
+            S.out_off = i * 2;
+            specs.push_back(std::move(S));
+            lf->slotOfEngineLogo.push_back(i);
+        }
+        lf->engine.reset(specs.empty() ? nullptr : new EvalEngine(lf->ctx, std::move(specs), {0.0f, 1.0f}, false, nl * 2));
+        // invalid / mismatching logos keep {corr0, corr1} = {0, -1}
+        lf->results.assign((size_t)num_frames * nl * 2, 0.0f);
+        for (size_t i = 0; i < (size_t)num_frames * nl; ++i) lf->results[i * 2 + 1] = -1.0f;
+        lf->dResults.alloc(std::max<size_t>(1, lf->results.size()));
+        lf->ctx->bind();
+        if (!lf->results.empty())
+            AMT_HIP(hipMemcpyAsync(lf->dResults.get(), lf->results.data(), lf->results.size() * sizeof(float), hipMemcpyHostToDevice, lf->ctx->stream));
+        AMT_HIP(hipStreamSynchronize(lf->ctx->stream));
+        lf->hostValid = true;
+        lf->selected = false;
+    });
+}
+
+int amtgpu_logoframe_scan_batch(AmtGpuLogoFrame* lf, const void* dY, int64_t frame_stride, int pitch, int first, int nframes)
+{
+    return guard(lf->ctx, [&] {
+        if (first < 0 || nframes < 0 || first + nframes > lf->numFrames) throw std::runtime_error("frame range outside the clip");
+        if (!lf->engine || nframes == 0) return;
+        const int nl = (int)lf->logos.size();
+        lf->engine->run(dY, frame_stride, pitch, lf->bits, nframes, lf->dResults.get() + (size_t)first * nl * 2);
+        lf->hostValid = false;
+        lf->selected = false;
+    });
+}
+
+static void logoframe_sync_results(AmtGpuLogoFrame* lf)
+{
+    if (lf->hostValid) return;
+    lf->ctx->bind();
+    if (!lf->results.empty())
+        AMT_HIP(hipMemcpyAsync(lf->results.data(), lf->dResults.get(), lf->results.size() * sizeof(float), hipMemcpyDeviceToHost, lf->ctx->stream));
+    AMT_HIP(hipStreamSynchronize(lf->ctx->stream));
+    lf->hostValid = true;
+}
+
+int amtgpu_logoframe_get_results(AmtGpuLogoFrame* lf, float* out)
+{
+    return guard(lf->ctx, [&] {
+        logoframe_sync_results(lf);
+        std::memcpy(out, lf->results.data(), lf->results.size() * sizeof(float));
+    });
+}
+
+int amtgpu_logoframe_set_results(AmtGpuLogoFrame* lf, int first, int nframes, const float* evals)
+{
+    return guard(lf->ctx, [&] {
+        if (first < 0 || nframes < 0 || first + nframes > lf->numFrames) throw std::runtime_error("frame range outside the clip");
+        logoframe_sync_results(lf);
+        const size_t nl = lf->logos.size();
+        std::memcpy(lf->results.data() + (size_t)first * nl * 2, evals, (size_t)nframes * nl * 2 * sizeof(float));
+        lf->ctx->bind();
+        if (nframes)
+            AMT_HIP(hipMemcpyAsync(lf->dResults.get() + (size_t)first * nl * 2, evals, (size_t)nframes * nl * 2 * sizeof(float),
+                                   hipMemcpyHostToDevice, lf->ctx->stream));
+        AMT_HIP(hipStreamSynchronize(lf->ctx->stream));
+        lf->selected = false;
+    });
+}
+
+int amtgpu_logoframe_select_logo(AmtGpuLogoFrame* lf, int ncand)
+{
+    return guard(lf->ctx, [&] {
+        logoframe_sync_results(lf);
+        lf->sel = select_logo(lf->results.data(), lf->numFrames, (int)lf->logos.size(), ncand);
+        lf->selected = true;
+    });
+}
+
+int amtgpu_logoframe_write_result(AmtGpuLogoFrame* lf, const char* outpath, int logo_index)
+{
+    return guard(lf->ctx, [&] {
+        logoframe_sync_results(lf);
+        if (logo_index < 0) {
+            if (!lf->selected) { lf->sel = select_logo(lf->results.data(), lf->numFrames, (int)lf->logos.size(), -1); lf->selected = true; }
+            logo_index = lf->sel.bestLogo;
+        }
+        if (logo_index < 0 || logo_index >= (int)lf->logos.size()) throw std::runtime_error("logo index out of range");
+        const std::string text = logoframe_text(lf->results.data(), lf->numFrames, (int)lf->logos.size(), logo_index, lf->fpsNum, lf->fpsDen);
+        std::ofstream f(outpath, std::ios::binary);
+        if (!f) throw std::runtime_error(std::string("failed to open file ") + outpath);
+        f.write(text.data(), (std::streamsize)text.size());
+    });
+}
+
+int amtgpu_logoframe_best_logo(const AmtGpuLogoFrame* lf) { return lf->sel.bestLogo; }
+float amtgpu_logoframe_logo_ratio(const AmtGpuLogoFrame* lf) { return lf->sel.logoRatio; }
+
+// ---------------------------------------------------------------------------------------------
+// AMTAnalyzeLogo
+// ---------------------------------------------------------------------------------------------
+struct AmtGpuAnalyze {
+    AmtGpuContext* ctx;
+    LogoPlanes logo;
+    std::unique_ptr<EvalEngine> engine;
+    DevBuf<float> dTmp;
+};
+
+static AmtGpuAnalyze* analyze_new(AmtGpuContext* c, LogoPlanes logo, float maskratio)
+{
+    std::unique_ptr<AmtGpuAnalyze> an(new AmtGpuAnalyze);
+    an->ctx = c;
+    an->logo = std::move(logo);
+    const LogoPlanes& P = an->logo;
+    if (P.h < 12 || P.w < 6) throw std::runtime_error("logo too small");
+    std::vector<EvalLogoSpec> specs(3);
+    for (int kind = 0; kind < 3; ++kind) {
+        EvalLogoSpec& S = specs[kind];
+        S.planes = kind == 0 ? deinterlaced_logo(P) : field_logo(P, kind == 2);
+        S.tables = build_mask_tables(S.planes, maskratio);
+        S.imgx = P.imgx; S.imgy = P.imgy;
+        S.deint = kind == 0;
+        S.row0 = kind == 2 ? 1 : 0;
+        S.row_step = kind == 0 ? 1 : 2;
+        S.out_off = kind * AMTGPU_NUM_FADE;
+    }
+    std::vector<float> fades(AMTGPU_NUM_FADE);
+    for (int f = 0; f < AMTGPU_NUM_FADE; ++f) fades[f] = (float)f / 10.0f;
+    an->engine.reset(new EvalEngine(c, std::move(specs), fades, true, AMTGPU_ANALYZE_FLOATS));
+    return an.release();
+}
+
+AmtGpuAnalyze* amtgpu_analyze_create(AmtGpuContext* c, const char* logopath, float maskratio)
+{
+    AmtGpuAnalyze* an = nullptr;
+    guard(c, [&] {
+        LogoPlanes P;
+        try { P = load_lgd(logopath); }
+        catch (const std::exception&) { throw std::runtime_error(std::string("Failed to read logo file (") + logopath + ")"); }
+        an = analyze_new(c, std::move(P), maskratio);
+    });
+    return an;
+}
+
+AmtGpuAnalyze* amtgpu_analyze_create_from_logo(AmtGpuContext* c, const AmtGpuLogo* logo, float maskratio)
+{
+    AmtGpuAnalyze* an = nullptr;
+    guard(c, [&] { an = analyze_new(c, logo->planes, maskratio); });
+    return an;
+}
+
+void amtgpu_analyze_destroy(AmtGpuAnalyze* an) { delete an; }
+
+int amtgpu_analyze_batch(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* dout)
+{
+    return guard(an->ctx, [&] {
+        if (bits < 8 || bits > 16) throw std::runtime_error("[AMTAnalyzeLogo] Unsupported pixel format");
+        an->engine->run(dY, frame_stride, pitch, bits, nframes, dout);
+    });
+}
+
+int amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* hout)
+{
+    return guard(an->ctx, [&] {
+        if (bits < 8 || bits > 16) throw std::runtime_error("[AMTAnalyzeLogo] Unsupported pixel format");
+        const size_t n = (size_t)nframes * AMTGPU_ANALYZE_FLOATS;
+        if (an->dTmp.size() < n) an->dTmp.alloc(n);
+        an->engine->run(dY, frame_stride, pitch, bits, nframes, an->dTmp.get());
+        an->ctx->bind();
+        if (n) AMT_HIP(hipMemcpyAsync(hout, an->dTmp.get(), n * sizeof(float), hipMemcpyDeviceToHost, an->ctx->stream));
+        AMT_HIP(hipStreamSynchronize(an->ctx->stream));
+    });
+}
+
+} // extern "C"

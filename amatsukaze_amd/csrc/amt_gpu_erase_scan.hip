@@ -1,0 +1,349 @@
+// amt_gpu_erase_scan.hip -- C ABI part 2: AMTEraseLogo, LogoScan, ScanLogo.
+#include "../../include/amt_gpu.h"
+
+#include <cfloat>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+
+#include "api_common.hpp"
+#include "logo_fit.hpp"
+
+namespace amt {
+struct EraseGeom {
+    int w, h, wUV, hUV;
+    int imgx, imgy, cx, cy;
+    int uvparity;
+};
+hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
+                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades);
+hipError_t launch_scan_border(hipStream_t st, int bits, const void* dY, const void* dU, const void* dV, long long strideY,
+                              long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy, int w, int h,
+                              int wUV, int hUV, int thy, int nframes, int4* dout);
+hipError_t launch_scan_accumulate(hipStream_t st, int bits, const void* dY, const void* dU, const void* dV, long long strideY,
+                                  long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy, int w, int h,
+                                  int wUV, int hUV, const int4* daccepted, int naccepted, unsigned long long* dacc);
+}
+
+using namespace amt;
+
+// ---------------------------------------------------------------------------------------------
+// AMTEraseLogo
+// ---------------------------------------------------------------------------------------------
+struct AmtGpuErase {
+    AmtGpuContext* ctx;
+    LogoPlanes logo;
+    std::vector<int> frameState;    // empty = no logoframe file (always analyse)
+    bool haveLogof = false;
+    std::string logofText;
+    int mode = 0, maxFade = 16;
+    DevBuf<float> dPlanes;
+    DevBuf<float2> dFades;
+};
+
+static AmtGpuErase* erase_new(AmtGpuContext* c, LogoPlanes logo, const std::string& logofText, bool haveLogof, int mode, int maxfade)
+{
+    std::unique_ptr<AmtGpuErase> er(new AmtGpuErase);
+    er->ctx = c;
+    er->logo = std::move(logo);
+    er->mode = mode;
+    er->maxFade = maxfade;
+    er->haveLogof = haveLogof;
+    er->logofText = logofText;
+    if (haveLogof) (void)parse_logoframe(logofText, 0);     // report a malformed file at construction, like the filter does
+    c->bind();
+    er->dPlanes.upload(er->logo.data, c->stream);
+    return er.release();
+}
+
+extern "C" {
+
+AmtGpuErase* amtgpu_erase_create(AmtGpuContext* c, const char* logopath, const char* logofpath, int mode, int maxfade)
+{
+    AmtGpuErase* er = nullptr;
+    guard(c, [&] {
+        LogoPlanes P;
+        try { P = load_lgd(logopath); }
+        catch (const std::exception&) { throw std::runtime_error(std::string("Failed to read logo file (") + logopath + ")"); }
+        std::string text;
+        const bool have = logofpath && logofpath[0];
+        if (have) {
+            std::ifstream f(logofpath, std::ios::binary);
+            if (!f) throw std::runtime_error(std::string("Failed to read dat file (") + logofpath + ")");
+            std::stringstream ss;
+            ss << f.rdbuf();
+            text = ss.str();
+        }
+        er = erase_new(c, std::move(P), text, have, mode, maxfade);
+    });
+    return er;
+}
+
+AmtGpuErase* amtgpu_erase_create_from_logo(AmtGpuContext* c, const AmtGpuLogo* logo, const char* logof_text, int mode, int maxfade)
+{
+    AmtGpuErase* er = nullptr;
+    guard(c, [&] {
+        const bool have = logof_text && logof_text[0];
+        er = erase_new(c, logo->planes, have ? logof_text : "", have, mode, maxfade);
+    });
+    return er;
+}
+
+void amtgpu_erase_destroy(AmtGpuErase* er) { delete er; }
+
+int amtgpu_erase_calc_fades(AmtGpuErase* er, const float* analysis, int num_frames, int first, int nframes, float* fades_out)
+{
+    return guard(er->ctx, [&] {
+        if (first < 0 || nframes < 0 || first + nframes > num_frames) throw std::runtime_error("frame range outside the clip");
+        if (er->haveLogof && (int)er->frameState.size() != num_frames) er->frameState = parse_logoframe(er->logofText, num_frames);
+        static const std::vector<int> none;
+        for (int i = 0; i < nframes; ++i) {
+            const FadePair fp = fade_for_frame(er->haveLogof ? er->frameState : none, er->maxFade, analysis, num_frames, first + i);
+            fades_out[2 * i] = fp.top;
+            fades_out[2 * i + 1] = fp.bottom;
+        }
+    });
+}
+
+int amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY,
+                       int pitchUV, int bits, int nframes, const float* fades)
+{
+    return guard(er->ctx, [&] {
+        if (bits < 8 || bits > 16) throw std::runtime_error("[AMTEraseLogo] Unsupported pixel format");
+        if (er->mode != 0) throw std::runtime_error("[AMTEraseLogo] only mode 0 is supported (debug overlay modes are out of scope)");
+        if (nframes <= 0) return;
+        const LogoPlanes& P = er->logo;
+        const int es = bits <= 8 ? 1 : 2;
+        er->ctx->bind();
+        if (er->dFades.size() < (size_t)nframes) er->dFades.alloc(nframes);
+        AMT_HIP(hipMemcpyAsync(er->dFades.get(), fades, (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
+        EraseGeom g;
+        g.w = P.w; g.h = P.h; g.wUV = P.wUV(); g.hUV = P.hUV();
+        g.imgx = P.imgx; g.imgy = P.imgy; g.cx = P.imgx >> P.logUVx; g.cy = P.imgy >> P.logUVy;
+        g.uvparity = (P.imgy / 2) % 2;
+        AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
+                              nframes, er->dFades.get()));
+        // the fades came from pageable host memory: make sure the copy has been consumed before returning
+        AMT_HIP(hipStreamSynchronize(er->ctx->stream));
+    });
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// LogoScan
+// ---------------------------------------------------------------------------------------------
+struct AmtGpuLogoScan {
+    AmtGpuContext* ctx;
+    ScanSums sums;
+    int thy = 0;
+    DevBuf<unsigned long long> dAcc;
+    DevBuf<int4> dVerdict, dAccepted;
+    std::vector<int4> lastVerdicts;      // verdicts of the most recent add_batch (frame-local)
+    bool accDirty = false;               // device accumulators newer than sums.px
+};
+
+static void logoscan_pull(AmtGpuLogoScan* s)
+{
+    if (!s->accDirty) return;
+    s->ctx->bind();
+    AMT_HIP(hipMemcpyAsync(s->sums.px.data(), s->dAcc.get(), s->sums.px.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s->ctx->stream));
+    AMT_HIP(hipStreamSynchronize(s->ctx->stream));
+    s->accDirty = false;
+}
+
+// border verdicts for a batch, then accumulate the accepted subset; returns accepted count
+static int logoscan_add(AmtGpuLogoScan* s, const void* dY, const void* dU, const void* dV, int64_t strideY, int64_t strideUV,
+                        int pitchY, int pitchUV, int bits, int imgx, int imgy, int nframes, int max_valid, const uint8_t* use_mask,
+                        uint8_t* valid_out, const int* frame_ids /* optional: batch slot -> frame index in dY */,
+                        const int4* known_verdicts /* optional: skip the border kernel */)
+{
+    if (bits < 8 || bits > 12) throw std::runtime_error("[LogoScan] 8..12 bit only");
+    const int es = bits <= 8 ? 1 : 2;
+    ScanSums& S = s->sums;
+    const int wUV = S.w >> S.logUVx, hUV = S.h >> S.logUVy;
+    const int cx = imgx >> S.logUVx, cy = imgy >> S.logUVy;
+    s->ctx->bind();
+    std::vector<int4>& v = s->lastVerdicts;
+    if (known_verdicts) {
+        v.assign(known_verdicts, known_verdicts + nframes);
+    } else {
+        if (s->dVerdict.size() < (size_t)nframes) s->dVerdict.alloc(nframes);
+        AMT_HIP(launch_scan_border(s->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, imgx, imgy, cx, cy,
+                                   S.w, S.h, wUV, hUV, s->thy, nframes, s->dVerdict.get()));
+        v.resize(nframes);
+        AMT_HIP(hipMemcpyAsync(v.data(), s->dVerdict.get(), (size_t)nframes * sizeof(int4), hipMemcpyDeviceToHost, s->ctx->stream));
+        AMT_HIP(hipStreamSynchronize(s->ctx->stream));
+    }
+    std::vector<int4> acc;
+    for (int i = 0; i < nframes; ++i) {
+        if (valid_out) valid_out[i] = 0;
+        if ((int)acc.size() >= max_valid) continue;          // stream order: later frames are not even looked at
+        if (use_mask && !use_mask[i]) continue;
+        if (!v[i].x) continue;
+        if (valid_out) valid_out[i] = 1;
+        acc.push_back(make_int4(frame_ids ? frame_ids[i] : i, v[i].y, v[i].z, v[i].w));
+        S.plane[0] += v[i].y; S.plane[1] += (int64_t)v[i].y * v[i].y;
+        S.plane[2] += v[i].z; S.plane[3] += (int64_t)v[i].z * v[i].z;
+        S.plane[4] += v[i].w; S.plane[5] += (int64_t)v[i].w * v[i].w;
+    }
+    if (!acc.empty()) {
+        if (s->dAccepted.size() < acc.size()) s->dAccepted.alloc(acc.size());
+        AMT_HIP(hipMemcpyAsync(s->dAccepted.get(), acc.data(), acc.size() * sizeof(int4), hipMemcpyHostToDevice, s->ctx->stream));
+        AMT_HIP(launch_scan_accumulate(s->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, imgx, imgy, cx, cy,
+                                       S.w, S.h, wUV, hUV, s->dAccepted.get(), (int)acc.size(), s->dAcc.get()));
+        AMT_HIP(hipStreamSynchronize(s->ctx->stream));        // acc (host vector) must outlive the copy
+        s->accDirty = true;
+        S.nframes += (int)acc.size();
+    }
+    return (int)acc.size();
+}
+
+static AmtGpuLogoScan* logoscan_new(AmtGpuContext* c, int w, int h, int logUVx, int logUVy, int thy)
+{
+    if (w <= 0 || h <= 0 || (w & 1) || (h & 1) || logUVx != 1 || logUVy != 1)
+        throw std::runtime_error("[LogoScan] rectangle must be even-sized 4:2:0");
+    std::unique_ptr<AmtGpuLogoScan> s(new AmtGpuLogoScan);
+    s->ctx = c;
+    s->thy = thy;
+    s->sums.w = w; s->sums.h = h; s->sums.logUVx = logUVx; s->sums.logUVy = logUVy;
+    s->sums.px.assign(s->sums.npixels() * 3, 0);
+    c->bind();
+    s->dAcc.alloc(s->sums.px.size());
+    AMT_HIP(hipMemsetAsync(s->dAcc.get(), 0, s->sums.px.size() * sizeof(int64_t), c->stream));
+    AMT_HIP(hipStreamSynchronize(c->stream));
+    return s.release();
+}
+
+extern "C" {
+
+AmtGpuLogoScan* amtgpu_logoscan_create(AmtGpuContext* c, int w, int h, int logUVx, int logUVy, int thy)
+{
+    AmtGpuLogoScan* s = nullptr;
+    guard(c, [&] { s = logoscan_new(c, w, h, logUVx, logUVy, thy); });
+    return s;
+}
+void amtgpu_logoscan_destroy(AmtGpuLogoScan* s) { delete s; }
+
+int amtgpu_logoscan_add_batch(AmtGpuLogoScan* s, const void* dY, const void* dU, const void* dV, int64_t strideY, int64_t strideUV,
+                              int pitchY, int pitchUV, int bits, int imgx, int imgy, int nframes, int max_valid,
+                              const uint8_t* use_mask, uint8_t* valid_out, int* naccepted)
+{
+    return guard(s->ctx, [&] {
+        const int n = logoscan_add(s, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, nframes, max_valid, use_mask,
+                                   valid_out, nullptr, nullptr);
+        if (naccepted) *naccepted = n;
+    });
+}
+
+int amtgpu_logoscan_nframes(const AmtGpuLogoScan* s) { return s->sums.nframes; }
+
+int amtgpu_logoscan_get_sums(AmtGpuLogoScan* s, int64_t* sums, int64_t* plane_sums)
+{
+    return guard(s->ctx, [&] {
+        logoscan_pull(s);
+        if (sums) std::memcpy(sums, s->sums.px.data(), s->sums.px.size() * sizeof(int64_t));
+        if (plane_sums) std::memcpy(plane_sums, s->sums.plane, sizeof s->sums.plane);
+    });
+}
+
+int amtgpu_logoscan_set_sums(AmtGpuLogoScan* s, const int64_t* sums, const int64_t* plane_sums, int nframes)
+{
+    return guard(s->ctx, [&] {
+        std::memcpy(s->sums.px.data(), sums, s->sums.px.size() * sizeof(int64_t));
+        std::memcpy(s->sums.plane, plane_sums, sizeof s->sums.plane);
+        s->sums.nframes = nframes;
+        s->ctx->bind();
+        AMT_HIP(hipMemcpyAsync(s->dAcc.get(), s->sums.px.data(), s->sums.px.size() * sizeof(int64_t), hipMemcpyHostToDevice, s->ctx->stream));
+        AMT_HIP(hipStreamSynchronize(s->ctx->stream));
+        s->accDirty = false;
+    });
+}
+
+AmtGpuLogo* amtgpu_logoscan_get_logo(AmtGpuLogoScan* s, int maxv, int clean, int imgw, int imgh, int imgx, int imgy)
+{
+    AmtGpuLogo* l = nullptr;
+    guard(s->ctx, [&] {
+        logoscan_pull(s);
+        std::unique_ptr<AmtGpuLogo> n(new AmtGpuLogo);
+        if (!fit_logo(s->sums, maxv, clean != 0, n->planes)) throw std::runtime_error("Insufficient logo frames");
+        n->planes.imgw = imgw; n->planes.imgh = imgh; n->planes.imgx = imgx; n->planes.imgy = imgy;
+        l = n.release();
+    });
+    return l;
+}
+
+// LogoAnalyzer::ScanLogo (LogoScan.hpp:1058-1079): initial logo from every flat-bordered frame (stop at
+// numMaxFrames), then twice: evaluate 20 fades per kept frame, re-accumulate only frames whose best fade
+// index is > 8, regress again with clean-up; save.
+int amtgpu_scanlogo(AmtGpuContext* c, const void* dY, const void* dU, const void* dV, int64_t strideY, int64_t strideUV,
+                    int pitchY, int pitchUV, int imgw, int imgh, int nframes, int serviceid, const char* dstpath, int imgx,
+                    int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb)
+{
+    return guard(c, [&] {
+        auto progress = [&](float p, int nread, int total, int ngather) {
+            if (cb && !cb(p, nread, total, ngather)) throw std::runtime_error("Cancel requested");
+        };
+        if (imgx < 0 || imgy < 0 || imgx + w > imgw || imgy + h > imgh) throw std::runtime_error("scan rectangle outside the frame");
+        const int bits = 8;                                   // the reference's scan path is 8-bit only (:813)
+        std::unique_ptr<AmtGpuLogoScan> scan(logoscan_new(c, w, h, 1, 1, thy));
+        // round 0: every frame in stream order until numMaxFrames are kept
+        std::vector<int> kept;              // frame index of every kept frame
+        std::vector<int4> keptVerdict;      // its {1,bgY,bgU,bgV}
+        const int chunk = 4096;
+        for (int f0 = 0; f0 < nframes && (int)kept.size() < numMaxFrames; f0 += chunk) {
+            const int n = std::min(chunk, nframes - f0);
+            std::vector<uint8_t> valid(n);
+            logoscan_add(scan.get(), (const uint8_t*)dY + f0 * strideY, (const uint8_t*)dU + f0 * strideUV, (const uint8_t*)dV + f0 * strideUV,
+                         strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, n, numMaxFrames - (int)kept.size(), nullptr, valid.data(),
+                         nullptr, nullptr);
+            for (int i = 0; i < n; ++i)
+                if (valid[i]) { kept.push_back(f0 + i); keptVerdict.push_back(scan->lastVerdicts[i]); }
+            progress(50.0f * (f0 + n) / std::max(1, nframes), f0 + n, 0, (int)kept.size());
+        }
+        const int numFrames = (int)kept.size();
+        std::unique_ptr<AmtGpuLogo> logo(amtgpu_logoscan_get_logo(scan.get(), 255, 0, imgw, imgh, imgx, imgy));
+        if (!logo) throw std::runtime_error(c->err);
+
+        DevBuf<int> dMap;
+        if (numFrames) dMap.upload(kept, c->stream);
+        std::vector<float> fades(20);
+        for (int fi = 0; fi < 20; ++fi) fades[fi] = 0.1f * fi;
+        DevBuf<float> dEval((size_t)std::max(1, numFrames) * 20);
+        std::vector<float> hEval((size_t)numFrames * 20);
+        for (int round = 0; round < 2; ++round) {
+            EvalLogoSpec S;
+            S.planes = deinterlaced_logo(logo->planes);
+            S.tables = build_mask_tables(S.planes, 0.1f);
+            S.imgx = imgx; S.imgy = imgy; S.row0 = 0; S.row_step = 1; S.deint = 1; S.out_off = 0;
+            std::vector<EvalLogoSpec> specs;
+            specs.push_back(std::move(S));
+            EvalEngine eng(c, std::move(specs), fades, true, 20);
+            std::vector<uint8_t> use(numFrames, 0);
+            if (numFrames) {
+                eng.run(dY, strideY, pitchY, bits, numFrames, dEval.get(), dMap.get());
+                AMT_HIP(hipMemcpyAsync(hEval.data(), dEval.get(), hEval.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                AMT_HIP(hipStreamSynchronize(c->stream));
+            }
+            for (int i = 0; i < numFrames; ++i) {
+                float best = FLT_MAX;
+                int bestIdx = 0;
+                for (int fi = 0; fi < 20; ++fi)
+                    if (hEval[(size_t)i * 20 + fi] < best) { best = hEval[(size_t)i * 20 + fi]; bestIdx = fi; }
+                use[i] = bestIdx > 8;                       // logo clearly present in this frame
+            }
+            progress(50.0f + 25.0f * round + 12.5f, numFrames, numFrames, numFrames);
+            std::unique_ptr<AmtGpuLogoScan> rescan(logoscan_new(c, w, h, 1, 1, thy));
+            if (numFrames)
+                logoscan_add(rescan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, numFrames, numFrames,
+                             use.data(), nullptr, kept.data(), keptVerdict.data());
+            logo.reset(amtgpu_logoscan_get_logo(rescan.get(), 255, 1, imgw, imgh, imgx, imgy));
+            if (!logo) throw std::runtime_error(c->err);
+        }
+        progress(1, numFrames, numFrames, numFrames);
+        save_lgd(logo->planes, dstpath, "No Name", serviceid);
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,74 @@
+// amt_gpu_stats.hip -- C ABI part 3: self-specified whole-frame metrics and their host decisions.
+#include "../../include/amt_gpu.h"
+
+#include <cstdio>
+#include <cstring>
+
+#include "api_common.hpp"
+#include "stats_decisions.hpp"
+
+namespace amt {
+hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long long frame_stride_bytes, int pitch_elems, int W,
+                              int H, const void* dprevY, int nframes, unsigned long long* dout);
+}
+using namespace amt;
+
+struct AmtGpuFrameStats {
+    AmtGpuContext* ctx;
+    int width, height, bits;
+};
+
+extern "C" {
+
+AmtGpuFrameStats* amtgpu_framestats_create(AmtGpuContext* c, int width, int height, int bits, int t1, int t2)
+{
+    AmtGpuFrameStats* fs = nullptr;
+    guard(c, [&] {
+        (void)t1; (void)t2;     // reserved for thresholded variants of the metrics
+        if (width <= 0 || height < 4 || bits < 8 || bits > 15) throw std::runtime_error("[FrameStats] unsupported frame format");
+        fs = new AmtGpuFrameStats{c, width, height, bits};
+    });
+    return fs;
+}
+void amtgpu_framestats_destroy(AmtGpuFrameStats* fs) { delete fs; }
+
+int amtgpu_framestats_batch(AmtGpuFrameStats* fs, const void* dY, int64_t frame_stride, int pitch, const void* dprevY, int nframes,
+                            uint64_t* dout)
+{
+    return guard(fs->ctx, [&] {
+        fs->ctx->bind();
+        AMT_HIP(launch_frame_stats(fs->ctx->stream, fs->bits, dY, frame_stride, pitch, fs->width, fs->height, dprevY, nframes,
+                                   (unsigned long long*)dout));
+    });
+}
+
+int amtgpu_cm_scene_changes(const uint64_t* metrics, int nframes, int width, int height, int* sc_out, int cap, int* nsc)
+{
+    try {
+        const std::vector<int> sc = scene_changes(metrics, nframes, width, height);
+        if (nsc) *nsc = (int)sc.size();
+        for (int i = 0; i < (int)sc.size() && i < cap; ++i) sc_out[i] = sc[i];
+        return (int)sc.size() <= cap ? 1 : 0;
+    } catch (...) { return 0; }
+}
+
+int amtgpu_kfm_cadence(const uint64_t* metrics, int nframes, int width, int height, uint8_t* cadence_out, uint8_t* phase_out)
+{
+    try { classify_cadence(metrics, nframes, width, height, cadence_out, phase_out); return 1; }
+    catch (...) { return 0; }
+}
+
+int amtgpu_kfm_write_durations(const uint8_t* cadence, const uint8_t* phase, int nframes, const char* path, int* nout)
+{
+    try {
+        const std::vector<int> d = cadence_durations(cadence, phase, nframes);
+        FILE* fp = std::fopen(path, "w");
+        if (!fp) return 0;
+        for (int v : d) std::fprintf(fp, "%d\n", v);
+        std::fclose(fp);
+        if (nout) *nout = (int)d.size();
+        return 1;
+    } catch (...) { return 0; }
+}
+
+} // extern "C"

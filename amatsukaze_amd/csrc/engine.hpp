@@ -1,0 +1,110 @@
+// engine.hpp -- host runtime around the kernels: context, device buffers, evaluation engine.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "eval_plan.h"
+#include "logo_model.hpp"
+
+#define AMT_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct AmtGpuContext {
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute stream (own or borrowed)
+    hipStream_t own_stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // side stream for ingest
+    hipEvent_t copy_done = nullptr;
+    bool copies_pending = false;
+    void* pinned = nullptr;             // pinned staging ring (2 slots)
+    size_t pinned_bytes = 0;
+    hipEvent_t slot_free[2] = {nullptr, nullptr};
+    int next_slot = 0;
+    std::string err;
+
+    void bind() const { AMT_HIP(hipSetDevice(device)); }
+};
+
+namespace amt {
+
+template <typename T> class DevBuf {
+    T* p_ = nullptr;
+    size_t n_ = 0;
+public:
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { alloc(n); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void alloc(size_t n) { release(); if (n) { AMT_HIP(hipMalloc((void**)&p_, n * sizeof(T))); n_ = n; } }
+    void release() { if (p_) { (void)hipFree(p_); p_ = nullptr; n_ = 0; } }
+    void upload(const T* h, size_t n, hipStream_t st) { if (n > n_) alloc(n); if (n) { AMT_HIP(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, st)); AMT_HIP(hipStreamSynchronize(st)); } }
+    void upload(const std::vector<T>& h, hipStream_t st) { upload(h.data(), h.size(), st); }
+    T* get() const { return p_; }
+    size_t size() const { return n_; }
+};
+
+// one evaluation logo + where its source pixels come from
+struct EvalLogoSpec {
+    LogoPlanes planes;       // evaluation logo (deinterlaced, or one field)
+    MaskTables tables;
+    int imgx = 0, imgy = 0;  // rectangle origin in the full frame
+    int row0 = 0, row_step = 1, deint = 1;
+    int out_off = 0;         // float offset in a frame's output record
+};
+
+// Evaluates `fades.size()` blends of every logo on every frame of a device batch:
+// out[frame*out_frame_stride + spec.out_off + f] = (|.|) CorrelationScore / blackScore.
+class EvalEngine {
+public:
+    EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std::vector<float> fades, bool take_abs, int out_frame_stride);
+    // async on ctx->stream; dout device, nframes*out_frame_stride floats
+    // dframe_map (device, optional): batch frame i reads source frame dframe_map[i] of dY
+    void run(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout,
+             const int* dframe_map = nullptr);
+    int num_logos() const { return (int)specs_.size(); }
+    const EvalLogoSpec& spec(int i) const { return specs_[i]; }
+    // flops / bytes bookkeeping for the bench (algorithmic, per frame)
+    double mask_pixel_evals_per_frame() const;
+    long long scratch_floats_per_frame() const { return scores_per_frame_; }
+
+private:
+    AmtGpuContext* ctx_;
+    std::vector<EvalLogoSpec> specs_;
+    std::vector<float> fades_;
+    bool take_abs_;
+    int out_frame_stride_;
+    int plane_cap_ = 0;
+    long long scores_per_frame_ = 0;
+    int chunk_frames_ = 0;
+    std::vector<EvalBand> bands_;
+    // device state
+    std::vector<DevBuf<float>> d_a_, d_b_, d_kern_;
+    std::vector<DevBuf<uint32_t>> d_pos_;
+    std::vector<DevBuf<float2>> d_scales_;
+    DevBuf<EvalLogoDev> d_logos_;
+    DevBuf<EvalBand> d_bands_;
+    DevBuf<float> d_fades_;
+    DevBuf<float> d_scratch_;
+};
+
+// kernel launchers (eval_kernels.hip)
+size_t corr_lds_bytes(int plane_cap);
+hipError_t launch_logo_corr(hipStream_t st, int bits, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
+                            const float* dfades, int nfades, const void* dY, const int* dframe_map, long long frame_stride_elems,
+                            int pitch, int nframes, float* dscores, long long scores_per_frame, int plane_cap);
+hipError_t launch_ordered_sum(hipStream_t st, const EvalLogoDev* dlogos, int nlogos, int nfades, int nframes,
+                              const float* dscores, long long scores_per_frame, float* dout, int out_frame_stride, int take_abs);
+
+} // namespace amt

@@ -1,0 +1,255 @@
+// erase_scan_kernels.hip -- logo erase (Delogo) and logo generation (LogoScan accumulate) kernels.
+//
+// Both are elementwise / reduction passes over the logo rectangle only (w*h luma + 2*wUV*hUV chroma
+// samples per frame): HBM-bound, a few ops per byte.  One workgroup row = one rectangle row so that a
+// wave reads/writes one contiguous run of the frame; frames and rows give >> 256 workgroups.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "exact_math.h"
+
+namespace amt {
+
+// ------------------------------------------------------------------------------------------------
+// AMTEraseLogo::Delogo (LogoScan.hpp:1248-1261) applied as GetFrameT mode 0 does (:1374-1397):
+// frame mode when fadeT == fadeB, otherwise per field with chroma row parity (imgy/2)%2.  In field mode
+// the reference processes hUV/2 chroma rows per field, so an odd last chroma row is left untouched.
+// ------------------------------------------------------------------------------------------------
+struct EraseGeom {
+    int w, h, wUV, hUV;
+    int imgx, imgy, cx, cy;       // rectangle origin in luma / chroma planes
+    int uvparity;
+};
+
+template <typename pix_t>
+__global__ __launch_bounds__(256)
+void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restrict__ V, long long strideY,
+                   long long strideUV, int pitchY, int pitchUV, const float* __restrict__ planes, EraseGeom g,
+                   float maxv, const float2* __restrict__ fades)
+{
+    const int frame = blockIdx.y;
+    const int r = blockIdx.x;
+    const float2 fd = fades[frame];
+    const bool frameMode = fd.x == fd.y;
+    const size_t ysz = (size_t)g.w * g.h, csz = (size_t)g.wUV * g.hUV;
+    pix_t* row;
+    const float *A, *B;
+    int roww, y;
+    float fade;
+    if (r < g.h) {
+        y = r; roww = g.w;
+        row = Y + (long long)frame * strideY + (long long)(g.imgy + y) * pitchY + g.imgx;
+        A = planes + (size_t)y * g.w; B = planes + ysz + (size_t)y * g.w;
+        fade = frameMode ? fd.x : ((y & 1) ? fd.y : fd.x);
+    } else {
+        const int pl = (r - g.h) >= g.hUV ? 1 : 0;
+        y = r - g.h - pl * g.hUV; roww = g.wUV;
+        if (!frameMode && y >= 2 * (g.hUV / 2)) return;
+        row = (pl ? V : U) + (long long)frame * strideUV + (long long)(g.cy + y) * pitchUV + g.cx;
+        const float* base = planes + 2 * ysz + (size_t)pl * 2 * csz;
+        A = base + (size_t)y * g.wUV; B = base + csz + (size_t)y * g.wUV;
+        fade = frameMode ? fd.x : (((y & 1) == g.uvparity) ? fd.x : fd.y);
+    }
+    for (int x = threadIdx.x; x < roww; x += blockDim.x) {
+        const float s = (float)row[x];
+        const float bg = unblend_bg(A[x], B[x], maxv, s);
+        const float t = fade_mix(fade, bg, s) + 0.5f;
+        const float lo = (t < 0.0f) ? 0.0f : t;            // std::max(t, 0.0f)
+        const float hi = (maxv < lo) ? maxv : lo;          // std::min(lo, maxv)
+        row[x] = (pix_t)hi;
+    }
+}
+
+hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
+                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades)
+{
+    if (nframes <= 0) return hipSuccess;
+    dim3 grid((unsigned)(g.h + 2 * g.hUV), (unsigned)nframes), block(256);
+    const float maxv = (float)((1 << bits) - 1);
+    if (bits <= 8)
+        hipLaunchKernelGGL(delogo_kernel<uint8_t>, grid, block, 0, st, (uint8_t*)dY, (uint8_t*)dU, (uint8_t*)dV, strideY,
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades);
+    else
+        hipLaunchKernelGGL(delogo_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)dY, (uint16_t*)dU, (uint16_t*)dV, strideY,
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LogoScan::AddFrame, first half (LogoScan.hpp:604-653): the rectangle's border samples of each plane,
+// reject when max-min > thy, else background = med_average (:414-428) = (int)((sum of the middle half of
+// the sorted samples + nn/2) / nn).  Sorting is replaced by a histogram (exact: the sorted sequence is
+// the histogram read out in order).  One workgroup per frame.
+// out[frame] = {valid, bgY, bgU, bgV}
+// ------------------------------------------------------------------------------------------------
+constexpr int kBorderThreads = 256;
+
+template <typename pix_t>
+__device__ void border_plane(const pix_t* __restrict__ p, int pitch, int w, int h, int nbins, int* hist,
+                             long long* red, int* redi, int& vmin, int& vmax, int& bg)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nbins; i += kBorderThreads) hist[i] = 0;
+    __syncthreads();
+    for (int x = tid; x < w; x += kBorderThreads) {
+        atomicAdd(&hist[p[x]], 1);
+        atomicAdd(&hist[p[x + (long long)(h - 1) * pitch]], 1);
+    }
+    for (int y = 1 + tid; y < h - 1; y += kBorderThreads) {
+        atomicAdd(&hist[p[(long long)y * pitch]], 1);
+        atomicAdd(&hist[p[w - 1 + (long long)y * pitch]], 1);
+    }
+    __syncthreads();
+    const int n = 2 * w + 2 * (h - 2);
+    const int lo = n / 4, hi = n - n / 4;
+    // each thread owns nbins/256 consecutive bins; exclusive prefix of the per-thread counts through LDS
+    const int per = (nbins + kBorderThreads - 1) / kBorderThreads;
+    const int b0 = tid * per, b1 = min(nbins, b0 + per);
+    int cnt = 0;
+    for (int b = b0; b < b1; ++b) cnt += hist[b];
+    redi[tid] = cnt;
+    __syncthreads();
+    int before = 0;
+    for (int t = 0; t < tid; ++t) before += redi[t];
+    long long part = 0;
+    int mn = 0x7FFFFFFF, mx = -1;
+    int cum = before;
+    for (int b = b0; b < b1; ++b) {
+        const int c = hist[b];
+        if (c) {
+            mn = min(mn, b);
+            mx = max(mx, b);
+            const int s = max(cum, lo), e = min(cum + c, hi);
+            if (e > s) part += (long long)(e - s) * b;
+        }
+        cum += c;
+    }
+    __syncthreads();
+    red[tid] = part;
+    redi[tid] = mn;
+    redi[kBorderThreads + tid] = mx;
+    __syncthreads();
+    for (int s = kBorderThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[tid] += red[tid + s];
+            redi[tid] = min(redi[tid], redi[tid + s]);
+            redi[kBorderThreads + tid] = max(redi[kBorderThreads + tid], redi[kBorderThreads + tid + s]);
+        }
+        __syncthreads();
+    }
+    vmin = redi[0];
+    vmax = redi[kBorderThreads];
+    const int nn = hi - lo;
+    double t = (double)red[0];
+    t = (t + nn / 2) / nn;
+    bg = (int)t;
+    __syncthreads();
+}
+
+template <typename pix_t>
+__global__ __launch_bounds__(kBorderThreads)
+void scan_border_kernel(const pix_t* __restrict__ Y, const pix_t* __restrict__ U, const pix_t* __restrict__ V,
+                        long long strideY, long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy,
+                        int w, int h, int wUV, int hUV, int nbins, int thy, int4* __restrict__ out)
+{
+    extern __shared__ int sh[];
+    int* hist = sh;                                        // nbins
+    int* redi = hist + nbins;                              // 2*256
+    long long* red = (long long*)(redi + 2 * kBorderThreads);   // 256 (8-byte aligned: nbins is a multiple of 2)
+    const int frame = blockIdx.x;
+    int mn, mx, bgY, bgU, bgV;
+    bool ok = true;
+    border_plane(Y + (long long)frame * strideY + (long long)imgy * pitchY + imgx, pitchY, w, h, nbins, hist, red, redi, mn, mx, bgY);
+    ok = ok && (abs(mn - mx) <= thy);
+    border_plane(U + (long long)frame * strideUV + (long long)cy * pitchUV + cx, pitchUV, wUV, hUV, nbins, hist, red, redi, mn, mx, bgU);
+    ok = ok && (abs(mn - mx) <= thy);
+    border_plane(V + (long long)frame * strideUV + (long long)cy * pitchUV + cx, pitchUV, wUV, hUV, nbins, hist, red, redi, mn, mx, bgV);
+    ok = ok && (abs(mn - mx) <= thy);
+    if (threadIdx.x == 0) out[frame] = make_int4(ok ? 1 : 0, bgY, bgU, bgV);
+}
+
+hipError_t launch_scan_border(hipStream_t st, int bits, const void* dY, const void* dU, const void* dV, long long strideY,
+                              long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy, int w, int h,
+                              int wUV, int hUV, int thy, int nframes, int4* dout)
+{
+    if (nframes <= 0) return hipSuccess;
+    const int nbins = 1 << bits;
+    const size_t lds = (size_t)nbins * 4 + 2 * kBorderThreads * 4 + kBorderThreads * 8;
+    dim3 grid((unsigned)nframes), block(kBorderThreads);
+    if (bits <= 8)
+        hipLaunchKernelGGL(scan_border_kernel<uint8_t>, grid, block, lds, st, (const uint8_t*)dY, (const uint8_t*)dU,
+                           (const uint8_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, nbins, thy, dout);
+    else
+        hipLaunchKernelGGL(scan_border_kernel<uint16_t>, grid, block, lds, st, (const uint16_t*)dY, (const uint16_t*)dU,
+                           (const uint16_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, nbins, thy, dout);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LogoScan::AddScanFrame (LogoScan.hpp:568-592) over the accepted frames of a batch.  The reference
+// keeps five double sums per pixel; F, F*F and F*B of integer samples are exact integers, so int64
+// accumulation gives the same values in any order (and lets shards be all-reduced exactly).  sumB and
+// sumB2 are per-plane constants of the accepted set and are kept by the host.
+// acc: 3 int64 per pixel {sumF, sumF2, sumFB}; pixels = Y rows, then U rows, then V rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAccFramesPerBlock = 32;
+
+template <typename pix_t>
+__global__ __launch_bounds__(256)
+void scan_accumulate_kernel(const pix_t* __restrict__ Y, const pix_t* __restrict__ U, const pix_t* __restrict__ V,
+                            long long strideY, long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy,
+                            int w, int h, int wUV, int hUV, const int4* __restrict__ accepted /* {frame, bgY, bgU, bgV} */,
+                            int naccepted, unsigned long long* __restrict__ acc)
+{
+    const int r = blockIdx.x;
+    const int g0 = blockIdx.y * kAccFramesPerBlock;
+    const int g1 = min(naccepted, g0 + kAccFramesPerBlock);
+    const pix_t* base;
+    long long stride;
+    int roww, pl;
+    size_t pix0;
+    if (r < h) {
+        pl = 0; roww = w; stride = strideY;
+        base = Y + (long long)(imgy + r) * pitchY + imgx;
+        pix0 = (size_t)r * w;
+    } else {
+        pl = (r - h) >= hUV ? 2 : 1;
+        const int y = r - h - (pl - 1) * hUV;
+        roww = wUV; stride = strideUV;
+        base = (pl == 1 ? U : V) + (long long)(cy + y) * pitchUV + cx;
+        pix0 = (size_t)w * h + (size_t)(pl - 1) * wUV * hUV + (size_t)y * wUV;
+    }
+    for (int x = threadIdx.x; x < roww; x += blockDim.x) {
+        long long sF = 0, sF2 = 0, sFB = 0;
+#pragma unroll 4
+        for (int i = g0; i < g1; ++i) {
+            const int4 a = accepted[i];
+            const int f = base[(long long)a.x * stride + x];
+            const int b = pl == 0 ? a.y : (pl == 1 ? a.z : a.w);
+            sF += f;
+            sF2 += f * f;
+            sFB += f * b;
+        }
+        unsigned long long* o = acc + (pix0 + x) * 3;
+        atomicAdd(o + 0, (unsigned long long)sF);
+        atomicAdd(o + 1, (unsigned long long)sF2);
+        atomicAdd(o + 2, (unsigned long long)sFB);
+    }
+}
+
+hipError_t launch_scan_accumulate(hipStream_t st, int bits, const void* dY, const void* dU, const void* dV, long long strideY,
+                                  long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy, int w, int h,
+                                  int wUV, int hUV, const int4* daccepted, int naccepted, unsigned long long* dacc)
+{
+    if (naccepted <= 0) return hipSuccess;
+    dim3 grid((unsigned)(h + 2 * hUV), (unsigned)((naccepted + kAccFramesPerBlock - 1) / kAccFramesPerBlock)), block(256);
+    if (bits <= 8)
+        hipLaunchKernelGGL(scan_accumulate_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)dY, (const uint8_t*)dU,
+                           (const uint8_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, daccepted, naccepted, dacc);
+    else
+        hipLaunchKernelGGL(scan_accumulate_kernel<uint16_t>, grid, block, 0, st, (const uint16_t*)dY, (const uint16_t*)dU,
+                           (const uint16_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, daccepted, naccepted, dacc);
+    return hipGetLastError();
+}
+
+} // namespace amt

@@ -1,0 +1,219 @@
+// eval_kernels.hip -- logo correlation on CDNA4 (gfx950).
+//
+// Replaces the inner loops of LogoDataParam::EvaluateLogo / CorrelationScore (LogoScan.hpp:231-255,
+// 288-318) + DeintY / CopyY (:763-790) as they are driven by LogoFrame::ScanFrame (:1543-1568),
+// AMTAnalyzeLogo::GetFrameT (:1119-1161) and LogoAnalyzer::ReMakeLogo (:955-982).
+//
+// Shape of the work: every mask pixel m of an evaluation logo owns a private 25-tap kernel k_m and is
+// evaluated on `nfades` blends of every frame.  There is no operand reuse across m (not a GEMM, no
+// MFMA); the reuse that exists is k_m across fades and the 5x5 windows overlapping in the rectangle.
+// So: one workgroup = (frame, band of <= 1024 raster-consecutive mask pixels); each thread keeps the
+// kernels of its <= 4 mask pixels in VGPRs for all fades, the unblended rectangle rows of the band live
+// in LDS (double buffered per fade, one barrier per fade), the source pixels and their background
+// estimate stay in registers between fades.  fp32 VALU-bound, ~115 non-fusable ops per mask pixel per
+// fade; the per-pixel order of operations is the reference's (exact_math.h).
+//
+// The cross-pixel sum is sequential in the reference (result += score, raster order).  To return the
+// reference's bits rather than a re-associated sum, per-pixel terms go to a scratch row and
+// ordered_sum_kernel adds each row front to back, 64 rows per wave (transposed through LDS so that the
+// global reads stay coalesced).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "eval_plan.h"
+#include "exact_math.h"
+
+namespace amt {
+
+// per-thread staged-pixel budget: plane floats <= kEvalThreads * kStagePerThread
+constexpr int kStagePerThread = 16;
+
+template <typename pix_t, int PXT>
+__global__ __launch_bounds__(kEvalThreads)
+void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands,
+                      int nbands, int nbands8, const float* __restrict__ fades, int nfades,
+                      const pix_t* __restrict__ Y, const int* __restrict__ frame_map, long long frame_stride, int pitch,
+                      float maxv, float* __restrict__ scores, long long scores_per_frame, int plane_cap)
+{
+    extern __shared__ float lds[];                 // W0[plane_cap], W1[plane_cap]
+    // XCD-aware block -> (frame, band): blocks are dealt to XCDs round-robin (b % 8), so band slot
+    // (b % 8) + 8*k keeps every band's tables (kernels, scales: ~350 B per mask pixel) in ONE XCD's L2.
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int j = id >> 3;
+    const int slot = j % nbands8;
+    const int frame = j / nbands8;
+    const int band = slot * 8 + xcd;
+    if (band >= nbands) return;
+
+    const EvalBand B = bands[band];
+    const EvalLogoDev L = logos[B.logo];
+    const int tid = threadIdx.x;
+    const int w = L.w;
+    const int lp = L.lp;                           // LDS row pitch: rows 8 banks apart
+    const int nplane = B.nrows * lp;
+
+    // ---- stage: source pixel s and background estimate bg = a*s + b*maxv, kept in registers ----
+    float sreg[kStagePerThread], bgreg[kStagePerThread];
+    {
+        const int srcFrame = frame_map ? frame_map[frame] : frame;      // optional gather of non-contiguous frames
+        const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
+#pragma unroll
+        for (int q = 0; q < kStagePerThread; ++q) {
+            const int i = tid + q * kEvalThreads;
+            float s = 0.0f, bg = 0.0f;
+            if (i < nplane) {
+                const int r = (int)__umulhi((unsigned)i, L.lp_magic);   // i / lp
+                const int x = i - r * lp;
+                if (x < w) {
+                    const int y = B.y0 + r;
+                    if (L.deint) {
+                        if (y == 0 || y == L.h - 1) {
+                            s = (float)src[x + (long long)y * pitch];
+                        } else {
+                            const int p0 = src[x + (long long)(y - 1) * pitch];
+                            const int p1 = src[x + (long long)y * pitch];
+                            const int p2 = src[x + (long long)(y + 1) * pitch];
+                            s = (float)(p0 + 2 * p1 + p2 + 2) / 4.0f;
+                        }
+                    } else {
+                        s = (float)src[x + (long long)(y * L.row_step) * pitch];
+                    }
+                    const float a = L.a[x + y * w];
+                    const float b = L.b[x + y * w];
+                    bg = unblend_bg(a, b, maxv, s);
+                }
+            }
+            sreg[q] = s;
+            bgreg[q] = bg;
+        }
+    }
+
+    // ---- this thread's mask pixels: kernel taps in registers for the whole fade loop ----
+    float k[PXT][25];
+    int woff[PXT];
+    int midx[PXT];
+    bool act[PXT];
+#pragma unroll
+    for (int p = 0; p < PXT; ++p) {
+        const int local = p * kEvalThreads + tid;
+        act[p] = local < B.npx;
+        const int m = B.m0 + (act[p] ? local : 0);
+        midx[p] = m;
+        const uint32_t ps = L.pos[m];
+        const int x = ps & 0xFFFF, y = ps >> 16;
+        woff[p] = (y - 2 - B.y0) * lp + (x - 2);
+#pragma unroll
+        for (int t = 0; t < 25; ++t) k[p][t] = L.kern[(long long)t * L.count_pad + m];
+    }
+
+    float* wbuf0 = lds;
+    float* wbuf1 = lds + plane_cap;
+    auto mix = [&](float* dst, float fade) {
+        const float omf = 1 - fade;
+#pragma unroll
+        for (int q = 0; q < kStagePerThread; ++q) {
+            const int i = tid + q * kEvalThreads;
+            if (i < nplane) dst[i] = fade * bgreg[q] + omf * sreg[q];
+        }
+    };
+
+    mix(wbuf0, fades[0]);
+    __syncthreads();
+    float* out = scores + (long long)frame * scores_per_frame + L.score_off;
+    for (int f = 0; f < nfades; ++f) {
+        const float* cur = (f & 1) ? wbuf1 : wbuf0;
+        float* nxt = (f & 1) ? wbuf0 : wbuf1;
+        if (f + 1 < nfades) mix(nxt, fades[f + 1]);
+#pragma unroll
+        for (int p = 0; p < PXT; ++p) {
+            if (act[p]) {
+                float v[5][5];
+#pragma unroll
+                for (int r = 0; r < 5; ++r)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) v[r][c] = cur[woff[p] + r * lp + c];
+                float mean;
+                const float corr = corr5x5(k[p], v, &mean);
+                const float2 sl = L.scales[(long long)score_bin(mean) * L.count_pad + midx[p]];
+                out[(long long)f * L.count_pad + midx[p]] = score_term(corr, sl.x, sl.y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Sequential (reference-order) sum of each score row; 64 rows per wave.
+// rows of one logo: row e = frame*nfades + f, at scores + frame*scores_per_frame + score_off + f*count_pad
+__global__ __launch_bounds__(64)
+void ordered_sum_kernel(const EvalLogoDev* __restrict__ logos, int nfades, int nframes,
+                        const float* __restrict__ scores, long long scores_per_frame,
+                        float* __restrict__ out, int out_frame_stride, int take_abs)
+{
+    __shared__ float tile[64][65];
+    __shared__ long long rowoff[64];
+    const EvalLogoDev L = logos[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int nrows = nframes * nfades;
+    const int row = blockIdx.x * 64 + lane;
+    const int crow = row < nrows ? row : nrows - 1;
+    const int frame = crow / nfades, f = crow - frame * nfades;
+    rowoff[lane] = (long long)frame * scores_per_frame + L.score_off + (long long)f * L.count_pad;
+    __syncthreads();
+
+    float acc = 0;
+    for (int c0 = 0; c0 < L.count; c0 += 64) {
+        const int ncol = min(64, L.count - c0);
+        if (lane < ncol) {
+#pragma unroll 16
+            for (int r = 0; r < 64; ++r) tile[r][lane] = scores[rowoff[r] + c0 + lane];
+        }
+        __syncthreads();
+        if (ncol == 64) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) acc += tile[lane][c];
+        } else {
+            for (int c = 0; c < ncol; ++c) acc += tile[lane][c];
+        }
+        __syncthreads();
+    }
+    if (row < nrows) {
+        float r = acc / L.blackScore;
+        if (take_abs) r = fabsf(r);
+        out[(long long)frame * out_frame_stride + L.out_off + f] = r;
+    }
+}
+
+// ---- launch helpers (called from the host engine) ----
+size_t corr_lds_bytes(int plane_cap) { return (size_t)plane_cap * 2 * sizeof(float); }
+
+hipError_t launch_logo_corr(hipStream_t st, int bits, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
+                            const float* dfades, int nfades, const void* dY, const int* dframe_map, long long frame_stride_elems,
+                            int pitch, int nframes, float* dscores, long long scores_per_frame, int plane_cap)
+{
+    const int nbands8 = (nbands + 7) / 8;
+    const long long nblocks = (long long)nframes * nbands8 * 8;
+    if (nblocks <= 0) return hipSuccess;
+    const float maxv = (float)((1 << bits) - 1);
+    dim3 grid((unsigned)nblocks), block(kEvalThreads);
+    const size_t lds = corr_lds_bytes(plane_cap);
+    if (bits <= 8)
+        hipLaunchKernelGGL((logo_corr_kernel<uint8_t, kEvalPxPerThread>), grid, block, lds, st, dlogos, dbands, nbands, nbands8,
+                           dfades, nfades, (const uint8_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap);
+    else
+        hipLaunchKernelGGL((logo_corr_kernel<uint16_t, kEvalPxPerThread>), grid, block, lds, st, dlogos, dbands, nbands, nbands8,
+                           dfades, nfades, (const uint16_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_ordered_sum(hipStream_t st, const EvalLogoDev* dlogos, int nlogos, int nfades, int nframes,
+                              const float* dscores, long long scores_per_frame, float* dout, int out_frame_stride, int take_abs)
+{
+    if (nframes <= 0 || nlogos <= 0) return hipSuccess;
+    dim3 grid((unsigned)((nframes * nfades + 63) / 64), (unsigned)nlogos), block(64);
+    hipLaunchKernelGGL(ordered_sum_kernel, grid, block, 0, st, dlogos, nfades, nframes, dscores, scores_per_frame, dout,
+                       out_frame_stride, take_abs);
+    return hipGetLastError();
+}
+
+} // namespace amt

@@ -1,0 +1,38 @@
+// eval_plan.h -- device-side description of a logo evaluation (shared by host code and kernels).
+#pragma once
+#include <cstdint>
+
+namespace amt {
+
+constexpr int kEvalThreads = 256;   // threads per workgroup of the correlation kernel
+constexpr int kEvalPxPerThread = 4; // mask pixels a thread keeps kernels for (registers)
+constexpr int kBandMaxPx = kEvalThreads * kEvalPxPerThread;
+constexpr int kNumBins = 32;        // 256 >> 3 background levels (LogoScan.hpp:63-68)
+
+// one evaluation logo (a LogoDataParam after CreateLogoMask) resident in HBM
+struct EvalLogoDev {
+    const float* a;          // [h*w]   A plane of the evaluation logo (deint or field)
+    const float* b;          // [h*w]
+    const uint32_t* pos;     // [count_pad]  (y << 16) | x, raster order
+    const float* kern;       // [25][count_pad]   tap-major so lanes read consecutive floats
+    const float2* scales;    // [32][count_pad]   bin-major {scale, scale2}
+    int w, h;                // evaluation-logo size (field logos: h/2)
+    int count, count_pad;
+    int imgx, imgy;          // rectangle origin in the full frame (full-frame rows)
+    int row0, row_step;      // source row of logo row y = imgy + row0 + y*row_step
+    int deint;               // 1: source is the [1 2 1] vertical blend of rows y-1,y,y+1 (DeintY)
+    int score_off;           // float offset of this logo's block in a frame's score scratch
+    float blackScore;
+    int out_off;             // float offset of this logo's results within a frame's output record
+    int lp;                  // LDS row pitch in floats: ((w+31)&~31)+8 -> consecutive rows sit 8 banks apart
+    uint32_t lp_magic;       // ceil(2^32 / lp): i / lp == __umulhi(i, lp_magic) for i*lp < 2^32
+};
+
+// a band = a contiguous range of mask pixels [m0, m0+npx) and the logo rows their windows touch
+struct EvalBand {
+    int logo;
+    int m0, npx;
+    int y0, nrows;           // staged logo rows [y0, y0+nrows)
+};
+
+} // namespace amt

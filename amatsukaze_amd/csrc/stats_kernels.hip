@@ -1,0 +1,154 @@
+// stats_kernels.hip -- whole-frame field-difference / combing metrics (self-specified).
+//
+// HBM-bound streaming reduction over the Y plane: every byte of every frame is read from HBM once.
+// One workgroup owns a tile (16 rows x up to 2048 bytes) for a RUN of consecutive frames; each thread
+// owns a 16-byte-wide column of that tile, so the vertical neighbours (rows y-1, y+1) and the previous
+// frame's rows are all in the thread's own registers -- no LDS staging, no re-reads except the two halo
+// rows per tile.  Loads are 16 B per lane, 64 lanes = 1 KiB contiguous per row.  The per-byte work is
+// done four pixels at a time with v_sad_u8 / v_lerp_u8 (two per instruction for 16-bit samples).
+//
+// Per frame n (prev = frame n-1; rows 1..H-2 for the vertical metrics), all sums of absolute values:
+//   0 DIFF_TOP   sum_{y even} |Y_n[y] - Y_prev[y]|          3 COMB       sum |Y_n[y] - avg(Y_n[y-1], Y_n[y+1])|
+//   1 DIFF_BOT   sum_{y odd}  |Y_n[y] - Y_prev[y]|          4 COMB_PREV  same on the weave (even rows of n, odd rows of prev)
+//   2 VERT_SAME  sum |Y_n[y-1] - Y_n[y+1]|                  5 SUM        sum Y_n
+//   6 VERT_PREV  VERT_SAME of that weave                    7 reserved (0)
+// avg(a,c) = (a + c) >> 1 per sample.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace amt {
+
+constexpr int kStatThreads = 128;
+constexpr int kStatTileRows = 16;
+constexpr int kStatRun = 16;          // frames a workgroup walks through
+constexpr int kStatWords = 8;
+
+template <int ES> struct Px;
+template <> struct Px<1> {
+    static __device__ __forceinline__ unsigned sad(unsigned a, unsigned b, unsigned acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+    static __device__ __forceinline__ unsigned avg(unsigned a, unsigned c) { return __builtin_amdgcn_lerp(a, c, 0u); }
+};
+template <> struct Px<2> {
+    static __device__ __forceinline__ unsigned sad(unsigned a, unsigned b, unsigned acc) { return __builtin_amdgcn_sad_u16(a, b, acc); }
+    // floor((a+c)/2) in each 16-bit half without carries crossing
+    static __device__ __forceinline__ unsigned avg(unsigned a, unsigned c)
+    {
+        return ((a >> 1) & 0x7FFF7FFFu) + ((c >> 1) & 0x7FFF7FFFu) + (a & c & 0x00010001u);
+    }
+};
+
+__device__ __forceinline__ uint4 load_chunk(const uint8_t* p, int nvalid)
+{
+    if (nvalid >= 16) return *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nvalid; ++i) w[i >> 2] |= (uint32_t)p[i] << ((i & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int ES> __device__ __forceinline__ unsigned sad16(const uint4& a, const uint4& b, unsigned acc)
+{
+    acc = Px<ES>::sad(a.x, b.x, acc);
+    acc = Px<ES>::sad(a.y, b.y, acc);
+    acc = Px<ES>::sad(a.z, b.z, acc);
+    return Px<ES>::sad(a.w, b.w, acc);
+}
+template <int ES> __device__ __forceinline__ uint4 avg16(const uint4& a, const uint4& c)
+{
+    return make_uint4(Px<ES>::avg(a.x, c.x), Px<ES>::avg(a.y, c.y), Px<ES>::avg(a.z, c.z), Px<ES>::avg(a.w, c.w));
+}
+
+template <int ES>
+__global__ __launch_bounds__(kStatThreads)
+void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*bytes*/, int pitch_bytes, int row_bytes, int H,
+                        const uint8_t* __restrict__ prevY /* frame before the batch or null */, int nframes, int col_groups,
+                        unsigned long long* __restrict__ out)
+{
+    constexpr int R = kStatTileRows + 2;
+    const int tile = blockIdx.x / col_groups;
+    const int cg = blockIdx.x - tile * col_groups;
+    const int y0 = tile * kStatTileRows;
+    const int xb = (cg * kStatThreads + threadIdx.x) * 16;       // byte column of this thread
+    const int nvalid = min(16, row_bytes - xb);                   // <= 0: thread has no pixels
+    const int n0 = blockIdx.y * kStatRun;
+    const int n1 = min(nframes, n0 + kStatRun);
+
+    auto load_rows = [&](const uint8_t* frame, uint4* rows) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int y = y0 - 1 + r;
+            rows[r] = (nvalid > 0 && y >= 0 && y < H) ? load_chunk(frame + (long long)y * pitch_bytes + xb, nvalid)
+                                                     : make_uint4(0, 0, 0, 0);
+        }
+    };
+
+    uint4 prev[R], cur[R];
+    {
+        const uint8_t* p = n0 > 0 ? Y + (long long)(n0 - 1) * frame_stride : (prevY ? prevY : Y);
+        load_rows(p, prev);
+    }
+    __shared__ unsigned red[kStatThreads / 64][kStatWords];
+    for (int n = n0; n < n1; ++n) {
+        load_rows(Y + (long long)n * frame_stride, cur);
+        unsigned acc[7] = {0, 0, 0, 0, 0, 0, 0};
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 1; r <= kStatTileRows; ++r) {
+            const int y = y0 - 1 + r;
+            if (y >= H) break;
+            const bool odd = y & 1;
+            acc[odd ? 1 : 0] = sad16<ES>(cur[r], prev[r], acc[odd ? 1 : 0]);
+            acc[5] = sad16<ES>(cur[r], zero, acc[5]);
+            if (y >= 1 && y <= H - 2) {
+                const uint4 mc = avg16<ES>(cur[r - 1], cur[r + 1]);
+                acc[2] = sad16<ES>(cur[r - 1], cur[r + 1], acc[2]);
+                acc[3] = sad16<ES>(cur[r], mc, acc[3]);
+                if (odd) {        // weave: this row comes from prev, its neighbours from cur
+                    acc[4] = sad16<ES>(prev[r], mc, acc[4]);
+                    acc[6] = sad16<ES>(cur[r - 1], cur[r + 1], acc[6]);
+                } else {          // this row from cur, neighbours from prev
+                    const uint4 mp = avg16<ES>(prev[r - 1], prev[r + 1]);
+                    acc[4] = sad16<ES>(cur[r], mp, acc[4]);
+                    acc[6] = sad16<ES>(prev[r - 1], prev[r + 1], acc[6]);
+                }
+            }
+        }
+        // workgroup reduction: wave shuffles, then one atomic per word per wave
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            unsigned v = acc[k];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
+            acc[k] = v;
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (acc[k]) atomicAdd(&out[(long long)n * kStatWords + k], (unsigned long long)acc[k]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) prev[r] = cur[r];
+    }
+    (void)red;
+}
+
+hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long long frame_stride_bytes, int pitch_elems, int W,
+                              int H, const void* dprevY, int nframes, unsigned long long* dout)
+{
+    if (nframes <= 0) return hipSuccess;
+    const int es = bits <= 8 ? 1 : 2;
+    const int row_bytes = W * es;
+    const int col_groups = (row_bytes + kStatThreads * 16 - 1) / (kStatThreads * 16);
+    const int tiles = (H + kStatTileRows - 1) / kStatTileRows;
+    hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(tiles * col_groups), (unsigned)((nframes + kStatRun - 1) / kStatRun)), block(kStatThreads);
+    if (es == 1)
+        hipLaunchKernelGGL(frame_stats_kernel<1>, grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es,
+                           row_bytes, H, (const uint8_t*)dprevY, nframes, col_groups, dout);
+    else
+        hipLaunchKernelGGL(frame_stats_kernel<2>, grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es,
+                           row_bytes, H, (const uint8_t*)dprevY, nframes, col_groups, dout);
+    return hipGetLastError();
+}
+
+} // namespace amt

@@ -1,0 +1,185 @@
+/*
+ * amt_gpu.h -- C ABI of the MI355X-native logo / CM / KFM analysis hot path.
+ *
+ * Drop-in boundary for the per-frame pixel analysis that nekopanda/Amatsukaze runs as scalar C++
+ * inside Amatsukaze.dll.  Every entry point names the reference interface it replaces (paths relative
+ * to the reference tree).  Conventions follow the reference's own exported C API
+ * (LogoScan.hpp:1083-1098 ScanLogo, StreamUtils.hpp:1037-1039 AMTContext_*, LogoGUISupport.hpp:254-275):
+ * opaque handles, int return 1 = ok / 0 = failure with the message kept on the context
+ * (amtgpu_last_error), no exceptions across the boundary, handles freed by *_destroy.
+ *
+ * Frames are 4:2:0 planar, 8-bit (uint8) or 9..16-bit (uint16 containers), the layout AMTSource hands to
+ * AviSynth (AMTSource.hpp:428-442).  A "batch" is `nframes` frames whose planes sit at
+ * base + n*frame_stride (bytes); `pitch` is in ELEMENTS.  Pointers named d* are DEVICE pointers (HBM,
+ * hipMalloc'ed by the caller or by amtgpu_frames_upload); everything else is host memory.
+ *
+ * All kernels are launched on the context's HIP stream (amtgpu_context_set_stream); calls that return
+ * results to host memory synchronise that stream, calls documented "async" do not.
+ */
+#ifndef AMT_GPU_H
+#define AMT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMTGPU_ABI_VERSION 1
+#define AMTGPU_NUM_FADE 11            /* LogoAnalyzeFrame p/t/b[11]  (LogoScan.hpp:1100-1103) */
+#define AMTGPU_ANALYZE_FLOATS 33      /* floats per source frame in an analysis record */
+
+typedef struct AmtGpuContext AmtGpuContext;       /* AMTContext            (StreamUtils.hpp:343-511) */
+typedef struct AmtGpuLogo AmtGpuLogo;             /* logo::LogoData+LogoHeader (AMTLogo.hpp:19-280) */
+typedef struct AmtGpuLogoFrame AmtGpuLogoFrame;   /* logo::LogoFrame       (LogoScan.hpp:1521-1836) */
+typedef struct AmtGpuAnalyze AmtGpuAnalyze;       /* logo::AMTAnalyzeLogo  (LogoScan.hpp:1106-1236) */
+typedef struct AmtGpuErase AmtGpuErase;           /* logo::AMTEraseLogo    (LogoScan.hpp:1238-1519) */
+typedef struct AmtGpuLogoScan AmtGpuLogoScan;     /* logo::LogoScan        (LogoScan.hpp:398-660) */
+typedef struct AmtGpuFrameStats AmtGpuFrameStats; /* self-specified CM / KFM whole-frame metrics */
+
+/* progress callback of ScanLogo (LogoScan.hpp:792): return 0 to cancel */
+typedef int (*AMTGPU_LOGO_ANALYZE_CB)(float progress, int nread, int total, int ngather);
+
+int amtgpu_abi_version(void);
+
+/* ---- context: replaces AMTContext_Create / ATMContext_Delete / AMTContext_GetError
+ *      (StreamUtils.hpp:1037-1039) ---- */
+AmtGpuContext* amtgpu_context_create(int device);       /* NULL if no HIP device / bad index */
+void           amtgpu_context_destroy(AmtGpuContext* ctx);
+const char*    amtgpu_last_error(const AmtGpuContext* ctx);
+/* use an existing hipStream_t (e.g. the caller's compute stream); NULL = the context's own stream */
+int            amtgpu_context_set_stream(AmtGpuContext* ctx, void* hip_stream);
+void*          amtgpu_context_get_stream(AmtGpuContext* ctx);
+int            amtgpu_context_synchronize(AmtGpuContext* ctx);
+
+/* ---- frame ingest: pinned staging + hipMemcpyAsync on a side stream, double buffered against the
+ *      compute stream (the step AMTSource::GetFrame feeds, AMTSource.hpp:721-780).  Allocates the device
+ *      batch; free with amtgpu_device_free. ---- */
+void* amtgpu_device_alloc(AmtGpuContext* ctx, uint64_t bytes);
+void  amtgpu_device_free(AmtGpuContext* ctx, void* dptr);
+int   amtgpu_frames_upload(AmtGpuContext* ctx, void* ddst, const void* hsrc, uint64_t bytes);   /* async on side stream */
+int   amtgpu_frames_upload_wait(AmtGpuContext* ctx);   /* make the compute stream wait for pending uploads */
+int   amtgpu_download(AmtGpuContext* ctx, void* hdst, const void* dsrc, uint64_t bytes);        /* synchronous */
+
+/* ---- logo model: replaces LogoData::Load / Save (AMTLogo.hpp:239-279), LogoFile_* getters
+ *      (LogoGUISupport.hpp:254-275) ---- */
+AmtGpuLogo* amtgpu_logo_load(AmtGpuContext* ctx, const char* path);
+/* planes = aY,bY,aU,bU,aV,bV back to back (AMTLogo.hpp:204-212) */
+AmtGpuLogo* amtgpu_logo_from_planes(AmtGpuContext* ctx, int w, int h, int logUVx, int logUVy,
+                                    int imgw, int imgh, int imgx, int imgy, const float* planes);
+int  amtgpu_logo_save(AmtGpuContext* ctx, const AmtGpuLogo* logo, const char* path, const char* name, int serviceId);
+void amtgpu_logo_destroy(AmtGpuLogo* logo);
+/* out[8] = w,h,logUVx,logUVy,imgw,imgh,imgx,imgy */
+int  amtgpu_logo_get_info(const AmtGpuLogo* logo, int* out8);
+int  amtgpu_logo_get_planes(const AmtGpuLogo* logo, float* out);
+/* evaluation tables of LogoDataParam::CreateLogoMask (LogoScan.hpp:112-229) for inspection / tests:
+ * kind 0 = DeintLogo'ed logo, 1 = top-field logo, 2 = bottom-field logo (MakeFieldLogo :257-283).
+ * Any out pointer may be NULL.  mask: w*h bytes; kernels: count*25; scales: count*32*{scale,scale2}. */
+int  amtgpu_logo_mask_tables(AmtGpuContext* ctx, const AmtGpuLogo* logo, int kind, float maskratio,
+                             int* maskpixels, int* count, float* blackScore,
+                             uint8_t* mask, float* kernels, float* scales);
+
+/* ---- CM all-frames logo scan: replaces logo::LogoFrame (ctor :1592-1616, scanFrames :1618-1630,
+ *      selectLogo :1647-1682, writeResult :1686-1827, getBestLogo/getLogoRatio :1829-1835) as driven by
+ *      CMAnalyze::logoFrame (CMAnalyze.hpp:273-317).  Unreadable logo files are ignored like the
+ *      reference does (:1612-1614) and score {0,-1}. ---- */
+AmtGpuLogoFrame* amtgpu_logoframe_create(AmtGpuContext* ctx, const char* const* logopaths, int nlogos, float maskratio);
+AmtGpuLogoFrame* amtgpu_logoframe_create_from_logos(AmtGpuContext* ctx, const AmtGpuLogo* const* logos, int nlogos, float maskratio);
+void amtgpu_logoframe_destroy(AmtGpuLogoFrame* lf);
+/* declare the clip (VideoInfo): resets results to num_frames entries */
+int  amtgpu_logoframe_begin(AmtGpuLogoFrame* lf, int width, int height, int bits, int num_frames, int fps_num, int fps_den);
+/* scan frames [first, first+nframes) of the clip from a device batch (Y plane only).  async */
+int  amtgpu_logoframe_scan_batch(AmtGpuLogoFrame* lf, const void* dY, int64_t frame_stride, int pitch, int first, int nframes);
+/* results: num_frames*nlogos*{corr0,corr1} (EvalResult, LogoScan.hpp:1532-1535) */
+int  amtgpu_logoframe_get_results(AmtGpuLogoFrame* lf, float* out);
+/* sharded scans: install results computed elsewhere (other ranks) for frames [first, first+nframes) */
+int  amtgpu_logoframe_set_results(AmtGpuLogoFrame* lf, int first, int nframes, const float* evals);
+int  amtgpu_logoframe_select_logo(AmtGpuLogoFrame* lf, int num_candidates);        /* -1 = all */
+int  amtgpu_logoframe_write_result(AmtGpuLogoFrame* lf, const char* outpath, int logo_index); /* -1 = best */
+int  amtgpu_logoframe_best_logo(const AmtGpuLogoFrame* lf);
+float amtgpu_logoframe_logo_ratio(const AmtGpuLogoFrame* lf);
+
+/* ---- encode-time analysis: replaces logo::AMTAnalyzeLogo ("AMTAnalyzeLogo" "cs[maskratio]i",
+ *      Amatsukaze.cpp:58; ctor :1164-1201, GetFrameT :1119-1161).  One record of 33 floats
+ *      {p[11],t[11],b[11]} per SOURCE frame; the AviSynth shim packs 8 per BGR32 frame (:1195-1200). ---- */
+AmtGpuAnalyze* amtgpu_analyze_create(AmtGpuContext* ctx, const char* logopath, float maskratio);
+AmtGpuAnalyze* amtgpu_analyze_create_from_logo(AmtGpuContext* ctx, const AmtGpuLogo* logo, float maskratio);
+void amtgpu_analyze_destroy(AmtGpuAnalyze* an);
+/* dout: device buffer of nframes*33 floats.  async */
+int  amtgpu_analyze_batch(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* dout);
+/* convenience: same, results copied to host (synchronises) */
+int  amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* hout);
+
+/* ---- encode-time erase: replaces logo::AMTEraseLogo ("AMTEraseLogo" "ccs[logof]s[mode]i[maxfade]i",
+ *      Amatsukaze.cpp:59; ctor :1464-1481, ReadLogoFrameFile :1421-1461, CalcFade :1317-1341,
+ *      CalcFade2 :1263-1315, Delogo :1248-1261, GetFrameT mode 0 :1343-1400).  logofpath may be "" ---- */
+AmtGpuErase* amtgpu_erase_create(AmtGpuContext* ctx, const char* logopath, const char* logofpath, int mode, int maxfade);
+AmtGpuErase* amtgpu_erase_create_from_logo(AmtGpuContext* ctx, const AmtGpuLogo* logo, const char* logof_text, int mode, int maxfade);
+void amtgpu_erase_destroy(AmtGpuErase* er);
+/* fades for frames [first, first+nframes) of a num_frames clip from the per-source-frame analysis of the
+ * WHOLE clip (host, num_frames*33 floats).  out = nframes*{fadeT,fadeB}.  Host-only (tiny). */
+int  amtgpu_erase_calc_fades(AmtGpuErase* er, const float* analysis, int num_frames, int first, int nframes, float* fades_out);
+/* in-place erase of a device batch with the given per-frame fades (host array nframes*2).  async */
+int  amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
+                        int pitchY, int pitchUV, int bits, int nframes, const float* fades);
+
+/* ---- logo generation: replaces logo::LogoScan (AddFrame :594-659, AddScanFrame :568-592,
+ *      Normalize :471-488, GetLogo :490-566) and LogoAnalyzer / the exported ScanLogo (:794-1098) ---- */
+AmtGpuLogoScan* amtgpu_logoscan_create(AmtGpuContext* ctx, int w, int h, int logUVx, int logUVy, int thy);
+void amtgpu_logoscan_destroy(AmtGpuLogoScan* s);
+/* planes of full frames; the scan rectangle sits at (imgx,imgy).  valid_out (host, nframes bytes, may be
+ * NULL) receives AddFrame's verdict per frame.  At most `max_valid` further frames are accepted, in
+ * stream order (numMaxFrames, :885).  Returns 1/0; *naccepted = frames accepted by this call.
+ * use_mask (host, nframes bytes, may be NULL): only frames with use_mask[i]!=0 are offered (ReMakeLogo :1018) */
+int  amtgpu_logoscan_add_batch(AmtGpuLogoScan* s, const void* dY, const void* dU, const void* dV,
+                               int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int bits,
+                               int imgx, int imgy, int nframes, int max_valid, const uint8_t* use_mask,
+                               uint8_t* valid_out, int* naccepted);
+int  amtgpu_logoscan_nframes(const AmtGpuLogoScan* s);
+/* exact integer sums per pixel {sumF, sumF2, sumFB} (Y then U then V) + per plane {sumB, sumB2}: for the
+ * sharded all-reduce.  sums: 3*(w*h+2*wUV*hUV) int64; plane_sums: 6 int64. */
+int  amtgpu_logoscan_get_sums(AmtGpuLogoScan* s, int64_t* sums, int64_t* plane_sums);
+int  amtgpu_logoscan_set_sums(AmtGpuLogoScan* s, const int64_t* sums, const int64_t* plane_sums, int nframes);
+/* Normalize(maxv) + GetLogo(clean); NULL (+ error) when the regression fails ("Insufficient logo frames") */
+AmtGpuLogo* amtgpu_logoscan_get_logo(AmtGpuLogoScan* s, int maxv, int clean, int imgw, int imgh, int imgx, int imgy);
+/* Same signature family as the reference's ScanLogo (LogoScan.hpp:1083-1098), over a device-resident
+ * 8-bit clip instead of a TS path: 1 ok / 0 fail. */
+int  amtgpu_scanlogo(AmtGpuContext* ctx, const void* dY, const void* dU, const void* dV,
+                     int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int imgw, int imgh,
+                     int nframes, int serviceid, const char* dstpath, int imgx, int imgy, int w, int h,
+                     int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb);
+
+/* ---- self-specified whole-frame passes (NO in-tree reference arithmetic: SURVEY.md section 0;
+ *      "parity unpinned").  Stand in for what chapter_exe (CMAnalyze.hpp:319-337) and KFMDeint's
+ *      analysis passes (Misc.cs:1300-1324, FilteredSource.hpp:232-238) compute.  Integer metrics,
+ *      specified in DESIGN.md section 6; per frame 8 x uint32/uint64 words, see AMTGPU_FS_*. ---- */
+#define AMTGPU_FS_WORDS 8
+/* word indices of one frame's record (uint64 each); all sums of absolute sample differences, prev = n-1,
+ * vertical metrics over rows 1..H-2, avg(a,c) = (a+c)>>1 */
+#define AMTGPU_FS_DIFF_TOP   0   /* sum over even rows |Y_n - Y_prev| */
+#define AMTGPU_FS_DIFF_BOT   1   /* sum over odd rows  |Y_n - Y_prev| */
+#define AMTGPU_FS_VERT       2   /* sum |Y_n[y-1] - Y_n[y+1]|  (detail inside one field) */
+#define AMTGPU_FS_COMB       3   /* sum |Y_n[y] - avg(Y_n[y-1], Y_n[y+1])|  (combing energy of the frame) */
+#define AMTGPU_FS_COMB_PREV  4   /* COMB of the weave (even rows of n, odd rows of n-1) */
+#define AMTGPU_FS_SUM        5   /* sum of luma */
+#define AMTGPU_FS_VERT_PREV  6   /* VERT of that weave */
+#define AMTGPU_FS_RESERVED   7
+AmtGpuFrameStats* amtgpu_framestats_create(AmtGpuContext* ctx, int width, int height, int bits, int t1, int t2);
+void amtgpu_framestats_destroy(AmtGpuFrameStats* fs);
+/* dprevY: Y plane of the frame before the batch (device), or NULL -> frame 0 compares with itself.
+ * dout: nframes*AMTGPU_FS_WORDS uint64 (device).  async */
+int  amtgpu_framestats_batch(AmtGpuFrameStats* fs, const void* dY, int64_t frame_stride, int pitch,
+                             const void* dprevY, int nframes, uint64_t* dout);
+/* host decisions from the metrics of a whole clip (nframes*8 uint64, host): scene-change list in
+ * chapter_exe's "SCPos:" sense and per-frame cadence class 0=30i/60p 1=24p(3:2) 2=30p + 3:2 phase.
+ * sc_out: up to cap frame numbers, returns count via *nsc.  cadence_out: nframes bytes, phase_out: nframes bytes */
+int  amtgpu_cm_scene_changes(const uint64_t* metrics, int nframes, int width, int height, int* sc_out, int cap, int* nsc);
+int  amtgpu_kfm_cadence(const uint64_t* metrics, int nframes, int width, int height, uint8_t* cadence_out, uint8_t* phase_out);
+/* KFM output-file contract (AMTDecimate, FilteredSource.hpp:645-654): one integer per output frame = how many
+ * frames of the 60p clip it spans; sum == 2*nframes.  *nout = output frames written. */
+int  amtgpu_kfm_write_durations(const uint8_t* cadence, const uint8_t* phase, int nframes, const char* path, int* nout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMT_GPU_H */

@@ -1,0 +1,120 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/amt_gpu.h declares, and
+its host-only entry points (logo model, .lgd format, evaluation tables, decisions) agree with the oracle
+bit for bit.  No GPU compute calls here."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+import amt_synth as S
+from amtlib import ROOT, Oracle, _ptr
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import frame_stats_oracle as FS
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from amatsukaze_amd import build as b
+    b.build()
+    from amatsukaze_amd import binding
+    return binding.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    from amatsukaze_amd import binding
+    hdr = open(os.path.join(ROOT, "include", "amt_gpu.h")).read()
+    declared = set(re.findall(r"\b(amtgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(binding.SIGNATURES), declared ^ set(binding.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.amtgpu_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert not lib.amtgpu_context_create(0)
+    from amatsukaze_amd import AmtError, Context
+    with pytest.raises((AmtError, Exception)):
+        Context(0)
+
+
+def test_product_never_touches_the_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "amatsukaze_amd")):
+        if os.path.basename(dp) == "build":
+            continue
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "amt_oracle" not in src and "libamt_ref" not in src and "frame_stats_oracle" not in src, f
+
+
+def test_lgd_and_mask_tables_match_oracle(lib, tmp_path):
+    LW, LH, W, H, X, Y0 = 96, 48, 352, 240, 224, 18
+    data, _, _ = S.make_logo(LW, LH)
+    orc = Oracle()
+    lo = orc.make_logo(data, LW, LH, W, H, X, Y0)
+    p1, p2 = str(tmp_path / "o.lgd").encode(), str(tmp_path / "g.lgd").encode()
+    assert orc.lib.orc_logo_save(lo, p1, b"synthetic", 1041) == 1
+    lg = lib.amtgpu_logo_load(None, p1)
+    assert lg
+    assert lib.amtgpu_logo_save(None, lg, p2, b"synthetic", 1041) == 1
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    info = np.zeros(8, np.int32)
+    lib.amtgpu_logo_get_info(lg, _ptr(info))
+    assert info.tolist() == [LW, LH, 1, 1, W, H, X, Y0]
+    for kind, maskratio in [(0, 0.35), (1, 0.35), (2, 0.35), (0, 0.1), (0, 0.95)]:
+        o2 = orc.lib.orc_logo_deint(lo) if kind == 0 else orc.lib.orc_logo_field(lo, kind - 1)
+        orc.lib.orc_logo_create_mask(o2, maskratio, 1)
+        _, mask, ker, sc, black, mp, cnt = orc.logo_arrays(o2)
+        gmp, gcnt, gblack = C.c_int(), C.c_int(), C.c_float()
+        h = LH if kind == 0 else LH // 2
+        gmask = np.zeros(LW * h, np.uint8)
+        assert lib.amtgpu_logo_mask_tables(None, lg, kind, maskratio, C.byref(gmp), C.byref(gcnt), C.byref(gblack), _ptr(gmask), None, None) == 1
+        assert (gmp.value, gcnt.value) == (mp, cnt)
+        gker, gsc = np.zeros(cnt * 25, np.float32), np.zeros(cnt * 64, np.float32)
+        assert lib.amtgpu_logo_mask_tables(None, lg, kind, maskratio, None, None, None, None, _ptr(gker), _ptr(gsc)) == 1
+        assert np.array_equal(gmask, mask)
+        assert gker.tobytes() == ker[:cnt * 25].tobytes()
+        assert gsc.tobytes() == sc[:cnt * 64].tobytes()
+        assert np.float32(gblack.value).tobytes() == np.float32(black).tobytes()
+    lib.amtgpu_logo_destroy(lg)
+    assert not lib.amtgpu_logo_load(None, b"/nonexistent.lgd")
+
+
+def test_stats_decisions_match_oracle(lib):
+    rng = np.random.RandomState(5)
+    W, H, n = 352, 240, 150
+    m = np.zeros((n, 8), np.uint64)
+    # synthetic metric streams: 24p (C C P P B), 30p (all C), interlaced (all B), still
+    for i in range(n):
+        seg = i // 50
+        motion = 400000 + int(rng.randint(0, 50000))
+        c_lo, c_hi = 100000, 600000
+        if seg == 0:
+            pos = i % 5
+            comb, combp = (c_lo, c_hi) if pos <= 1 else ((c_hi, c_lo) if pos <= 3 else (c_lo, c_lo))
+        elif seg == 1:
+            comb, combp = c_lo, c_hi
+        else:
+            comb, combp = c_hi, c_hi - 1000
+        if 120 <= i < 135:
+            motion = 1000
+        m[i] = [motion // 2, motion // 2, 300000, comb + int(rng.randint(0, 2000)), combp, 10000000, 300000, 0]
+    m[77, 0] = m[77, 1] = W * H * 20
+    cad, ph = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    assert lib.amtgpu_kfm_cadence(_ptr(m), n, W, H, _ptr(cad), _ptr(ph)) == 1
+    ocad, oph = FS.classify_cadence(m, W, H)
+    assert np.array_equal(cad, ocad) and np.array_equal(ph, oph)
+    assert (cad[5:40] == 1).all() and (cad[60:90] == 2).all() and (cad[105:118] == 0).all()
+    assert (cad[120:135] == cad[119]).all()           # still frames inherit
+    sc = np.zeros(n, np.int32)
+    k = C.c_int()
+    assert lib.amtgpu_cm_scene_changes(_ptr(m), n, W, H, _ptr(sc), n, C.byref(k)) == 1
+    assert sc[:k.value].tolist() == FS.scene_changes(m, W, H) and 77 in sc[:k.value].tolist()
