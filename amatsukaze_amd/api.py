@@ -52,6 +52,20 @@ class Context:
     def synchronize(self):
         self.check(self.lib.amtgpu_context_synchronize(self.h))
 
+    def profile(self, on: bool = True):
+        self.check(self.lib.amtgpu_profile_enable(self.h, 1 if on else 0))
+
+    def profile_report(self):
+        """{kernel: (calls, total_ms)} measured with HIP events on the launch stream"""
+        buf = C.create_string_buffer(1 << 14)
+        n = self.lib.amtgpu_profile_report(self.h, buf, len(buf))
+        self.check(n >= 0, "profile_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.split()
+            out[name] = (int(calls), float(ms))
+        return out
+
     def close(self):
         if self.h:
             self.lib.amtgpu_context_destroy(self.h)

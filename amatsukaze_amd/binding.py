@@ -23,6 +23,8 @@ SIGNATURES = {
     "amtgpu_context_set_stream": (c_i, [c_p, c_p]),
     "amtgpu_context_get_stream": (c_p, [c_p]),
     "amtgpu_context_synchronize": (c_i, [c_p]),
+    "amtgpu_profile_enable": (c_i, [c_p, c_i]),
+    "amtgpu_profile_report": (c_i, [c_p, c_p, c_i]),
     "amtgpu_device_alloc": (c_p, [c_p, c_u64]),
     "amtgpu_device_free": (None, [c_p, c_p]),
     "amtgpu_frames_upload": (c_i, [c_p, c_p, c_p, c_u64]),

@@ -42,6 +42,8 @@ void amtgpu_context_destroy(AmtGpuContext* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (auto& sp : c->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto& e : c->slot_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
@@ -62,6 +64,36 @@ void* amtgpu_context_get_stream(AmtGpuContext* c) { return c ? (void*)c->stream 
 int amtgpu_context_synchronize(AmtGpuContext* c)
 {
     return guard(c, [&] { c->bind(); AMT_HIP(hipStreamSynchronize(c->stream)); });
+}
+
+// per-kernel timing (HIP events on the launch stream) for bench.py's roofline figures
+int amtgpu_profile_enable(AmtGpuContext* c, int on)
+{
+    return guard(c, [&] {
+        c->bind();
+        c->prof_resolve();
+        c->profiling = on != 0;
+        if (on) { std::fill(c->prof_ms.begin(), c->prof_ms.end(), 0.0); std::fill(c->prof_calls.begin(), c->prof_calls.end(), 0LL); }
+    });
+}
+// text: one line per kernel "name calls total_ms\n"; returns bytes written or -1
+int amtgpu_profile_report(AmtGpuContext* c, char* out, int cap)
+{
+    int n = -1;
+    guard(c, [&] {
+        c->bind();
+        c->prof_resolve();
+        std::string s;
+        char line[160];
+        for (size_t i = 0; i < c->prof_names.size(); ++i) {
+            std::snprintf(line, sizeof line, "%s %lld %.6f\n", c->prof_names[i].c_str(), c->prof_calls[i], c->prof_ms[i]);
+            s += line;
+        }
+        if ((int)s.size() + 1 > cap) throw std::runtime_error("profile buffer too small");
+        std::memcpy(out, s.c_str(), s.size() + 1);
+        n = (int)s.size();
+    });
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -122,8 +122,10 @@ int amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t st
         g.w = P.w; g.h = P.h; g.wUV = P.wUV(); g.hUV = P.hUV();
         g.imgx = P.imgx; g.imgy = P.imgy; g.cx = P.imgx >> P.logUVx; g.cy = P.imgy >> P.logUVy;
         g.uvparity = (P.imgy / 2) % 2;
+        const int sp = er->ctx->prof_begin("delogo_kernel");
         AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
                               nframes, er->dFades.get()));
+        er->ctx->prof_end(sp);
         // the fades came from pageable host memory: make sure the copy has been consumed before returning
         AMT_HIP(hipStreamSynchronize(er->ctx->stream));
     });
@@ -170,8 +172,10 @@ static int logoscan_add(AmtGpuLogoScan* s, const void* dY, const void* dU, const
         v.assign(known_verdicts, known_verdicts + nframes);
     } else {
         if (s->dVerdict.size() < (size_t)nframes) s->dVerdict.alloc(nframes);
+        const int spb = s->ctx->prof_begin("scan_border_kernel");
         AMT_HIP(launch_scan_border(s->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, imgx, imgy, cx, cy,
                                    S.w, S.h, wUV, hUV, s->thy, nframes, s->dVerdict.get()));
+        s->ctx->prof_end(spb);
         v.resize(nframes);
         AMT_HIP(hipMemcpyAsync(v.data(), s->dVerdict.get(), (size_t)nframes * sizeof(int4), hipMemcpyDeviceToHost, s->ctx->stream));
         AMT_HIP(hipStreamSynchronize(s->ctx->stream));
@@ -191,8 +195,10 @@ static int logoscan_add(AmtGpuLogoScan* s, const void* dY, const void* dU, const
     if (!acc.empty()) {
         if (s->dAccepted.size() < acc.size()) s->dAccepted.alloc(acc.size());
         AMT_HIP(hipMemcpyAsync(s->dAccepted.get(), acc.data(), acc.size() * sizeof(int4), hipMemcpyHostToDevice, s->ctx->stream));
+        const int spa = s->ctx->prof_begin("scan_accumulate_kernel");
         AMT_HIP(launch_scan_accumulate(s->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, imgx, imgy, cx, cy,
                                        S.w, S.h, wUV, hUV, s->dAccepted.get(), (int)acc.size(), s->dAcc.get()));
+        s->ctx->prof_end(spa);
         AMT_HIP(hipStreamSynchronize(s->ctx->stream));        // acc (host vector) must outlive the copy
         s->accDirty = true;
         S.nframes += (int)acc.size();

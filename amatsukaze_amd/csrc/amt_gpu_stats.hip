@@ -37,8 +37,10 @@ int amtgpu_framestats_batch(AmtGpuFrameStats* fs, const void* dY, int64_t frame_
 {
     return guard(fs->ctx, [&] {
         fs->ctx->bind();
+        const int sp = fs->ctx->prof_begin("frame_stats_kernel");
         AMT_HIP(launch_frame_stats(fs->ctx->stream, fs->bits, dY, frame_stride, pitch, fs->width, fs->height, dprevY, nframes,
                                    (unsigned long long*)dout));
+        fs->ctx->prof_end(sp);
     });
 }
 

@@ -31,7 +31,22 @@ struct AmtGpuContext {
     int next_slot = 0;
     std::string err;
 
+    // optional per-kernel timing with HIP events on the launch stream (amtgpu_profile_*)
+    struct ProfSpan { int name; hipEvent_t a, b; };
+    bool profiling = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfSpan> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
+    std::vector<double> prof_ms;        // resolved totals per name
+    std::vector<long long> prof_calls;
+
     void bind() const { AMT_HIP(hipSetDevice(device)); }
+    int prof_id(const char* name);
+    hipEvent_t prof_event();
+    // RAII-less helpers: begin returns a span index or -1 when profiling is off
+    int prof_begin(const char* name);
+    void prof_end(int span);
+    void prof_resolve();
 };
 
 namespace amt {

@@ -4,6 +4,49 @@
 #include <algorithm>
 #include <cstdlib>
 
+int AmtGpuContext::prof_id(const char* name)
+{
+    for (size_t i = 0; i < prof_names.size(); ++i) if (prof_names[i] == name) return (int)i;
+    prof_names.push_back(name);
+    prof_ms.push_back(0.0);
+    prof_calls.push_back(0);
+    return (int)prof_names.size() - 1;
+}
+hipEvent_t AmtGpuContext::prof_event()
+{
+    if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    AMT_HIP(hipEventCreate(&e));
+    return e;
+}
+int AmtGpuContext::prof_begin(const char* name)
+{
+    if (!profiling) return -1;
+    if (prof_spans.size() >= 4096) prof_resolve();
+    ProfSpan sp{prof_id(name), prof_event(), prof_event()};
+    AMT_HIP(hipEventRecord(sp.a, stream));
+    prof_spans.push_back(sp);
+    return (int)prof_spans.size() - 1;
+}
+void AmtGpuContext::prof_end(int span)
+{
+    if (span < 0) return;
+    AMT_HIP(hipEventRecord(prof_spans[span].b, stream));
+}
+void AmtGpuContext::prof_resolve()
+{
+    for (auto& sp : prof_spans) {
+        AMT_HIP(hipEventSynchronize(sp.b));
+        float ms = 0;
+        AMT_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        prof_ms[sp.name] += ms;
+        prof_calls[sp.name] += 1;
+        prof_pool.push_back(sp.a);
+        prof_pool.push_back(sp.b);
+    }
+    prof_spans.clear();
+}
+
 namespace amt {
 
 namespace {
@@ -112,11 +155,15 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
     for (int f0 = 0; f0 < nframes; f0 += chunk) {
         const int n = std::min(chunk, nframes - f0);
         const uint8_t* base = static_cast<const uint8_t*>(dY) + (dframe_map ? 0 : (int64_t)f0 * frame_stride_bytes);
+        int sp = ctx_->prof_begin("logo_corr_kernel");
         AMT_HIP(launch_logo_corr(ctx_->stream, bits, d_logos_.get(), d_bands_.get(), (int)bands_.size(), d_fades_.get(),
                                  (int)fades_.size(), base, dframe_map ? dframe_map + f0 : nullptr, frame_stride_bytes / es, pitch,
                                  n, d_scratch_.get(), scores_per_frame_, plane_cap_));
+        ctx_->prof_end(sp);
+        sp = ctx_->prof_begin("ordered_sum_kernel");
         AMT_HIP(launch_ordered_sum(ctx_->stream, d_logos_.get(), (int)specs_.size(), (int)fades_.size(), n, d_scratch_.get(),
                                    scores_per_frame_, dout + (size_t)f0 * out_frame_stride_, out_frame_stride_, take_abs_ ? 1 : 0));
+        ctx_->prof_end(sp);
     }
 }
 

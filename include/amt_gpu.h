@@ -51,6 +51,11 @@ const char*    amtgpu_last_error(const AmtGpuContext* ctx);
 int            amtgpu_context_set_stream(AmtGpuContext* ctx, void* hip_stream);
 void*          amtgpu_context_get_stream(AmtGpuContext* ctx);
 int            amtgpu_context_synchronize(AmtGpuContext* ctx);
+/* per-kernel timing with HIP events on the launch stream (no counterpart in the reference, which only logs
+ * phase wall times, CMAnalyze.hpp:37-39).  enable(1) resets the totals; report writes
+ * "kernel_name calls total_ms\n" lines and returns the byte count (-1 on error). */
+int            amtgpu_profile_enable(AmtGpuContext* ctx, int on);
+int            amtgpu_profile_report(AmtGpuContext* ctx, char* out, int cap);
 
 /* ---- frame ingest: pinned staging + hipMemcpyAsync on a side stream, double buffered against the
  *      compute stream (the step AMTSource::GetFrame feeds, AMTSource.hpp:721-780).  Allocates the device

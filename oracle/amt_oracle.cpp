@@ -953,4 +953,51 @@ OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V, int6
     return logodata.release();
 }
 
+
+// self-specified metrics (parity unpinned): see amt_oracle.h
+extern "C++" {
+template <typename T>
+void frame_metrics_t(const uint8_t* base, int64_t frame_stride, int pitch, int W, int H, int nframes,
+                            const uint8_t* prev_first, uint64_t* out)
+{
+    for (int n = 0; n < nframes; ++n) {
+        const T* cur = reinterpret_cast<const T*>(base + n * frame_stride);
+        const T* prev = n > 0 ? reinterpret_cast<const T*>(base + (n - 1) * frame_stride)
+                              : (prev_first ? reinterpret_cast<const T*>(prev_first) : cur);
+        uint64_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int y = 0; y < H; ++y) {
+            const T* c = cur + (size_t)y * pitch;
+            const T* p = prev + (size_t)y * pitch;
+            uint64_t d = 0, sum = 0;
+            for (int x = 0; x < W; ++x) { d += (uint64_t)std::abs((int)c[x] - (int)p[x]); sum += c[x]; }
+            m[y & 1] += d;
+            m[5] += sum;
+            if (y >= 1 && y <= H - 2) {
+                const T *ca = c - pitch, *cc = c + pitch, *pa = p - pitch, *pc = p + pitch;
+                uint64_t vert = 0, comb = 0, combp = 0, vertp = 0;
+                const bool odd = y & 1;
+                for (int x = 0; x < W; ++x) {
+                    const int a = ca[x], b = c[x], e = cc[x];
+                    vert += (uint64_t)std::abs(a - e);
+                    comb += (uint64_t)std::abs(b - ((a + e) >> 1));
+                    // weave: even rows from cur, odd rows from prev
+                    const int wa = odd ? a : (int)pa[x], wb = odd ? (int)p[x] : b, wc = odd ? e : (int)pc[x];
+                    combp += (uint64_t)std::abs(wb - ((wa + wc) >> 1));
+                    vertp += (uint64_t)std::abs(wa - wc);
+                }
+                m[2] += vert; m[3] += comb; m[4] += combp; m[6] += vertp;
+            }
+        }
+        std::memcpy(out + (size_t)n * 8, m, sizeof m);
+    }
+}
+} // extern "C++"
+
+void orc_frame_metrics(const void* Y, int64_t frame_stride, int pitch, int bits, int W, int H, int nframes,
+                       const void* prev_first, uint64_t* out)
+{
+    if (bits <= 8) frame_metrics_t<uint8_t>((const uint8_t*)Y, frame_stride, pitch, W, H, nframes, (const uint8_t*)prev_first, out);
+    else frame_metrics_t<uint16_t>((const uint8_t*)Y, frame_stride, pitch, W, H, nframes, (const uint8_t*)prev_first, out);
+}
+
 } // extern "C"

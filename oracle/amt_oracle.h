@@ -110,6 +110,12 @@ OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V,
                       int imgx, int imgy, int w, int h, int thy, int numMaxFrames,
                       int use_avx, int* num_valid_out, int* minfades_out);
 
+/* ---- SELF-SPECIFIED whole-frame metrics -- PARITY UNPINNED: the reference has no
+ * in-tree arithmetic for them.  C restatement of oracle/frame_stats_oracle.py, used as
+ * the CPU baseline leg for these passes.  out = nframes*8 uint64, layout AMTGPU_FS_*; prev_first may be NULL. */
+void orc_frame_metrics(const void* Y, int64_t frame_stride, int pitch, int bits, int W, int H, int nframes,
+                       const void* prev_first, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ class Oracle:
         d("orc_scan_nframes", c_i, [c_p])
         d("orc_scan_sums", None, [c_p, c_p])
         d("orc_scan_get_logo", c_p, [c_p, c_i, c_i, c_i, c_i, c_i, c_i])
+        d("orc_frame_metrics", None, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
         d("orc_scanlogo", c_p, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
 
     # ---- helpers ----

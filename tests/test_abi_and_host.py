@@ -118,3 +118,14 @@ def test_stats_decisions_match_oracle(lib):
     k = C.c_int()
     assert lib.amtgpu_cm_scene_changes(_ptr(m), n, W, H, _ptr(sc), n, C.byref(k)) == 1
     assert sc[:k.value].tolist() == FS.scene_changes(m, W, H) and 77 in sc[:k.value].tolist()
+
+
+def test_c_and_numpy_stat_oracles_agree():
+    """the two restatements of the self-specified metrics (C for the CPU baseline, numpy for readability)"""
+    orc = Oracle()
+    for bits in (8, 10):
+        clip = S.make_clip_np(5, 96, 38, 0x5EED0003, bits=bits, pitchY=104)
+        Y = clip["Y"]
+        out = np.zeros((5, 8), np.uint64)
+        orc.lib.orc_frame_metrics(_ptr(Y), Y.strides[0], Y.shape[2], bits, 96, 38, 5, None, _ptr(out))
+        assert np.array_equal(out, FS.frame_metrics(Y[:, :, :96]))

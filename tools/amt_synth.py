@@ -106,8 +106,16 @@ def frame_planes_np(n: int, W: int, H: int, seed: int, bits: int = 8, cadence: s
         return 2 * n + parity       # 30i: every field its own time
 
     def picture(t):
+        # smooth panning texture (2 px per field time) + moving box + a little temporal noise; a new scene
+        # (every 97 frames) re-draws the texture and shifts the level
         yy, xx = np.mgrid[0:H, 0:W]
-        base = 40.0 + 120.0 * ((xx * 3 + yy * 2 + ((sseed >> 8) & 0xFF)) % (W + H)) / float(W + H)
+        xs = (xx + 2 * t).astype(np.float64)
+        f1 = 37.0 + float((sseed >> 8) & 0x1F)
+        f2 = 23.0 + float((sseed >> 16) & 0xF)
+        p1 = float((sseed >> 24) & 0xFF) / 40.0
+        p2 = float((sseed >> 32) & 0xFF) / 40.0
+        level = 95.0 + float((sseed >> 40) & 0x3F)
+        base = level + 40.0 * np.sin((xs + 0.6 * yy) / f1 * 2.0 + p1) + 22.0 * np.sin((xs * 0.7 - yy) / f2 * 2.0 + p2)
         bx = (int(sseed & 0x3FF) + 7 * t) % max(1, W - 160)
         by = (int((sseed >> 10) & 0x1FF) + 3 * t) % max(1, H - 120)
         box = ((xx >= bx) & (xx < bx + 160) & (yy >= by) & (yy < by + 120))
@@ -115,8 +123,7 @@ def frame_planes_np(n: int, W: int, H: int, seed: int, bits: int = 8, cadence: s
         key = np.uint64((sseed ^ (t * 0x9E3779B97F4A7C15)) & MASK64)
         idx = (yy.astype(np.uint64) * np.uint64(W) + xx.astype(np.uint64)) + key
         hsh = _mix_np(idx)
-        noise = ((hsh & np.uint64(0xF)).astype(np.float64) + ((hsh >> np.uint64(4)) & np.uint64(0xF)).astype(np.float64)
-                 + ((hsh >> np.uint64(8)) & np.uint64(0xF)).astype(np.float64) - 22.5) * 0.9
+        noise = ((hsh & np.uint64(0x7)).astype(np.float64) + ((hsh >> np.uint64(4)) & np.uint64(0x7)).astype(np.float64) - 7.0) * 0.5
         return base + noise, hsh
 
     pt, ht = picture(field_time(0))
