@@ -128,9 +128,11 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
     d_bands_.upload(bands_, ctx_->stream);
     d_fades_.upload(fades_, ctx_->stream);
 
-    // frames per launch: keep the score scratch inside the 256 MiB Infinity Cache so that the ordered-sum
-    // pass re-reads it on die (override with AMTGPU_SCRATCH_MB)
-    long long budget_mb = 160;
+    // frames per launch: large enough that each launch fills the chip many times over and the ordered-sum pass
+    // has thousands of independent rows (its per-row chain of adds is serial); the scratch round trip through
+    // HBM (~2 MB per frame for the 33-evaluation analysis) is far below the 8 TB/s roofline at this kernel's
+    // VALU-bound frame rate.  Override with AMTGPU_SCRATCH_MB.
+    long long budget_mb = 1536;
     if (const char* e = std::getenv("AMTGPU_SCRATCH_MB")) budget_mb = std::max(1LL, std::atoll(e));
     const long long per_frame_bytes = std::max(1LL, scores_per_frame_ * 4);
     chunk_frames_ = (int)std::max(1LL, std::min(65536LL, budget_mb * (1LL << 20) / per_frame_bytes));

@@ -143,41 +143,60 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
     }
 }
 
-// Sequential (reference-order) sum of each score row; 64 rows per wave.
-// rows of one logo: row e = frame*nfades + f, at scores + frame*scores_per_frame + score_off + f*count_pad
+// Sequential (reference-order) sum of each score row.
+// rows of one logo: row e = frame*nfades + f, at scores + frame*scores_per_frame + score_off + f*count_pad.
+// One wave owns 16 rows: all 64 lanes stream the rows in 128-column chunks (16 B per lane, two rows per
+// instruction, next chunk in flight while the current one is consumed), lanes 0..15 then add their row's chunk
+// front to back out of LDS.  The chain of dependent adds (count x ~5 cycles) is the floor per row; thousands of
+// rows run side by side.
+constexpr int kSumRows = 16, kSumCols = 128, kSumPitch = 132;   // pitch 132: the 16 row readers hit 64 distinct banks
+
 __global__ __launch_bounds__(64)
 void ordered_sum_kernel(const EvalLogoDev* __restrict__ logos, int nfades, int nframes,
                         const float* __restrict__ scores, long long scores_per_frame,
                         float* __restrict__ out, int out_frame_stride, int take_abs)
 {
-    __shared__ float tile[64][65];
-    __shared__ long long rowoff[64];
+    __shared__ float tile[2][kSumRows][kSumPitch];
     const EvalLogoDev L = logos[blockIdx.y];
     const int lane = threadIdx.x;
     const int nrows = nframes * nfades;
-    const int row = blockIdx.x * 64 + lane;
-    const int crow = row < nrows ? row : nrows - 1;
-    const int frame = crow / nfades, f = crow - frame * nfades;
-    rowoff[lane] = (long long)frame * scores_per_frame + L.score_off + (long long)f * L.count_pad;
-    __syncthreads();
-
-    float acc = 0;
-    for (int c0 = 0; c0 < L.count; c0 += 64) {
-        const int ncol = min(64, L.count - c0);
-        if (lane < ncol) {
-#pragma unroll 16
-            for (int r = 0; r < 64; ++r) tile[r][lane] = scores[rowoff[r] + c0 + lane];
-        }
-        __syncthreads();
-        if (ncol == 64) {
+    const int half = lane >> 5, c4 = (lane & 31) * 4;
+    long long offs[kSumRows / 2];
 #pragma unroll
-            for (int c = 0; c < 64; ++c) acc += tile[lane][c];
-        } else {
-            for (int c = 0; c < ncol; ++c) acc += tile[lane][c];
+    for (int j = 0; j < kSumRows / 2; ++j) {
+        const int row = min(nrows - 1, (int)blockIdx.x * kSumRows + 2 * j + half);
+        const int frame = row / nfades, f = row - frame * nfades;
+        offs[j] = (long long)frame * scores_per_frame + L.score_off + (long long)f * L.count_pad + c4;
+    }
+    const int nchunks = (L.count + kSumCols - 1) / kSumCols;
+    float4 v[kSumRows / 2];
+#pragma unroll
+    for (int j = 0; j < kSumRows / 2; ++j) v[j] = *reinterpret_cast<const float4*>(scores + offs[j]);
+    float acc = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+#pragma unroll
+        for (int j = 0; j < kSumRows / 2; ++j) *reinterpret_cast<float4*>(&tile[buf][2 * j + half][c4]) = v[j];
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int j = 0; j < kSumRows / 2; ++j)
+                v[j] = *reinterpret_cast<const float4*>(scores + offs[j] + (long long)(c + 1) * kSumCols);
         }
         __syncthreads();
+        if (lane < kSumRows) {
+            const int ncol = min(kSumCols, L.count - c * kSumCols);
+            const float* rowp = tile[buf][lane];
+            int q = 0;
+            for (; q + 4 <= ncol; q += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(rowp + q);
+                acc += t.x; acc += t.y; acc += t.z; acc += t.w;
+            }
+            for (; q < ncol; ++q) acc += rowp[q];
+        }
     }
-    if (row < nrows) {
+    const int row = blockIdx.x * kSumRows + lane;
+    if (lane < kSumRows && row < nrows) {
+        const int frame = row / nfades, f = row - frame * nfades;
         float r = acc / L.blackScore;
         if (take_abs) r = fabsf(r);
         out[(long long)frame * out_frame_stride + L.out_off + f] = r;
@@ -210,7 +229,7 @@ hipError_t launch_ordered_sum(hipStream_t st, const EvalLogoDev* dlogos, int nlo
                               const float* dscores, long long scores_per_frame, float* dout, int out_frame_stride, int take_abs)
 {
     if (nframes <= 0 || nlogos <= 0) return hipSuccess;
-    dim3 grid((unsigned)((nframes * nfades + 63) / 64), (unsigned)nlogos), block(64);
+    dim3 grid((unsigned)((nframes * nfades + kSumRows - 1) / kSumRows), (unsigned)nlogos), block(64);
     hipLaunchKernelGGL(ordered_sum_kernel, grid, block, 0, st, dlogos, nfades, nframes, dscores, scores_per_frame, dout,
                        out_frame_stride, take_abs);
     return hipGetLastError();

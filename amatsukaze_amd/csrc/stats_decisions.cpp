@@ -66,7 +66,8 @@ void classify_cadence(const uint64_t* metrics, int nframes, int width, int heigh
         }
         const int span = b - a;
         uint8_t cls, ph = 0;
-        if (motion < still || nDecided * 2 < span) { cls = last; ph = last == kCadence24p ? (uint8_t)((lastPhase + 1) % 5) : 0; }
+        if (motion < still) { cls = last; ph = last == kCadence24p ? (uint8_t)((lastPhase + 1) % 5) : 0; }   // nothing moves: keep
+        else if (nDecided * 2 < span) { cls = kCadence60i; }         // moving, but neither weave is clean: true interlaced
         else if (best * 10 >= span * 7) { cls = kCadence24p; ph = (uint8_t)((n - a + bestPhase) % 5); }
         else if (nC * 10 >= span * 7) { cls = kCadence30p; }
         else if (nDecided * 10 >= span * 7 && best * 10 >= span * 5) { cls = kCadence24p; ph = (uint8_t)((n - a + bestPhase) % 5); }

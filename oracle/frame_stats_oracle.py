@@ -73,8 +73,10 @@ def classify_cadence(m: np.ndarray, width: int, height: int):
                     hit += code[k] == 'P'
             if hit > best:
                 best, best_phase = hit, p
-        if motion < still or nD * 2 < span:
+        if motion < still:
             cls, p = last, ((last_phase + 1) % 5 if last == 1 else 0)
+        elif nD * 2 < span:
+            cls, p = 0, 0
         elif best * 10 >= span * 7:
             cls, p = 1, (i - a + best_phase) % 5
         elif nC * 10 >= span * 7:
