@@ -33,16 +33,16 @@ std::vector<int> scene_changes(const uint64_t* metrics, int nframes, int width, 
 }
 
 // Field matching per frame from the two weaves' combing energy (minus nothing: both share the picture's
-// own vertical detail): 'C' the frame's own fields belong together (COMB*2 < COMB_PREV), 'P' its top
-// field belongs with the previous bottom field (COMB_PREV*2 < COMB), 'B' undecided.  3:2 pulldown gives
+// own vertical detail): 'C' the frame's own fields belong together (COMB*1.5 < COMB_PREV), 'P' its top
+// field belongs with the previous bottom field (COMB_PREV*1.5 < COMB), 'B' undecided.  3:2 pulldown gives
 // C C P P x every five frames, progressive 30p gives all C, interlaced video all B (while moving).
 void classify_cadence(const uint64_t* metrics, int nframes, int width, int height, uint8_t* cadence, uint8_t* phase)
 {
     std::vector<char> code(nframes, 'B');
     for (int n = 0; n < nframes; ++n) {
         const uint64_t c0 = m(metrics, n, W_COMB), c1 = m(metrics, n, W_COMB_PREV);
-        if (c0 * 2 < c1) code[n] = 'C';
-        else if (c1 * 2 < c0) code[n] = 'P';
+        if (c0 * 3 < c1 * 2) code[n] = 'C';
+        else if (c1 * 3 < c0 * 2) code[n] = 'P';
     }
     const uint64_t still = (uint64_t)width * height / 2;      // < 0.5 per pixel of field difference: nothing moves
     uint8_t last = kCadence60i, lastPhase = 0;

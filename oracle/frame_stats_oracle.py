@@ -51,7 +51,7 @@ def classify_cadence(m: np.ndarray, width: int, height: int):
     c0 = [int(x) for x in m[:, 3]]
     c1 = [int(x) for x in m[:, 4]]
     en = [int(a) + int(b) for a, b in zip(m[:, 0], m[:, 1])]
-    code = ['C' if c0[i] * 2 < c1[i] else ('P' if c1[i] * 2 < c0[i] else 'B') for i in range(n)]
+    code = ['C' if c0[i] * 3 < c1[i] * 2 else ('P' if c1[i] * 3 < c0[i] * 2 else 'B') for i in range(n)]
     still = width * height // 2
     cad = np.zeros(n, np.uint8)
     ph = np.zeros(n, np.uint8)
