@@ -50,9 +50,6 @@ void AmtGpuContext::prof_resolve()
 namespace amt {
 
 namespace {
-constexpr int kStagePerThreadHost = 16;                            // must match eval_kernels.hip
-constexpr int kPlaneCapMax = kEvalThreads * kStagePerThreadHost;   // floats per LDS plane
-
 int lds_pitch(int w) { return ((w + 31) & ~31) + 8; }
 }
 
@@ -61,6 +58,10 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
     : ctx_(ctx), specs_(std::move(specs)), fades_(std::move(fades)), take_abs_(take_abs), out_frame_stride_(out_frame_stride)
 {
     ctx_->bind();
+    if (const char* e = std::getenv("AMTGPU_PXT")) pxt_ = std::atoi(e);
+    if (pxt_ != 1 && pxt_ != 2 && pxt_ != 4) pxt_ = 2;
+    const int kPlaneCapMax = kEvalThreads * eval_stage_per_thread(pxt_);   // floats per LDS plane
+    const int kBandMaxPx = kEvalThreads * pxt_;
     const int nl = (int)specs_.size();
     const int nf = (int)fades_.size();
     std::vector<EvalLogoDev> hl(nl);
@@ -158,7 +159,7 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
         const int n = std::min(chunk, nframes - f0);
         const uint8_t* base = static_cast<const uint8_t*>(dY) + (dframe_map ? 0 : (int64_t)f0 * frame_stride_bytes);
         int sp = ctx_->prof_begin("logo_corr_kernel");
-        AMT_HIP(launch_logo_corr(ctx_->stream, bits, d_logos_.get(), d_bands_.get(), (int)bands_.size(), d_fades_.get(),
+        AMT_HIP(launch_logo_corr(ctx_->stream, bits, pxt_, d_logos_.get(), d_bands_.get(), (int)bands_.size(), d_fades_.get(),
                                  (int)fades_.size(), base, dframe_map ? dframe_map + f0 : nullptr, frame_stride_bytes / es, pitch,
                                  n, d_scratch_.get(), scores_per_frame_, plane_cap_));
         ctx_->prof_end(sp);

@@ -25,10 +25,9 @@
 
 namespace amt {
 
-// per-thread staged-pixel budget: plane floats <= kEvalThreads * kStagePerThread
-constexpr int kStagePerThread = 16;
-
-template <typename pix_t, int PXT>
+// PXT = mask pixels per thread (kernel taps held in VGPRs), STG = staged rectangle pixels per thread
+// (plane floats <= kEvalThreads * STG).  {4,16}: 198 VGPRs, 2 waves/SIMD; {2,12}: ~128 VGPRs, 4 waves/SIMD.
+template <typename pix_t, int PXT, int STG>
 __global__ __launch_bounds__(kEvalThreads)
 void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands,
                       int nbands, int nbands8, const float* __restrict__ fades, int nfades,
@@ -54,12 +53,12 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
     const int nplane = B.nrows * lp;
 
     // ---- stage: source pixel s and background estimate bg = a*s + b*maxv, kept in registers ----
-    float sreg[kStagePerThread], bgreg[kStagePerThread];
+    float sreg[STG], bgreg[STG];
     {
         const int srcFrame = frame_map ? frame_map[frame] : frame;      // optional gather of non-contiguous frames
         const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
 #pragma unroll
-        for (int q = 0; q < kStagePerThread; ++q) {
+        for (int q = 0; q < STG; ++q) {
             const int i = tid + q * kEvalThreads;
             float s = 0.0f, bg = 0.0f;
             if (i < nplane) {
@@ -112,7 +111,7 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
     auto mix = [&](float* dst, float fade) {
         const float omf = 1 - fade;
 #pragma unroll
-        for (int q = 0; q < kStagePerThread; ++q) {
+        for (int q = 0; q < STG; ++q) {
             const int i = tid + q * kEvalThreads;
             if (i < nplane) dst[i] = fade * bgreg[q] + omf * sreg[q];
         }
@@ -206,7 +205,16 @@ void ordered_sum_kernel(const EvalLogoDev* __restrict__ logos, int nfades, int n
 // ---- launch helpers (called from the host engine) ----
 size_t corr_lds_bytes(int plane_cap) { return (size_t)plane_cap * 2 * sizeof(float); }
 
-hipError_t launch_logo_corr(hipStream_t st, int bits, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
+template <typename pix_t, int PXT, int STG>
+static void launch_corr_t(hipStream_t st, dim3 grid, size_t lds, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
+                          int nbands8, const float* dfades, int nfades, const void* dY, const int* dframe_map,
+                          long long frame_stride_elems, int pitch, float maxv, float* dscores, long long scores_per_frame, int plane_cap)
+{
+    hipLaunchKernelGGL((logo_corr_kernel<pix_t, PXT, STG>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, nbands, nbands8, dfades,
+                       nfades, (const pix_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap);
+}
+
+hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
                             const float* dfades, int nfades, const void* dY, const int* dframe_map, long long frame_stride_elems,
                             int pitch, int nframes, float* dscores, long long scores_per_frame, int plane_cap)
 {
@@ -214,14 +222,16 @@ hipError_t launch_logo_corr(hipStream_t st, int bits, const EvalLogoDev* dlogos,
     const long long nblocks = (long long)nframes * nbands8 * 8;
     if (nblocks <= 0) return hipSuccess;
     const float maxv = (float)((1 << bits) - 1);
-    dim3 grid((unsigned)nblocks), block(kEvalThreads);
+    dim3 grid((unsigned)nblocks);
     const size_t lds = corr_lds_bytes(plane_cap);
-    if (bits <= 8)
-        hipLaunchKernelGGL((logo_corr_kernel<uint8_t, kEvalPxPerThread>), grid, block, lds, st, dlogos, dbands, nbands, nbands8,
-                           dfades, nfades, (const uint8_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap);
-    else
-        hipLaunchKernelGGL((logo_corr_kernel<uint16_t, kEvalPxPerThread>), grid, block, lds, st, dlogos, dbands, nbands, nbands8,
-                           dfades, nfades, (const uint16_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap);
+#define AMT_CORR(T, P, S) launch_corr_t<T, P, S>(st, grid, lds, dlogos, dbands, nbands, nbands8, dfades, nfades, dY, dframe_map, \
+                                               frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap)
+    if (bits <= 8) {
+        if (pxt == 4) AMT_CORR(uint8_t, 4, 16); else if (pxt == 2) AMT_CORR(uint8_t, 2, 12); else AMT_CORR(uint8_t, 1, 8);
+    } else {
+        if (pxt == 4) AMT_CORR(uint16_t, 4, 16); else if (pxt == 2) AMT_CORR(uint16_t, 2, 12); else AMT_CORR(uint16_t, 1, 8);
+    }
+#undef AMT_CORR
     return hipGetLastError();
 }
 

@@ -5,8 +5,8 @@
 namespace amt {
 
 constexpr int kEvalThreads = 256;   // threads per workgroup of the correlation kernel
-constexpr int kEvalPxPerThread = 4; // mask pixels a thread keeps kernels for (registers)
-constexpr int kBandMaxPx = kEvalThreads * kEvalPxPerThread;
+// kernel variants: mask pixels per thread (PXT) -> staged rectangle pixels per thread (STG)
+inline constexpr int eval_stage_per_thread(int pxt) { return pxt == 4 ? 16 : (pxt == 2 ? 12 : 8); }
 constexpr int kNumBins = 32;        // 256 >> 3 background levels (LogoScan.hpp:63-68)
 
 // one evaluation logo (a LogoDataParam after CreateLogoMask) resident in HBM
