@@ -25,6 +25,17 @@
 
 namespace amt {
 
+// Table pointers reach the kernel inside a struct read from memory, so the compiler cannot tell their address
+// space and would emit FLAT loads (which also tick the LDS counter and serialise against the window reads).
+// They are all hipMalloc'ed: say so.
+// They are all hipMalloc'ed: say so, and address them as uniform base + 32-bit byte offset so that the loads
+// take the SGPR-base form instead of 64-bit per-lane address arithmetic.
+typedef const __attribute__((address_space(1))) char* gbase_t;
+template <typename T> __device__ __forceinline__ T gload(gbase_t base, unsigned byteoff)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(base + byteoff);
+}
+
 // PXT = mask pixels per thread (kernel taps held in VGPRs), STG = staged rectangle pixels per thread
 // (plane floats <= kEvalThreads * STG).  {4,16}: 198 VGPRs, 2 waves/SIMD; {2,12}: ~128 VGPRs, 4 waves/SIMD.
 template <typename pix_t, int PXT, int STG>
@@ -47,6 +58,8 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
 
     const EvalBand B = bands[band];
     const EvalLogoDev L = logos[B.logo];
+    const gbase_t gA = (gbase_t)L.a, gB = (gbase_t)L.b, gPos = (gbase_t)L.pos, gKern = (gbase_t)L.kern, gScales = (gbase_t)L.scales;
+    const unsigned cpad = (unsigned)L.count_pad;
     const int tid = threadIdx.x;
     const int w = L.w;
     const int lp = L.lp;                           // LDS row pitch: rows 8 banks apart
@@ -56,7 +69,8 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
     float sreg[STG], bgreg[STG];
     {
         const int srcFrame = frame_map ? frame_map[frame] : frame;      // optional gather of non-contiguous frames
-        const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
+        const gbase_t src = (gbase_t)(Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx);
+        constexpr unsigned ES = sizeof(pix_t);
 #pragma unroll
         for (int q = 0; q < STG; ++q) {
             const int i = tid + q * kEvalThreads;
@@ -68,18 +82,18 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
                     const int y = B.y0 + r;
                     if (L.deint) {
                         if (y == 0 || y == L.h - 1) {
-                            s = (float)src[x + (long long)y * pitch];
+                            s = (float)gload<pix_t>(src, (unsigned)(x + y * pitch) * ES);
                         } else {
-                            const int p0 = src[x + (long long)(y - 1) * pitch];
-                            const int p1 = src[x + (long long)y * pitch];
-                            const int p2 = src[x + (long long)(y + 1) * pitch];
+                            const int p0 = gload<pix_t>(src, (unsigned)(x + (y - 1) * pitch) * ES);
+                            const int p1 = gload<pix_t>(src, (unsigned)(x + y * pitch) * ES);
+                            const int p2 = gload<pix_t>(src, (unsigned)(x + (y + 1) * pitch) * ES);
                             s = (float)(p0 + 2 * p1 + p2 + 2) / 4.0f;
                         }
                     } else {
-                        s = (float)src[x + (long long)(y * L.row_step) * pitch];
+                        s = (float)gload<pix_t>(src, (unsigned)(x + y * L.row_step * pitch) * ES);
                     }
-                    const float a = L.a[x + y * w];
-                    const float b = L.b[x + y * w];
+                    const float a = gload<float>(gA, (unsigned)(x + y * w) * 4u);
+                    const float b = gload<float>(gB, (unsigned)(x + y * w) * 4u);
                     bg = unblend_bg(a, b, maxv, s);
                 }
             }
@@ -91,19 +105,19 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
     // ---- this thread's mask pixels: kernel taps in registers for the whole fade loop ----
     float k[PXT][25];
     int woff[PXT];
-    int midx[PXT];
+    unsigned midx[PXT];
     bool act[PXT];
 #pragma unroll
     for (int p = 0; p < PXT; ++p) {
         const int local = p * kEvalThreads + tid;
         act[p] = local < B.npx;
-        const int m = B.m0 + (act[p] ? local : 0);
+        const unsigned m = (unsigned)(B.m0 + (act[p] ? local : 0));
         midx[p] = m;
-        const uint32_t ps = L.pos[m];
+        const uint32_t ps = gload<uint32_t>(gPos, m * 4u);
         const int x = ps & 0xFFFF, y = ps >> 16;
         woff[p] = (y - 2 - B.y0) * lp + (x - 2);
 #pragma unroll
-        for (int t = 0; t < 25; ++t) k[p][t] = L.kern[(long long)t * L.count_pad + m];
+        for (int t = 0; t < 25; ++t) k[p][t] = gload<float>(gKern, ((unsigned)t * cpad + m) * 4u);
     }
 
     float* wbuf0 = lds;
@@ -119,7 +133,8 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
 
     mix(wbuf0, fades[0]);
     __syncthreads();
-    float* out = scores + (long long)frame * scores_per_frame + L.score_off;
+    __attribute__((address_space(1))) char* out =
+        (__attribute__((address_space(1))) char*)(scores + (long long)frame * scores_per_frame + L.score_off);
     for (int f = 0; f < nfades; ++f) {
         const float* cur = (f & 1) ? wbuf1 : wbuf0;
         float* nxt = (f & 1) ? wbuf0 : wbuf1;
@@ -134,8 +149,9 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
                     for (int c = 0; c < 5; ++c) v[r][c] = cur[woff[p] + r * lp + c];
                 float mean;
                 const float corr = corr5x5(k[p], v, &mean);
-                const float2 sl = L.scales[(long long)score_bin(mean) * L.count_pad + midx[p]];
-                out[(long long)f * L.count_pad + midx[p]] = score_term(corr, sl.x, sl.y);
+                const float2 sl = gload<float2>(gScales, ((unsigned)score_bin(mean) * cpad + midx[p]) * 8u);
+                *reinterpret_cast<__attribute__((address_space(1))) float*>(out + ((unsigned)f * cpad + midx[p]) * 4u) =
+                    score_term(corr, sl.x, sl.y);
             }
         }
         __syncthreads();
