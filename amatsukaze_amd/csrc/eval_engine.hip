@@ -65,7 +65,7 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
     const int nl = (int)specs_.size();
     const int nf = (int)fades_.size();
     std::vector<EvalLogoDev> hl(nl);
-    d_a_.resize(nl); d_b_.resize(nl); d_kern_.resize(nl); d_pos_.resize(nl); d_scales_.resize(nl);
+    d_a_.resize(nl); d_b_.resize(nl); d_kern_.resize(nl); d_pos_.resize(nl); d_rast_.resize(nl); d_scales_.resize(nl);
     long long off = 0;
     plane_cap_ = 0;
     for (int i = 0; i < nl; ++i) {
@@ -77,24 +77,82 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         if (5 * lp > kPlaneCapMax) throw std::runtime_error("logo too wide for the evaluation kernel");
         const int cpad = std::max(kEvalThreads, (T.count + kEvalThreads - 1) / kEvalThreads * kEvalThreads);
 
-        // tables, re-laid for the kernel: taps and bins major, mask pixels minor
+        // bands: raster-consecutive mask pixels, at most kBandMaxPx, whose windows fit the LDS plane
+        const size_t firstBand = bands_.size();
+        {
+            int m = 0;
+            while (m < T.count) {
+                EvalBand B;
+                B.logo = i; B.m0 = m;
+                const int ytop = (int)(T.pos[m] >> 16) - 2;
+                int e = m;
+                while (e < T.count && e - m < kBandMaxPx) {
+                    const int ybot = (int)(T.pos[e] >> 16) + 2;
+                    if ((ybot - ytop + 1) * lp > kPlaneCapMax) break;
+                    ++e;
+                }
+                B.npx = e - m;
+                B.y0 = ytop;
+                B.nrows = (int)(T.pos[e - 1] >> 16) + 2 - ytop + 1;
+                plane_cap_ = std::max(plane_cap_, B.nrows * lp);
+                bands_.push_back(B);
+                m = e;
+            }
+        }
+        // slot order: inside every 128-slot block of a band, deal the pixels into half-waves (32 slots) so that
+        // the 32 window origins fall into 32 different LDS banks (bank = (x + y*lp) mod 32) as far as possible;
+        // every tap of the 5x5 window then reads conflict-free as well (same shift for all lanes)
+        std::vector<uint32_t> order(T.count);
+        for (size_t bi = firstBand; bi < bands_.size(); ++bi) {
+            const EvalBand& B = bands_[bi];
+            for (int b0 = 0; b0 < B.npx; b0 += 128) {
+                const int nb = std::min(128, B.npx - b0);
+                std::vector<int> bucket[32];
+                for (int j = 0; j < nb; ++j) {
+                    const uint32_t ps = T.pos[B.m0 + b0 + j];
+                    bucket[((ps & 0xFFFF) + (ps >> 16) * (uint32_t)lp) & 31].push_back(B.m0 + b0 + j);
+                }
+                int q = B.m0 + b0;
+                int left = nb;
+                while (left > 0) {
+                    // one half-wave: at most one pixel per bank, fullest banks first
+                    int idx[32];
+                    for (int r = 0; r < 32; ++r) idx[r] = r;
+                    std::stable_sort(idx, idx + 32, [&](int a, int b) { return bucket[a].size() > bucket[b].size(); });
+                    int taken = 0;
+                    const int want = std::min(32, left);
+                    for (int r = 0; r < 32 && taken < want; ++r)
+                        if (!bucket[idx[r]].empty()) { order[q++] = bucket[idx[r]].front(); bucket[idx[r]].erase(bucket[idx[r]].begin()); ++taken; }
+                    for (int r = 0; r < 32 && taken < want; ++r)     // not enough distinct banks left: accept conflicts
+                        while (!bucket[idx[r]].empty() && taken < want) { order[q++] = bucket[idx[r]].front(); bucket[idx[r]].erase(bucket[idx[r]].begin()); ++taken; }
+                    left -= taken;
+                }
+            }
+        }
+
+        // tables, re-laid for the kernel: taps and bins major, slots minor
         std::vector<uint32_t> pos(cpad, T.count ? T.pos[0] : ((2u << 16) | 2u));
-        std::copy(T.pos.begin(), T.pos.end(), pos.begin());
+        std::vector<uint32_t> rast(cpad, 0);
         std::vector<float> kern((size_t)25 * cpad, 0.0f);
         std::vector<float2> scales((size_t)kNumBins * cpad, float2{0.0f, 0.0f});
-        for (int m = 0; m < T.count; ++m) {
-            for (int t = 0; t < 25; ++t) kern[(size_t)t * cpad + m] = T.kernels[(size_t)m * 25 + t];
+        for (int q = 0; q < T.count; ++q) {
+            const int m = (int)order[q];
+            pos[q] = T.pos[m];
+            rast[q] = (uint32_t)m;
+            for (int t = 0; t < 25; ++t) kern[(size_t)t * cpad + q] = T.kernels[(size_t)m * 25 + t];
             for (int c = 0; c < kNumBins; ++c)
-                scales[(size_t)c * cpad + m] = float2{T.scales[((size_t)m * 32 + c) * 2], T.scales[((size_t)m * 32 + c) * 2 + 1]};
+                scales[(size_t)c * cpad + q] = float2{T.scales[((size_t)m * 32 + c) * 2], T.scales[((size_t)m * 32 + c) * 2 + 1]};
         }
         d_a_[i].upload(S.planes.A(0), (size_t)w * h, ctx_->stream);
         d_b_[i].upload(S.planes.B(0), (size_t)w * h, ctx_->stream);
         d_pos_[i].upload(pos, ctx_->stream);
+        d_rast_[i].upload(rast, ctx_->stream);
         d_kern_[i].upload(kern, ctx_->stream);
         d_scales_[i].upload(scales, ctx_->stream);
 
         EvalLogoDev& D = hl[i];
-        D.a = d_a_[i].get(); D.b = d_b_[i].get(); D.pos = d_pos_[i].get(); D.kern = d_kern_[i].get(); D.scales = d_scales_[i].get();
+        D.a = d_a_[i].get(); D.b = d_b_[i].get(); D.pos = d_pos_[i].get(); D.rast = d_rast_[i].get();
+        D.kern = d_kern_[i].get(); D.scales = d_scales_[i].get();
         D.w = w; D.h = h; D.count = T.count; D.count_pad = cpad;
         D.imgx = S.imgx; D.imgy = S.imgy; D.row0 = S.row0; D.row_step = S.row_step; D.deint = S.deint;
         D.score_off = (int)off;
@@ -103,26 +161,6 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         D.lp = lp;
         D.lp_magic = (uint32_t)((0x100000000ull + lp - 1) / lp);
         off += (long long)nf * cpad;
-
-        // bands: raster-consecutive mask pixels, at most kBandMaxPx, whose windows fit the LDS plane
-        int m = 0;
-        while (m < T.count) {
-            EvalBand B;
-            B.logo = i; B.m0 = m;
-            const int ytop = (int)(T.pos[m] >> 16) - 2;
-            int e = m;
-            while (e < T.count && e - m < kBandMaxPx) {
-                const int ybot = (int)(T.pos[e] >> 16) + 2;
-                if ((ybot - ytop + 1) * lp > kPlaneCapMax) break;
-                ++e;
-            }
-            B.npx = e - m;
-            B.y0 = ytop;
-            B.nrows = (int)(T.pos[e - 1] >> 16) + 2 - ytop + 1;
-            plane_cap_ = std::max(plane_cap_, B.nrows * lp);
-            bands_.push_back(B);
-            m = e;
-        }
     }
     scores_per_frame_ = off;
     d_logos_.upload(hl, ctx_->stream);

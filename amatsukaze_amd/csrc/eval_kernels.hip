@@ -31,6 +31,7 @@ namespace amt {
 // They are all hipMalloc'ed: say so, and address them as uniform base + 32-bit byte offset so that the loads
 // take the SGPR-base form instead of 64-bit per-lane address arithmetic.
 typedef const __attribute__((address_space(1))) char* gbase_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <typename T> __device__ __forceinline__ T gload(gbase_t base, unsigned byteoff)
 {
     return *reinterpret_cast<const __attribute__((address_space(1))) T*>(base + byteoff);
@@ -105,14 +106,16 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
     // ---- this thread's mask pixels: kernel taps in registers for the whole fade loop ----
     float k[PXT][25];
     int woff[PXT];
-    unsigned midx[PXT];
+    unsigned qslot[PXT];     // position in the (bank-permuted) tables
+    unsigned midx[PXT];      // raster index of the mask pixel = position of its score in the scratch row
     bool act[PXT];
 #pragma unroll
     for (int p = 0; p < PXT; ++p) {
         const int local = p * kEvalThreads + tid;
         act[p] = local < B.npx;
         const unsigned m = (unsigned)(B.m0 + (act[p] ? local : 0));
-        midx[p] = m;
+        qslot[p] = m;
+        midx[p] = gload<uint32_t>((gbase_t)L.rast, m * 4u);
         const uint32_t ps = gload<uint32_t>(gPos, m * 4u);
         const int x = ps & 0xFFFF, y = ps >> 16;
         woff[p] = (y - 2 - B.y0) * lp + (x - 2);
@@ -149,7 +152,7 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
                     for (int c = 0; c < 5; ++c) v[r][c] = cur[woff[p] + r * lp + c];
                 float mean;
                 const float corr = corr5x5(k[p], v, &mean);
-                const float2 sl = gload<float2>(gScales, ((unsigned)score_bin(mean) * cpad + midx[p]) * 8u);
+                const f32x2_t sl = gload<f32x2_t>(gScales, ((unsigned)score_bin(mean) * cpad + qslot[p]) * 8u);
                 *reinterpret_cast<__attribute__((address_space(1))) float*>(out + ((unsigned)f * cpad + midx[p]) * 4u) =
                     score_term(corr, sl.x, sl.y);
             }

@@ -13,7 +13,10 @@ constexpr int kNumBins = 32;        // 256 >> 3 background levels (LogoScan.hpp:
 struct EvalLogoDev {
     const float* a;          // [h*w]   A plane of the evaluation logo (deint or field)
     const float* b;          // [h*w]
-    const uint32_t* pos;     // [count_pad]  (y << 16) | x, raster order
+    const uint32_t* pos;     // [count_pad]  (y << 16) | x, SLOT order (see rast)
+    const uint32_t* rast;    // [count_pad]  slot -> raster index of the mask pixel.  Within every 128-slot block of a
+                             // band the pixels are permuted so that each half-wave (32 consecutive slots) reads 32
+                             // distinct LDS banks; kern/scales/pos are stored in slot order, scores in raster order
     const float* kern;       // [25][count_pad]   tap-major so lanes read consecutive floats
     const float2* scales;    // [32][count_pad]   bin-major {scale, scale2}
     int w, h;                // evaluation-logo size (field logos: h/2)
