@@ -50,7 +50,12 @@ void AmtGpuContext::prof_resolve()
 namespace amt {
 
 namespace {
-int lds_pitch(int w) { return ((w + 31) & ~31) + 8; }
+int lds_pitch(int w)
+{
+    int pad = 8;
+    if (const char* e = std::getenv("AMTGPU_LPPAD")) pad = std::atoi(e);      // experiments
+    return ((w + 31) & ~31) + pad;
+}
 }
 
 EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std::vector<float> fades, bool take_abs,
@@ -103,7 +108,13 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         // the 32 window origins fall into 32 different LDS banks (bank = (x + y*lp) mod 32) as far as possible;
         // every tap of the 5x5 window then reads conflict-free as well (same shift for all lanes)
         std::vector<uint32_t> order(T.count);
-        for (size_t bi = firstBand; bi < bands_.size(); ++bi) {
+        // Measured on MI355X (profiles/r01_notes.md): with only 128 pixels per block the greedy deal still leaves one
+        // duplicate bank in most half-waves (cost = max multiplicity), so SQ_LDS_BANK_CONFLICT barely moves
+        // (105M -> 96M per 512 frames) while the scattered score stores cost more than that buys.  Kept as an
+        // experiment switch (AMTGPU_PERM=1); the default is raster order.
+        const bool noperm = std::getenv("AMTGPU_PERM") == nullptr;
+        for (size_t q = 0; q < order.size(); ++q) order[q] = (uint32_t)q;
+        for (size_t bi = firstBand; bi < bands_.size() && !noperm; ++bi) {
             const EvalBand& B = bands_[bi];
             for (int b0 = 0; b0 < B.npx; b0 += 128) {
                 const int nb = std::min(128, B.npx - b0);

@@ -19,6 +19,7 @@
 // global reads stay coalesced).
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 
 #include "eval_plan.h"
 #include "exact_math.h"
@@ -119,12 +120,14 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
         const uint32_t ps = gload<uint32_t>(gPos, m * 4u);
         const int x = ps & 0xFFFF, y = ps >> 16;
         woff[p] = (y - 2 - B.y0) * lp + (x - 2);
+        if (plane_cap < 0) woff[p] = (tid & 63);          // DEBUG probe: conflict-free window origin
 #pragma unroll
         for (int t = 0; t < 25; ++t) k[p][t] = gload<float>(gKern, ((unsigned)t * cpad + m) * 4u);
     }
 
+    const int pcap = plane_cap < 0 ? -plane_cap : plane_cap;
     float* wbuf0 = lds;
-    float* wbuf1 = lds + plane_cap;
+    float* wbuf1 = lds + pcap;
     auto mix = [&](float* dst, float fade) {
         const float omf = 1 - fade;
 #pragma unroll
@@ -243,6 +246,7 @@ hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, const EvalLogoDev
     const float maxv = (float)((1 << bits) - 1);
     dim3 grid((unsigned)nblocks);
     const size_t lds = corr_lds_bytes(plane_cap);
+    if (getenv("AMTGPU_DBG_WOFF")) plane_cap = -plane_cap;
 #define AMT_CORR(T, P, S) launch_corr_t<T, P, S>(st, grid, lds, dlogos, dbands, nbands, nbands8, dfades, nfades, dY, dframe_map, \
                                                frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap)
     if (bits <= 8) {
