@@ -110,6 +110,7 @@ def main():
 
     import amt_synth as S
     from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Context, DeviceClip, FrameStats, Logo, LogoFrame
+    from amatsukaze_amd import sharding as SH
 
     N = args.frames
     logos_np, alpha, alphaUV = make_logos()
@@ -126,7 +127,6 @@ def main():
     d_analysis = torch.empty((N, 33), dtype=torch.float32, device=dev)
     d_stats = torch.empty((N, 8), dtype=torch.int64, device=dev)
     h_analysis = torch.empty((N, 33), dtype=torch.float32).pin_memory()
-    gathered = [torch.empty((N, 3, 2), dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
 
     def step():
         lf.scan_batch(dclip.Y, 8, 0, N)                              # a9: all-frames scan, 3 logos x 2 fades
@@ -138,7 +138,7 @@ def main():
         stats.run_device(dclip.Y, d_stats)                           # CM field-diff + KFM comb metrics
         if world > 1:
             ev = torch.from_numpy(lf.evalResults).to(dev)
-            dist.all_gather(gathered, ev)                            # the scan's one exchange step
+            SH.gather_frame_records(ev, N * world)                   # the scan's one exchange step (RCCL all_gather)
 
     def fence():
         torch.cuda.synchronize()
@@ -198,12 +198,19 @@ def main():
         if "ordered_sum_kernel" in kern:
             k = kern["ordered_sum_kernel"]
             out_kern["ordered_sum_kernel"] = {"avg_ms": k["avg_ms"], "launches": k["calls"], "total_ms": k["total_ms"]}
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        except Exception:
+            pass
         dom = max(kern, key=lambda n: kern[n]["total_ms"]) if kern else None
         if dom == "logo_corr_kernel":
             kk = out_kern[dom]
             per_launch_flops = evals_per_frame * FLOPS_PER_MASK_PIXEL_EVAL * frames_timed / max(1, kern[dom]["calls"])
             roofline = {"kernel": dom, "bound": "mfma", "achieved": kk["achieved_tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": kk["frac_fp32_peak"], "traffic": None, "avg_launch_ms": kk["avg_ms"], "flops_per_launch": per_launch_flops,
+                        "frac": kk["frac_fp32_peak"],
+                        "traffic": (pmc.get("logo_corr_kernel", {}).get("hbm_bytes_per_frame_analyze") or 0) * frames_timed / max(1, kern[dom]["calls"]) or None,
+                        "traffic_note": pmc.get("note"), "avg_launch_ms": kk["avg_ms"], "flops_per_launch": per_launch_flops,
                         "note": "fp32 VALU kernel (no MFMA: per-pixel private 25-tap kernels, no operand reuse); priced against the fp32 "
                                 "vector peak, which equals the dense fp32 MFMA peak; ops are mul/add/sub without FMA contraction "
                                 "(bit-exactness), so 0.5 is the ceiling of this fraction"}

@@ -1,0 +1,56 @@
+"""The HIP path against the committed golden vectors of the REAL reference (tests/golden/, tools/make_golden.py):
+no oracle in the loop."""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_reproduces_reference_golden(tmp_path):
+    import torch
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Context, DeviceClip, Logo, LogoFrame, LogoScan, ScanLogo
+    g = G.load()
+    W, H, LW, LH, X, Y0, N = (g[k] for k in ("W", "H", "LW", "LH", "X", "Y0", "N"))
+    dev = torch.device("cuda:0")
+    ctx = Context(0)
+    Y, U, V = G.frames(g, pitch_pad=32)
+    mk = lambda: DeviceClip(torch.from_numpy(Y).to(dev), torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev), W, H)
+    logos = [Logo.from_planes(ctx, g[k], LW, LH, W, H, X, Y0) for k in ("logo0", "logo1")]
+    p = tmp_path / "l.lgd"
+    logos[0].save(p, "golden", 1041)
+    assert p.read_bytes() == g["lgd0"].tobytes()
+    lf = LogoFrame(ctx, logos, 0.35)
+    lf.scanFrames(mk())
+    assert lf.evalResults.tobytes() == g["logoframe_evals"].tobytes()
+    lf.selectLogo(2)
+    assert lf.getBestLogo() == int(g["logoframe_best"]) and np.float32(lf.getLogoRatio()) == g["logoframe_ratio"]
+    out = tmp_path / "lf.txt"
+    lf.writeResult(out, 0)
+    assert out.read_bytes() == g["logoframe_text"].tobytes()
+    an = AMTAnalyzeLogo(ctx, logos[0], 0.35).analyze(mk())
+    assert an.tobytes() == g["analysis"].tobytes()
+    for tag in ("nolf", "lf"):
+        dc = mk()
+        er = AMTEraseLogo(ctx, logos[0], g["logof_text"].tobytes().decode() if tag == "lf" else "", 0, 16)
+        fades = er.calc_fades(an, N)
+        assert fades.tobytes() == g[f"erase_{tag}_fades"].tobytes()
+        er.erase(dc, fades)
+        cy, cu, cv = G.crops(g, dc.Y.cpu().numpy(), dc.U.cpu().numpy(), dc.V.cpu().numpy())
+        assert np.array_equal(cy, g[f"erase_{tag}_Y"]) and np.array_equal(cu, g[f"erase_{tag}_U"]) and np.array_equal(cv, g[f"erase_{tag}_V"])
+    scan = LogoScan(ctx, LW, LH, 12)
+    valid, nacc = scan.add_batch(mk(), X, Y0)
+    assert valid.tolist() == g["scan_valid"].tolist()
+    s, pl = scan.sums()
+    ref = g["scan_sums"]
+    s = s.reshape(-1, 3)
+    assert np.array_equal(s[:, 0], ref[:, 0].astype(np.int64)) and np.array_equal(s[:, 1], ref[:, 2].astype(np.int64)) \
+        and np.array_equal(s[:, 2], ref[:, 4].astype(np.int64))
+    assert scan.get_logo(255, False, W, H, X, Y0).planes.tobytes() == g["scan_logo_raw"].tobytes()
+    assert scan.get_logo(255, True, W, H, X, Y0).planes.tobytes() == g["scan_logo_clean"].tobytes()
+    Y2, U2, V2 = G.frames(g, "scanlogo_crop_y", "scanlogo_crop_u", "scanlogo_crop_v")
+    dc2 = DeviceClip(torch.from_numpy(Y2).to(dev), torch.from_numpy(U2).to(dev), torch.from_numpy(V2).to(dev), W, H)
+    dst = tmp_path / "scan.lgd"
+    assert ScanLogo(ctx, dc2, 1041, dst, X, Y0, LW, LH, 12, 25)
+    assert dst.read_bytes() == g["scanlogo_lgd"].tobytes()
