@@ -34,7 +34,8 @@ W, H = 1440, 1080
 PITCH_Y, PITCH_UV = 1472, 768          # AviSynth planes are 64-byte aligned (include/avs/config.h:45)
 LW, LH, IMGX, IMGY = 256, 128, 1120, 64
 MASKRATIO = 0.35                       # CMAnalyze.hpp:291 / AMTAnalyzeLogo default
-FLOPS_PER_MASK_PIXEL_EVAL = 108        # 20+7 (mean) +1 (div) +25+25+20+7 (corr) +2 (score) +1
+FLOPS_PER_MASK_PIXEL = 101             # mean 20+4 adds + 1 div, corr 25 sub + 25 mul + 20+4 adds, score 2 mul
+FLOPS_PER_RECT_PIXEL = 6               # EvaluateLogo's unblend per rectangle pixel per evaluation (LogoScan.hpp:244-249)
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3               # fp32 vector peak == dense fp32 MFMA peak
 
@@ -169,6 +170,8 @@ def main():
         an_tab = [logos[0].mask_tables(k, MASKRATIO)["count"] for k in (0, 1, 2)]
         scan_tab = [l.mask_tables(0, MASKRATIO)["count"] for l in logos]
         evals_per_frame = 11 * sum(an_tab) + 2 * sum(scan_tab)      # mask-pixel evaluations per frame (both passes)
+        rect_px_evals = 11 * (LW * LH + 2 * LW * (LH // 2)) + 2 * 3 * LW * LH
+        flops_per_frame = FLOPS_PER_MASK_PIXEL * evals_per_frame + FLOPS_PER_RECT_PIXEL * rect_px_evals
         kern = {}
         for name, (calls, ms) in prof.items():
             kern[name] = {"calls": calls, "avg_ms": ms / max(1, calls), "total_ms": ms}
@@ -176,7 +179,7 @@ def main():
         out_kern = {}
         if "logo_corr_kernel" in kern:
             k = kern["logo_corr_kernel"]
-            flops = evals_per_frame * FLOPS_PER_MASK_PIXEL_EVAL * frames_timed
+            flops = flops_per_frame * frames_timed
             algo_bytes = (4 * LW * LH * 1 + 8 * 3 + 132) * frames_timed   # rect rows per logo-pass + results (section 8d)
             out_kern["logo_corr_kernel"] = {
                 "bound": "fp32-valu", "avg_ms": k["avg_ms"], "launches": k["calls"],
@@ -206,7 +209,7 @@ def main():
         dom = max(kern, key=lambda n: kern[n]["total_ms"]) if kern else None
         if dom == "logo_corr_kernel":
             kk = out_kern[dom]
-            per_launch_flops = evals_per_frame * FLOPS_PER_MASK_PIXEL_EVAL * frames_timed / max(1, kern[dom]["calls"])
+            per_launch_flops = flops_per_frame * frames_timed / max(1, kern[dom]["calls"])
             roofline = {"kernel": dom, "bound": "mfma", "achieved": kk["achieved_tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": kk["frac_fp32_peak"],
                         "traffic": (pmc.get("logo_corr_kernel", {}).get("hbm_bytes_per_frame_analyze") or 0) * frames_timed / max(1, kern[dom]["calls"]) or None,
