@@ -107,7 +107,7 @@ private:
     std::vector<EvalBand> bands_;
     // device state
     std::vector<DevBuf<float>> d_a_, d_b_, d_kern_;
-    std::vector<DevBuf<uint32_t>> d_pos_, d_rast_;
+    std::vector<DevBuf<uint32_t>> d_pos_, d_slots_;
     std::vector<DevBuf<float2>> d_scales_;
     DevBuf<EvalLogoDev> d_logos_;
     DevBuf<EvalBand> d_bands_;

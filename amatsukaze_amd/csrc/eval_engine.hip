@@ -66,11 +66,10 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
     if (const char* e = std::getenv("AMTGPU_PXT")) pxt_ = std::atoi(e);
     if (pxt_ != 1 && pxt_ != 2 && pxt_ != 4) pxt_ = 2;
     const int kPlaneCapMax = kEvalThreads * eval_stage_per_thread(pxt_);   // floats per LDS plane
-    const int kBandMaxPx = kEvalThreads * pxt_;
     const int nl = (int)specs_.size();
     const int nf = (int)fades_.size();
     std::vector<EvalLogoDev> hl(nl);
-    d_a_.resize(nl); d_b_.resize(nl); d_kern_.resize(nl); d_pos_.resize(nl); d_rast_.resize(nl); d_scales_.resize(nl);
+    d_a_.resize(nl); d_b_.resize(nl); d_kern_.resize(nl); d_pos_.resize(nl); d_slots_.resize(nl); d_scales_.resize(nl);
     long long off = 0;
     plane_cap_ = 0;
     for (int i = 0; i < nl; ++i) {
@@ -82,87 +81,59 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         if (5 * lp > kPlaneCapMax) throw std::runtime_error("logo too wide for the evaluation kernel");
         const int cpad = std::max(kEvalThreads, (T.count + kEvalThreads - 1) / kEvalThreads * kEvalThreads);
 
-        // bands: raster-consecutive mask pixels, at most kBandMaxPx, whose windows fit the LDS plane
-        const size_t firstBand = bands_.size();
+        // run slots: greedily group horizontally adjacent mask pixels (same row, x+1) -- they are consecutive
+        // in raster order -- into runs of at most pxt_ pixels; one thread evaluates one slot
+        std::vector<uint32_t> slots;
+        for (int m = 0; m < T.count;) {
+            int n = 1;
+            while (n < pxt_ && m + n < T.count && T.pos[m + n] == T.pos[m + n - 1] + 1) ++n;
+            slots.push_back(((uint32_t)n << 28) | (uint32_t)m);
+            m += n;
+        }
+        if (T.count >= (1 << 28)) throw std::runtime_error("logo too large");
+        // bands: up to kEvalThreads consecutive slots whose windows fit the LDS plane
         {
-            int m = 0;
-            while (m < T.count) {
+            const int ns = (int)slots.size();
+            int s = 0;
+            while (s < ns) {
                 EvalBand B;
-                B.logo = i; B.m0 = m;
-                const int ytop = (int)(T.pos[m] >> 16) - 2;
-                int e = m;
-                while (e < T.count && e - m < kBandMaxPx) {
-                    const int ybot = (int)(T.pos[e] >> 16) + 2;
+                B.logo = i; B.s0 = s;
+                const int ytop = (int)(T.pos[slots[s] & 0x0FFFFFFFu] >> 16) - 2;
+                int e = s;
+                while (e < ns && e - s < kEvalThreads) {
+                    const int ybot = (int)(T.pos[slots[e] & 0x0FFFFFFFu] >> 16) + 2;
                     if ((ybot - ytop + 1) * lp > kPlaneCapMax) break;
                     ++e;
                 }
-                B.npx = e - m;
+                B.nslots = e - s;
                 B.y0 = ytop;
-                B.nrows = (int)(T.pos[e - 1] >> 16) + 2 - ytop + 1;
+                B.nrows = (int)(T.pos[slots[e - 1] & 0x0FFFFFFFu] >> 16) + 2 - ytop + 1;
                 plane_cap_ = std::max(plane_cap_, B.nrows * lp);
                 bands_.push_back(B);
-                m = e;
-            }
-        }
-        // slot order: inside every 128-slot block of a band, deal the pixels into half-waves (32 slots) so that
-        // the 32 window origins fall into 32 different LDS banks (bank = (x + y*lp) mod 32) as far as possible;
-        // every tap of the 5x5 window then reads conflict-free as well (same shift for all lanes)
-        std::vector<uint32_t> order(T.count);
-        // Measured on MI355X (profiles/r01_notes.md): with only 128 pixels per block the greedy deal still leaves one
-        // duplicate bank in most half-waves (cost = max multiplicity), so SQ_LDS_BANK_CONFLICT barely moves
-        // (105M -> 96M per 512 frames) while the scattered score stores cost more than that buys.  Kept as an
-        // experiment switch (AMTGPU_PERM=1); the default is raster order.
-        const bool noperm = std::getenv("AMTGPU_PERM") == nullptr;
-        for (size_t q = 0; q < order.size(); ++q) order[q] = (uint32_t)q;
-        for (size_t bi = firstBand; bi < bands_.size() && !noperm; ++bi) {
-            const EvalBand& B = bands_[bi];
-            for (int b0 = 0; b0 < B.npx; b0 += 128) {
-                const int nb = std::min(128, B.npx - b0);
-                std::vector<int> bucket[32];
-                for (int j = 0; j < nb; ++j) {
-                    const uint32_t ps = T.pos[B.m0 + b0 + j];
-                    bucket[((ps & 0xFFFF) + (ps >> 16) * (uint32_t)lp) & 31].push_back(B.m0 + b0 + j);
-                }
-                int q = B.m0 + b0;
-                int left = nb;
-                while (left > 0) {
-                    // one half-wave: at most one pixel per bank, fullest banks first
-                    int idx[32];
-                    for (int r = 0; r < 32; ++r) idx[r] = r;
-                    std::stable_sort(idx, idx + 32, [&](int a, int b) { return bucket[a].size() > bucket[b].size(); });
-                    int taken = 0;
-                    const int want = std::min(32, left);
-                    for (int r = 0; r < 32 && taken < want; ++r)
-                        if (!bucket[idx[r]].empty()) { order[q++] = bucket[idx[r]].front(); bucket[idx[r]].erase(bucket[idx[r]].begin()); ++taken; }
-                    for (int r = 0; r < 32 && taken < want; ++r)     // not enough distinct banks left: accept conflicts
-                        while (!bucket[idx[r]].empty() && taken < want) { order[q++] = bucket[idx[r]].front(); bucket[idx[r]].erase(bucket[idx[r]].begin()); ++taken; }
-                    left -= taken;
-                }
+                s = e;
             }
         }
 
-        // tables, re-laid for the kernel: taps and bins major, slots minor
+        // tables, re-laid for the kernel: taps and bins major, mask pixels minor
         std::vector<uint32_t> pos(cpad, T.count ? T.pos[0] : ((2u << 16) | 2u));
-        std::vector<uint32_t> rast(cpad, 0);
+        std::copy(T.pos.begin(), T.pos.end(), pos.begin());
         std::vector<float> kern((size_t)25 * cpad, 0.0f);
         std::vector<float2> scales((size_t)kNumBins * cpad, float2{0.0f, 0.0f});
-        for (int q = 0; q < T.count; ++q) {
-            const int m = (int)order[q];
-            pos[q] = T.pos[m];
-            rast[q] = (uint32_t)m;
-            for (int t = 0; t < 25; ++t) kern[(size_t)t * cpad + q] = T.kernels[(size_t)m * 25 + t];
+        for (int m = 0; m < T.count; ++m) {
+            for (int t = 0; t < 25; ++t) kern[(size_t)t * cpad + m] = T.kernels[(size_t)m * 25 + t];
             for (int c = 0; c < kNumBins; ++c)
-                scales[(size_t)c * cpad + q] = float2{T.scales[((size_t)m * 32 + c) * 2], T.scales[((size_t)m * 32 + c) * 2 + 1]};
+                scales[(size_t)c * cpad + m] = float2{T.scales[((size_t)m * 32 + c) * 2], T.scales[((size_t)m * 32 + c) * 2 + 1]};
         }
+        if (slots.empty()) slots.push_back(0);
         d_a_[i].upload(S.planes.A(0), (size_t)w * h, ctx_->stream);
         d_b_[i].upload(S.planes.B(0), (size_t)w * h, ctx_->stream);
         d_pos_[i].upload(pos, ctx_->stream);
-        d_rast_[i].upload(rast, ctx_->stream);
+        d_slots_[i].upload(slots, ctx_->stream);
         d_kern_[i].upload(kern, ctx_->stream);
         d_scales_[i].upload(scales, ctx_->stream);
 
         EvalLogoDev& D = hl[i];
-        D.a = d_a_[i].get(); D.b = d_b_[i].get(); D.pos = d_pos_[i].get(); D.rast = d_rast_[i].get();
+        D.a = d_a_[i].get(); D.b = d_b_[i].get(); D.pos = d_pos_[i].get(); D.slots = d_slots_[i].get();
         D.kern = d_kern_[i].get(); D.scales = d_scales_[i].get();
         D.w = w; D.h = h; D.count = T.count; D.count_pad = cpad;
         D.imgx = S.imgx; D.imgy = S.imgy; D.row0 = S.row0; D.row_step = S.row_step; D.deint = S.deint;

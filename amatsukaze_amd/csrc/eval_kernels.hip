@@ -7,10 +7,11 @@
 // Shape of the work: every mask pixel m of an evaluation logo owns a private 25-tap kernel k_m and is
 // evaluated on `nfades` blends of every frame.  There is no operand reuse across m (not a GEMM, no
 // MFMA); the reuse that exists is k_m across fades and the 5x5 windows overlapping in the rectangle.
-// So: one workgroup = (frame, band of <= 1024 raster-consecutive mask pixels); each thread keeps the
-// kernels of its <= 4 mask pixels in VGPRs for all fades, the unblended rectangle rows of the band live
-// in LDS (double buffered per fade, one barrier per fade), the source pixels and their background
-// estimate stay in registers between fades.  fp32 VALU-bound, ~115 non-fusable ops per mask pixel per
+// So: one workgroup = (frame, band of <= 256 run slots); a run slot is up to PXT horizontally adjacent mask pixels
+// owned by one thread, which keeps their kernel taps in VGPRs for all fades and reads ONE 5 x (4+PXT) window
+// per fade for all of them (mask pixels come in runs along logo edges: 97 % pair up, which halves the LDS
+// traffic per pixel).  The unblended rectangle rows of the band live in LDS (double buffered per fade, one
+// barrier per fade), the source pixels and their background estimate stay in registers between fades.  fp32 VALU-bound, ~115 non-fusable ops per mask pixel per
 // fade; the per-pixel order of operations is the reference's (exact_math.h).
 //
 // The cross-pixel sum is sequential in the reference (result += score, raster order).  To return the
@@ -104,28 +105,28 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
         }
     }
 
-    // ---- this thread's mask pixels: kernel taps in registers for the whole fade loop ----
-    float k[PXT][25];
-    int woff[PXT];
-    unsigned qslot[PXT];     // position in the (bank-permuted) tables
-    unsigned midx[PXT];      // raster index of the mask pixel = position of its score in the scratch row
-    bool act[PXT];
-#pragma unroll
-    for (int p = 0; p < PXT; ++p) {
-        const int local = p * kEvalThreads + tid;
-        act[p] = local < B.npx;
-        const unsigned m = (unsigned)(B.m0 + (act[p] ? local : 0));
-        qslot[p] = m;
-        midx[p] = gload<uint32_t>((gbase_t)L.rast, m * 4u);
-        const uint32_t ps = gload<uint32_t>(gPos, m * 4u);
+    // ---- this thread's run slot: up to PXT horizontally adjacent mask pixels, their kernel taps in registers
+    //      for the whole fade loop, one shared 5 x (4+PXT) window per fade ----
+    constexpr int WW = 4 + PXT;
+    const bool act = tid < B.nslots;
+    const uint32_t sl = gload<uint32_t>((gbase_t)L.slots, (unsigned)(B.s0 + (act ? tid : 0)) * 4u);
+    const unsigned m0 = sl & 0x0FFFFFFFu;
+    const int npx = act ? (int)(sl >> 28) : 0;
+    int woff;
+    {
+        const uint32_t ps = gload<uint32_t>(gPos, m0 * 4u);
         const int x = ps & 0xFFFF, y = ps >> 16;
-        woff[p] = (y - 2 - B.y0) * lp + (x - 2);
-        if (plane_cap < 0) woff[p] = (tid & 63);          // DEBUG probe: conflict-free window origin
+        woff = (y - 2 - B.y0) * lp + (x - 2);
+    }
+    float k[PXT][25];
 #pragma unroll
-        for (int t = 0; t < 25; ++t) k[p][t] = gload<float>(gKern, ((unsigned)t * cpad + m) * 4u);
+    for (int j = 0; j < PXT; ++j) {
+        const unsigned m = min(m0 + (unsigned)j, (unsigned)L.count - 1u);
+#pragma unroll
+        for (int t = 0; t < 25; ++t) k[j][t] = gload<float>(gKern, ((unsigned)t * cpad + m) * 4u);
     }
 
-    const int pcap = plane_cap < 0 ? -plane_cap : plane_cap;
+    const int pcap = plane_cap;
     float* wbuf0 = lds;
     float* wbuf1 = lds + pcap;
     auto mix = [&](float* dst, float fade) {
@@ -145,19 +146,21 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
         const float* cur = (f & 1) ? wbuf1 : wbuf0;
         float* nxt = (f & 1) ? wbuf0 : wbuf1;
         if (f + 1 < nfades) mix(nxt, fades[f + 1]);
+        if (act) {
+            float v[5 * WW];
 #pragma unroll
-        for (int p = 0; p < PXT; ++p) {
-            if (act[p]) {
-                float v[5][5];
+            for (int r = 0; r < 5; ++r)
 #pragma unroll
-                for (int r = 0; r < 5; ++r)
+                for (int c = 0; c < WW; ++c) v[r * WW + c] = cur[woff + r * lp + c];
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) v[r][c] = cur[woff[p] + r * lp + c];
-                float mean;
-                const float corr = corr5x5(k[p], v, &mean);
-                const f32x2_t sl = gload<f32x2_t>(gScales, ((unsigned)score_bin(mean) * cpad + qslot[p]) * 8u);
-                *reinterpret_cast<__attribute__((address_space(1))) float*>(out + ((unsigned)f * cpad + midx[p]) * 4u) =
-                    score_term(corr, sl.x, sl.y);
+            for (int j = 0; j < PXT; ++j) {
+                if (j < npx) {
+                    float mean;
+                    const float corr = corr5x5_strided<WW>(k[j], v + j, &mean);
+                    const f32x2_t sc = gload<f32x2_t>(gScales, ((unsigned)score_bin(mean) * cpad + m0 + j) * 8u);
+                    *reinterpret_cast<__attribute__((address_space(1))) float*>(out + ((unsigned)f * cpad + m0 + j) * 4u) =
+                        score_term(corr, sc.x, sc.y);
+                }
             }
         }
         __syncthreads();
@@ -246,7 +249,6 @@ hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, const EvalLogoDev
     const float maxv = (float)((1 << bits) - 1);
     dim3 grid((unsigned)nblocks);
     const size_t lds = corr_lds_bytes(plane_cap);
-    if (getenv("AMTGPU_DBG_WOFF")) plane_cap = -plane_cap;
 #define AMT_CORR(T, P, S) launch_corr_t<T, P, S>(st, grid, lds, dlogos, dbands, nbands, nbands8, dfades, nfades, dY, dframe_map, \
                                                frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap)
     if (bits <= 8) {

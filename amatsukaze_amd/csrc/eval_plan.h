@@ -5,18 +5,19 @@
 namespace amt {
 
 constexpr int kEvalThreads = 256;   // threads per workgroup of the correlation kernel
+constexpr int kNumBins = 32;        // 256 >> 3 background levels (LogoScan.hpp:63-68)
 // kernel variants: mask pixels per thread (PXT) -> staged rectangle pixels per thread (STG)
 inline constexpr int eval_stage_per_thread(int pxt) { return pxt == 4 ? 16 : (pxt == 2 ? 12 : 8); }
-constexpr int kNumBins = 32;        // 256 >> 3 background levels (LogoScan.hpp:63-68)
 
-// one evaluation logo (a LogoDataParam after CreateLogoMask) resident in HBM
+// one evaluation logo (a LogoDataParam after CreateLogoMask) resident in HBM.  Mask-pixel tables are in raster
+// order of the visited pixels (index m).
 struct EvalLogoDev {
     const float* a;          // [h*w]   A plane of the evaluation logo (deint or field)
     const float* b;          // [h*w]
-    const uint32_t* pos;     // [count_pad]  (y << 16) | x, SLOT order (see rast)
-    const uint32_t* rast;    // [count_pad]  slot -> raster index of the mask pixel.  Within every 128-slot block of a
-                             // band the pixels are permuted so that each half-wave (32 consecutive slots) reads 32
-                             // distinct LDS banks; kern/scales/pos are stored in slot order, scores in raster order
+    const uint32_t* pos;     // [count_pad]  (y << 16) | x
+    const uint32_t* slots;   // [nslots]  run slots: (n << 28) | m0 -- n <= PXT horizontally adjacent mask pixels
+                             // m0..m0+n-1 (adjacent in x, hence consecutive in raster order) evaluated by ONE thread
+                             // from one shared 5 x (4+PXT) register window
     const float* kern;       // [25][count_pad]   tap-major so lanes read consecutive floats
     const float2* scales;    // [32][count_pad]   bin-major {scale, scale2}
     int w, h;                // evaluation-logo size (field logos: h/2)
@@ -31,10 +32,10 @@ struct EvalLogoDev {
     uint32_t lp_magic;       // ceil(2^32 / lp): i / lp == __umulhi(i, lp_magic) for i*lp < 2^32
 };
 
-// a band = a contiguous range of mask pixels [m0, m0+npx) and the logo rows their windows touch
+// a band = up to 256 consecutive run slots (one per thread) and the logo rows their windows touch
 struct EvalBand {
     int logo;
-    int m0, npx;
+    int s0, nslots;
     int y0, nrows;           // staged logo rows [y0, y0+nrows)
 };
 

@@ -47,26 +47,29 @@ AMT_HD int trunc_x86(float f)
     return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (-2147483647 - 1);
 }
 
-// window v[row][col], kernel k[row*5+col]; returns the correlation, *mean gets the window average
-AMT_HD float corr5x5(const float* k, const float v[5][5], float* mean)
+// window element (row r, col c) at v[r*STRIDE + c], kernel k[row*5+col]; returns the correlation, *mean gets the
+// window average.  STRIDE > 5 lets horizontally adjacent mask pixels share one wider register window.
+template <int STRIDE>
+AMT_HD float corr5x5_strided(const float* k, const float* v, float* mean)
 {
     float c[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) c[i] = ((v[0][i] + v[1][i]) + (v[2][i] + v[3][i])) + v[4][i];
-    float m = div25(hsum5(c[0], c[1], c[2], c[3], c[4]));
+    for (int i = 0; i < 5; ++i) c[i] = ((v[i] + v[STRIDE + i]) + (v[2 * STRIDE + i] + v[3 * STRIDE + i])) + v[4 * STRIDE + i];
+    const float m = div25(hsum5(c[0], c[1], c[2], c[3], c[4]));
     float p[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        float t0 = k[0 + i] * (v[0][i] - m);
-        float t1 = k[5 + i] * (v[1][i] - m);
-        float t2 = k[10 + i] * (v[2][i] - m);
-        float t3 = k[15 + i] * (v[3][i] - m);
-        float t4 = k[20 + i] * (v[4][i] - m);
+        const float t0 = k[0 + i] * (v[i] - m);
+        const float t1 = k[5 + i] * (v[STRIDE + i] - m);
+        const float t2 = k[10 + i] * (v[2 * STRIDE + i] - m);
+        const float t3 = k[15 + i] * (v[3 * STRIDE + i] - m);
+        const float t4 = k[20 + i] * (v[4 * STRIDE + i] - m);
         p[i] = ((t0 + t1) + (t2 + t3)) + t4;
     }
     *mean = m;
     return hsum5(p[0], p[1], p[2], p[3], p[4]);
 }
+AMT_HD float corr5x5(const float* k, const float v[5][5], float* mean) { return corr5x5_strided<5>(k, &v[0][0], mean); }
 
 // one mask pixel's contribution (LogoScan.hpp:302-308); scale/scale2 already selected by bin
 AMT_HD int score_bin(float mean)
