@@ -142,20 +142,6 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
     __syncthreads();
     __attribute__((address_space(1))) char* out =
         (__attribute__((address_space(1))) char*)(scores + (long long)frame * scores_per_frame + L.score_off);
-    // The normalisation pair {scale, scale2} of a pixel depends on its window mean (one of 32 background bins): a
-    // dependent gather from L2.  It is issued as soon as the mean is known and consumed one fade later, so its
-    // latency hides behind a whole fade iteration instead of stalling every evaluation.
-    float pcorr[PXT];
-    f32x2_t psc[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) { pcorr[j] = 0.0f; psc[j] = f32x2_t{0.0f, 0.0f}; }
-    auto flush = [&](int f) {        // finish fade f: score = clamp(corr*scale)*scale2, to the scratch row
-#pragma unroll
-        for (int j = 0; j < PXT; ++j)
-            if (j < npx)
-                *reinterpret_cast<__attribute__((address_space(1))) float*>(out + ((unsigned)f * cpad + m0 + j) * 4u) =
-                    score_term(pcorr[j], psc[j].x, psc[j].y);
-    };
     for (int f = 0; f < nfades; ++f) {
         const float* cur = (f & 1) ? wbuf1 : wbuf0;
         float* nxt = (f & 1) ? wbuf0 : wbuf1;
@@ -166,21 +152,19 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
             for (int r = 0; r < 5; ++r)
 #pragma unroll
                 for (int c = 0; c < WW; ++c) v[r * WW + c] = cur[woff + r * lp + c];
-            float ncorr[PXT];
-            f32x2_t nsc[PXT];
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
-                float mean;
-                ncorr[j] = corr5x5_strided<WW>(k[j], v + j, &mean);
-                nsc[j] = gload<f32x2_t>(gScales, ((unsigned)score_bin(mean) * cpad + min(m0 + (unsigned)j, (unsigned)L.count - 1u)) * 8u);
+                if (j < npx) {
+                    float mean;
+                    const float corr = corr5x5_strided<WW>(k[j], v + j, &mean);
+                    const f32x2_t sc = gload<f32x2_t>(gScales, ((unsigned)score_bin(mean) * cpad + m0 + j) * 8u);
+                    *reinterpret_cast<__attribute__((address_space(1))) float*>(out + ((unsigned)f * cpad + m0 + j) * 4u) =
+                        score_term(corr, sc.x, sc.y);
+                }
             }
-            if (f > 0) flush(f - 1);
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) { pcorr[j] = ncorr[j]; psc[j] = nsc[j]; }
         }
         __syncthreads();
     }
-    if (act) flush(nfades - 1);
 }
 
 // Sequential (reference-order) sum of each score row.
