@@ -101,7 +101,7 @@ private:
     bool take_abs_;
     int out_frame_stride_;
     int plane_cap_ = 0;
-    int pxt_ = 2;            // kernel variant (mask pixels per thread)
+    int pxt_ = 1, nt_ = 256; // kernel variant (mask pixels per thread, threads per workgroup)
     long long scores_per_frame_ = 0;
     int chunk_frames_ = 0;
     std::vector<EvalBand> bands_;
@@ -117,7 +117,7 @@ private:
 
 // kernel launchers (eval_kernels.hip)
 size_t corr_lds_bytes(int plane_cap);
-hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
+hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, int nt, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
                             const float* dfades, int nfades, const void* dY, const int* dframe_map, long long frame_stride_elems,
                             int pitch, int nframes, float* dscores, long long scores_per_frame, int plane_cap);
 hipError_t launch_ordered_sum(hipStream_t st, const EvalLogoDev* dlogos, int nlogos, int nfades, int nframes,

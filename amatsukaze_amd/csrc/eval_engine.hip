@@ -64,8 +64,9 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
 {
     ctx_->bind();
     if (const char* e = std::getenv("AMTGPU_PXT")) pxt_ = std::atoi(e);
-    if (pxt_ != 1 && pxt_ != 2 && pxt_ != 4) pxt_ = 2;
-    const int kPlaneCapMax = kEvalThreads * eval_stage_per_thread(pxt_);   // floats per LDS plane
+    if (const char* e = std::getenv("AMTGPU_NT")) nt_ = std::atoi(e);
+    if (eval_stage_per_thread(pxt_, nt_) == 0) { pxt_ = 1; nt_ = 256; }
+    const int kPlaneCapMax = nt_ * eval_stage_per_thread(pxt_, nt_);   // floats per LDS plane
     const int nl = (int)specs_.size();
     const int nf = (int)fades_.size();
     std::vector<EvalLogoDev> hl(nl);
@@ -79,7 +80,7 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         const int lp = lds_pitch(w);
         if (w > 0xFFFF || h > 0xFFFF) throw std::runtime_error("logo too large");
         if (5 * lp > kPlaneCapMax) throw std::runtime_error("logo too wide for the evaluation kernel");
-        const int cpad = std::max(kEvalThreads, (T.count + kEvalThreads - 1) / kEvalThreads * kEvalThreads);
+        const int cpad = std::max(kTablePad, (T.count + kTablePad - 1) / kTablePad * kTablePad);
 
         // run slots: greedily group horizontally adjacent mask pixels (same row, x+1) -- they are consecutive
         // in raster order -- into runs of at most pxt_ pixels; one thread evaluates one slot
@@ -91,7 +92,7 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
             m += n;
         }
         if (T.count >= (1 << 28)) throw std::runtime_error("logo too large");
-        // bands: up to kEvalThreads consecutive slots whose windows fit the LDS plane
+        // bands: up to nt_ consecutive slots (one per thread) whose windows fit the LDS plane
         {
             const int ns = (int)slots.size();
             int s = 0;
@@ -100,7 +101,7 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
                 B.logo = i; B.s0 = s;
                 const int ytop = (int)(T.pos[slots[s] & 0x0FFFFFFFu] >> 16) - 2;
                 int e = s;
-                while (e < ns && e - s < kEvalThreads) {
+                while (e < ns && e - s < nt_) {
                     const int ybot = (int)(T.pos[slots[e] & 0x0FFFFFFFu] >> 16) + 2;
                     if ((ybot - ytop + 1) * lp > kPlaneCapMax) break;
                     ++e;
@@ -179,7 +180,7 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
         const int n = std::min(chunk, nframes - f0);
         const uint8_t* base = static_cast<const uint8_t*>(dY) + (dframe_map ? 0 : (int64_t)f0 * frame_stride_bytes);
         int sp = ctx_->prof_begin("logo_corr_kernel");
-        AMT_HIP(launch_logo_corr(ctx_->stream, bits, pxt_, d_logos_.get(), d_bands_.get(), (int)bands_.size(), d_fades_.get(),
+        AMT_HIP(launch_logo_corr(ctx_->stream, bits, pxt_, nt_, d_logos_.get(), d_bands_.get(), (int)bands_.size(), d_fades_.get(),
                                  (int)fades_.size(), base, dframe_map ? dframe_map + f0 : nullptr, frame_stride_bytes / es, pitch,
                                  n, d_scratch_.get(), scores_per_frame_, plane_cap_));
         ctx_->prof_end(sp);

@@ -41,8 +41,8 @@ template <typename T> __device__ __forceinline__ T gload(gbase_t base, unsigned 
 
 // PXT = mask pixels per thread (kernel taps held in VGPRs), STG = staged rectangle pixels per thread
 // (plane floats <= kEvalThreads * STG).  {4,16}: 198 VGPRs, 2 waves/SIMD; {2,12}: ~128 VGPRs, 4 waves/SIMD.
-template <typename pix_t, int PXT, int STG>
-__global__ __launch_bounds__(kEvalThreads)
+template <typename pix_t, int PXT, int STG, int NT>
+__global__ __launch_bounds__(NT)
 void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands,
                       int nbands, int nbands8, const float* __restrict__ fades, int nfades,
                       const pix_t* __restrict__ Y, const int* __restrict__ frame_map, long long frame_stride, int pitch,
@@ -76,7 +76,7 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
         constexpr unsigned ES = sizeof(pix_t);
 #pragma unroll
         for (int q = 0; q < STG; ++q) {
-            const int i = tid + q * kEvalThreads;
+            const int i = tid + q * NT;
             float s = 0.0f, bg = 0.0f;
             if (i < nplane) {
                 const int r = (int)__umulhi((unsigned)i, L.lp_magic);   // i / lp
@@ -133,7 +133,7 @@ void logo_corr_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __r
         const float omf = 1 - fade;
 #pragma unroll
         for (int q = 0; q < STG; ++q) {
-            const int i = tid + q * kEvalThreads;
+            const int i = tid + q * NT;
             if (i < nplane) dst[i] = fade * bgreg[q] + omf * sreg[q];
         }
     };
@@ -230,16 +230,17 @@ void ordered_sum_kernel(const EvalLogoDev* __restrict__ logos, int nfades, int n
 // ---- launch helpers (called from the host engine) ----
 size_t corr_lds_bytes(int plane_cap) { return (size_t)plane_cap * 2 * sizeof(float); }
 
-template <typename pix_t, int PXT, int STG>
+template <typename pix_t, int PXT, int STG, int NT>
 static void launch_corr_t(hipStream_t st, dim3 grid, size_t lds, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
                           int nbands8, const float* dfades, int nfades, const void* dY, const int* dframe_map,
                           long long frame_stride_elems, int pitch, float maxv, float* dscores, long long scores_per_frame, int plane_cap)
 {
-    hipLaunchKernelGGL((logo_corr_kernel<pix_t, PXT, STG>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, nbands, nbands8, dfades,
+    hipLaunchKernelGGL((logo_corr_kernel<pix_t, PXT, STG, NT>), grid, dim3(NT), lds, st, dlogos, dbands, nbands, nbands8, dfades,
                        nfades, (const pix_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap);
 }
 
-hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
+// variant = (mask pixels per thread, threads per workgroup); see eval_variant() in eval_plan.h
+hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, int nt, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
                             const float* dfades, int nfades, const void* dY, const int* dframe_map, long long frame_stride_elems,
                             int pitch, int nframes, float* dscores, long long scores_per_frame, int plane_cap)
 {
@@ -249,13 +250,20 @@ hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, const EvalLogoDev
     const float maxv = (float)((1 << bits) - 1);
     dim3 grid((unsigned)nblocks);
     const size_t lds = corr_lds_bytes(plane_cap);
-#define AMT_CORR(T, P, S) launch_corr_t<T, P, S>(st, grid, lds, dlogos, dbands, nbands, nbands8, dfades, nfades, dY, dframe_map, \
-                                               frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap)
-    if (bits <= 8) {
-        if (pxt == 4) AMT_CORR(uint8_t, 4, 16); else if (pxt == 2) AMT_CORR(uint8_t, 2, 12); else AMT_CORR(uint8_t, 1, 8);
-    } else {
-        if (pxt == 4) AMT_CORR(uint16_t, 4, 16); else if (pxt == 2) AMT_CORR(uint16_t, 2, 12); else AMT_CORR(uint16_t, 1, 8);
-    }
+#define AMT_CORR(T, P, S, N) launch_corr_t<T, P, S, N>(st, grid, lds, dlogos, dbands, nbands, nbands8, dfades, nfades, dY, dframe_map, \
+                                                    frame_stride_elems, pitch, maxv, dscores, scores_per_frame, plane_cap)
+#define AMT_CORR_T(T)                                                    \
+    do {                                                                 \
+        if (pxt == 1 && nt == 256) AMT_CORR(T, 1, 8, 256);               \
+        else if (pxt == 1 && nt == 512) AMT_CORR(T, 1, 8, 512);          \
+        else if (pxt == 1 && nt == 1024) AMT_CORR(T, 1, 4, 1024);        \
+        else if (pxt == 2 && nt == 256) AMT_CORR(T, 2, 12, 256);         \
+        else if (pxt == 2 && nt == 512) AMT_CORR(T, 2, 8, 512);          \
+        else if (pxt == 4 && nt == 256) AMT_CORR(T, 4, 16, 256);         \
+        else return hipErrorInvalidValue;                                \
+    } while (0)
+    if (bits <= 8) AMT_CORR_T(uint8_t); else AMT_CORR_T(uint16_t);
+#undef AMT_CORR_T
 #undef AMT_CORR
     return hipGetLastError();
 }

@@ -4,10 +4,15 @@
 
 namespace amt {
 
-constexpr int kEvalThreads = 256;   // threads per workgroup of the correlation kernel
+constexpr int kTablePad = 256;      // mask-pixel tables are padded to a multiple of this
 constexpr int kNumBins = 32;        // 256 >> 3 background levels (LogoScan.hpp:63-68)
-// kernel variants: mask pixels per thread (PXT) -> staged rectangle pixels per thread (STG)
-inline constexpr int eval_stage_per_thread(int pxt) { return pxt == 4 ? 16 : (pxt == 2 ? 12 : 8); }
+// kernel variants: (mask pixels per thread PXT, threads per workgroup NT) -> staged rectangle pixels per thread
+// STG (LDS plane floats <= NT*STG); 0 = variant not built
+inline constexpr int eval_stage_per_thread(int pxt, int nt)
+{
+    return (pxt == 1 && nt == 256) ? 8 : (pxt == 1 && nt == 512) ? 8 : (pxt == 1 && nt == 1024) ? 4
+         : (pxt == 2 && nt == 256) ? 12 : (pxt == 2 && nt == 512) ? 8 : (pxt == 4 && nt == 256) ? 16 : 0;
+}
 
 // one evaluation logo (a LogoDataParam after CreateLogoMask) resident in HBM.  Mask-pixel tables are in raster
 // order of the visited pixels (index m).
@@ -32,7 +37,7 @@ struct EvalLogoDev {
     uint32_t lp_magic;       // ceil(2^32 / lp): i / lp == __umulhi(i, lp_magic) for i*lp < 2^32
 };
 
-// a band = up to 256 consecutive run slots (one per thread) and the logo rows their windows touch
+// a band = up to NT consecutive run slots (one per thread) and the logo rows their windows touch
 struct EvalBand {
     int logo;
     int s0, nslots;
