@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libamt_gpu.so")
+LIB_PATH = os.environ.get("AMTGPU_LIB") or os.path.join(HERE, "libamt_gpu.so")   # AMTGPU_LIB: instrumented builds (tools/)
 
 c_i, c_f, c_p, c_s = C.c_int, C.c_float, C.c_void_p, C.c_char_p
 c_i64, c_u64 = C.c_int64, C.c_uint64

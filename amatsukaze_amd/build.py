@@ -17,7 +17,7 @@ SOURCES = [
     "amt_gpu_erase_scan.hip",
     "amt_gpu_stats.hip",
     "eval_engine.hip",
-    "eval_kernels.hip",
+    "eval_fused_kernels.hip",
     "erase_scan_kernels.hip",
     "stats_kernels.hip",
     "logo_model.cpp",
@@ -30,6 +30,12 @@ SOURCES = [
 # feed discontinuous decisions -- the kernels must round exactly where it rounds.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+# per-file extras.  eval_fused_kernels.hip: the fade loop is ~200 straight-line VALU instructions per iteration with
+# 8-cycle dependent-issue latency (tools/ubench/valu_rate.hip); the max-ILP scheduler spaces dependent packed ops
+# further apart than the default occupancy-driven one (measured: 2.58 -> 2.40 ms per 2048-frame analysis).
+EXTRA_FLAGS = {"eval_fused_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def hipcc() -> str:
@@ -47,6 +53,29 @@ def needs_build(srcs) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, defines, extra_flags=()) -> str:
+    """An instrumented copy of the library (tools/phase_timing.py): amatsukaze_amd/libamt_gpu_<name>.so"""
+    out = os.path.join(HERE, f"libamt_gpu_{name}.so")
+    bdir = os.path.join(HERE, "build", name)
+    os.makedirs(bdir, exist_ok=True)
+    procs, objs = [], []
+    for f in SOURCES:
+        o = os.path.join(bdir, f + ".o")
+        objs.append(o)
+        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(f, []), *extra_flags, *[f"-D{d}" for d in defines], "-x", "hip", "-c",
+               os.path.join(CSRC, f), "-o", o]
+        procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for f, p in procs:
+        o_, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"variant build failed on {f}:\n" + o_.decode(errors="replace"))
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("variant link failed:\n" + r.stdout.decode(errors="replace"))
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not force and not needs_build(srcs):
@@ -61,7 +90,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                          + [os.path.getmtime(s), os.path.getmtime(os.path.join(HERE, "..", "include", "amt_gpu.h"))])
         if not force and os.path.exists(o) and os.path.getmtime(o) > newest_dep:
             continue
-        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", s, "-o", o]
+        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(os.path.basename(s), []), "-x", "hip", "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -92,7 +92,6 @@ public:
     const EvalLogoSpec& spec(int i) const { return specs_[i]; }
     // flops / bytes bookkeeping for the bench (algorithmic, per frame)
     double mask_pixel_evals_per_frame() const;
-    long long scratch_floats_per_frame() const { return scores_per_frame_; }
 
 private:
     AmtGpuContext* ctx_;
@@ -101,26 +100,21 @@ private:
     bool take_abs_;
     int out_frame_stride_;
     int plane_cap_ = 0;
-    int pxt_ = 1, nt_ = 256; // kernel variant (mask pixels per thread, threads per workgroup)
-    long long scores_per_frame_ = 0;
-    int chunk_frames_ = 0;
+    int group_frames_ = 0;   // frames per workgroup (0 = pick per batch; AMTGPU_G overrides)
     std::vector<EvalBand> bands_;
     // device state
-    std::vector<DevBuf<float>> d_a_, d_b_, d_kern_;
-    std::vector<DevBuf<uint32_t>> d_pos_, d_slots_;
-    std::vector<DevBuf<float2>> d_scales_;
+    std::vector<DevBuf<float>> d_a_, d_b_;
+    std::vector<DevBuf<float2>> d_scales_, d_kslot_;
+    std::vector<DevBuf<uint2>> d_slot2_;
     DevBuf<EvalLogoDev> d_logos_;
     DevBuf<EvalBand> d_bands_;
     DevBuf<float> d_fades_;
-    DevBuf<float> d_scratch_;
 };
 
-// kernel launchers (eval_kernels.hip)
-size_t corr_lds_bytes(int plane_cap);
-hipError_t launch_logo_corr(hipStream_t st, int bits, int pxt, int nt, const EvalLogoDev* dlogos, const EvalBand* dbands, int nbands,
-                            const float* dfades, int nfades, const void* dY, const int* dframe_map, long long frame_stride_elems,
-                            int pitch, int nframes, float* dscores, long long scores_per_frame, int plane_cap);
-hipError_t launch_ordered_sum(hipStream_t st, const EvalLogoDev* dlogos, int nlogos, int nfades, int nframes,
-                              const float* dscores, long long scores_per_frame, float* dout, int out_frame_stride, int take_abs);
+// kernel launcher (eval_fused_kernels.hip)
+hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* dlogos, int nlogos, const EvalBand* dbands,
+                                  const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
+                                  long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
+                                  int take_abs, int plane_cap);
 
 } // namespace amt

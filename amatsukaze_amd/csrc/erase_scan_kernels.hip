@@ -21,42 +21,74 @@ struct EraseGeom {
     int uvparity;
 };
 
+// One workgroup = kDelogoRows consecutive rectangle rows (luma rows first, then U, then V) of one frame; a
+// thread owns PAIRS of horizontally adjacent samples (the rectangle origin and width are even, LogoScan.hpp:69,
+// so a luma pair is one aligned 2*sizeof(pix_t) access; chroma pairs are used when the chroma origin, width and
+// pitch are even too, otherwise that plane goes sample by sample).  16 workgroups per frame at 256x128 instead of
+// one per row: the pass is a read-modify-write of 48 KiB per frame and wants few, fat workgroups.
+constexpr int kDelogoRows = 16;
+constexpr int kDelogoThreads = 256;
+
+template <typename pix_t> struct PixPair;
+template <> struct PixPair<uint8_t> { typedef uint16_t type; };
+template <> struct PixPair<uint16_t> { typedef uint32_t type; };
+
+__device__ __forceinline__ float delogo_px(float s, float a, float b, float maxv, float fade)
+{
+    const float bg = unblend_bg(a, b, maxv, s);
+    const float t = fade_mix(fade, bg, s) + 0.5f;
+    const float lo = (t < 0.0f) ? 0.0f : t;            // std::max(t, 0.0f)
+    return (maxv < lo) ? maxv : lo;                    // std::min(lo, maxv)
+}
+
 template <typename pix_t>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kDelogoThreads)
 void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restrict__ V, long long strideY,
                    long long strideUV, int pitchY, int pitchUV, const float* __restrict__ planes, EraseGeom g,
-                   float maxv, const float2* __restrict__ fades)
+                   float maxv, const float2* __restrict__ fades, int pairY, int pairUV)
 {
+    typedef typename PixPair<pix_t>::type pair_t;
+    constexpr int SH = 8 * sizeof(pix_t);
     const int frame = blockIdx.y;
-    const int r = blockIdx.x;
     const float2 fd = fades[frame];
     const bool frameMode = fd.x == fd.y;
     const size_t ysz = (size_t)g.w * g.h, csz = (size_t)g.wUV * g.hUV;
-    pix_t* row;
-    const float *A, *B;
-    int roww, y;
-    float fade;
-    if (r < g.h) {
-        y = r; roww = g.w;
-        row = Y + (long long)frame * strideY + (long long)(g.imgy + y) * pitchY + g.imgx;
-        A = planes + (size_t)y * g.w; B = planes + ysz + (size_t)y * g.w;
-        fade = frameMode ? fd.x : ((y & 1) ? fd.y : fd.x);
-    } else {
-        const int pl = (r - g.h) >= g.hUV ? 1 : 0;
-        y = r - g.h - pl * g.hUV; roww = g.wUV;
-        if (!frameMode && y >= 2 * (g.hUV / 2)) return;
-        row = (pl ? V : U) + (long long)frame * strideUV + (long long)(g.cy + y) * pitchUV + g.cx;
-        const float* base = planes + 2 * ysz + (size_t)pl * 2 * csz;
-        A = base + (size_t)y * g.wUV; B = base + csz + (size_t)y * g.wUV;
-        fade = frameMode ? fd.x : (((y & 1) == g.uvparity) ? fd.x : fd.y);
-    }
-    for (int x = threadIdx.x; x < roww; x += blockDim.x) {
-        const float s = (float)row[x];
-        const float bg = unblend_bg(A[x], B[x], maxv, s);
-        const float t = fade_mix(fade, bg, s) + 0.5f;
-        const float lo = (t < 0.0f) ? 0.0f : t;            // std::max(t, 0.0f)
-        const float hi = (maxv < lo) ? maxv : lo;          // std::min(lo, maxv)
-        row[x] = (pix_t)hi;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rend = min(g.h + 2 * g.hUV, (int)(blockIdx.x + 1) * kDelogoRows);
+    for (int r = blockIdx.x * kDelogoRows + wv; r < rend; r += kDelogoThreads / 64) {
+        pix_t* row;
+        const float *A, *B;
+        int roww, paired;
+        float fade;
+        if (r < g.h) {
+            const int y = r;
+            roww = g.w; paired = pairY;
+            row = Y + (long long)frame * strideY + (long long)(g.imgy + y) * pitchY + g.imgx;
+            A = planes + (size_t)y * g.w; B = planes + ysz + (size_t)y * g.w;
+            fade = frameMode ? fd.x : ((y & 1) ? fd.y : fd.x);
+        } else {
+            const int pl = (r - g.h) >= g.hUV ? 1 : 0;
+            const int y = r - g.h - pl * g.hUV;
+            roww = g.wUV; paired = pairUV;
+            if (!frameMode && y >= 2 * (g.hUV / 2)) continue;
+            row = (pl ? V : U) + (long long)frame * strideUV + (long long)(g.cy + y) * pitchUV + g.cx;
+            const float* base = planes + 2 * ysz + (size_t)pl * 2 * csz;
+            A = base + (size_t)y * g.wUV; B = base + csz + (size_t)y * g.wUV;
+            fade = frameMode ? fd.x : (((y & 1) == g.uvparity) ? fd.x : fd.y);
+        }
+        if (paired) {
+            for (int x = 2 * lane; x < roww; x += 128) {
+                const pair_t p = *reinterpret_cast<const pair_t*>(row + x);
+                const float2 a = *reinterpret_cast<const float2*>(A + x);
+                const float2 b = *reinterpret_cast<const float2*>(B + x);
+                const float r0 = delogo_px((float)(pix_t)p, a.x, b.x, maxv, fade);
+                const float r1 = delogo_px((float)(pix_t)(p >> SH), a.y, b.y, maxv, fade);
+                *reinterpret_cast<pair_t*>(row + x) = (pair_t)((pair_t)(pix_t)r0 | ((pair_t)(pix_t)r1 << SH));
+            }
+        } else {
+            for (int x = lane; x < roww; x += 64)
+                row[x] = (pix_t)delogo_px((float)row[x], A[x], B[x], maxv, fade);
+        }
     }
 }
 
@@ -64,14 +96,22 @@ hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV,
                          int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades)
 {
     if (nframes <= 0) return hipSuccess;
-    dim3 grid((unsigned)(g.h + 2 * g.hUV), (unsigned)nframes), block(256);
+    const int rows = g.h + 2 * g.hUV;
+    dim3 grid((unsigned)((rows + kDelogoRows - 1) / kDelogoRows), (unsigned)nframes), block(kDelogoThreads);
     const float maxv = (float)((1 << bits) - 1);
+    const int es = bits <= 8 ? 1 : 2;
+    auto even = [](long long v) { return (v & 1) == 0; };
+    // a pair access needs 2*es alignment of every row start and an even width (plane bases come from hipMalloc /
+    // AviSynth's 64-byte aligned planes; a caller handing odd byte offsets falls back to single samples)
+    const int pairY = even(g.w) && even(g.imgx) && even(pitchY) && even(strideY) && ((uintptr_t)dY % (2 * es) == 0);
+    const int pairUV = even(g.wUV) && even(g.cx) && even(pitchUV) && even(strideUV) && ((uintptr_t)dU % (2 * es) == 0) &&
+                       ((uintptr_t)dV % (2 * es) == 0);
     if (bits <= 8)
         hipLaunchKernelGGL(delogo_kernel<uint8_t>, grid, block, 0, st, (uint8_t*)dY, (uint8_t*)dU, (uint8_t*)dV, strideY,
-                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades);
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV);
     else
         hipLaunchKernelGGL(delogo_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)dY, (uint16_t*)dU, (uint16_t*)dV, strideY,
-                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades);
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV);
     return hipGetLastError();
 }
 

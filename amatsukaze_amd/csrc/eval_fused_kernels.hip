@@ -1,0 +1,431 @@
+// eval_fused_kernels.hip -- logo correlation on CDNA4 (gfx950), fused with the reference-order sum.
+//
+// Replaces LogoDataParam::EvaluateLogo / CorrelationScore (LogoScan.hpp:231-255, 288-318) + DeintY / CopyY
+// (:763-790) as driven by LogoFrame::ScanFrame (:1543-1568), AMTAnalyzeLogo::GetFrameT (:1119-1161) and
+// LogoAnalyzer::ReMakeLogo (:955-982): out[frame][logo][fade] = (|.|) CorrelationScore(blend(fade)) / blackScore.
+//
+// Shape of the work: every mask pixel m of an evaluation logo owns a private 25-tap kernel k_m and is evaluated on
+// `nfades` blends  fade*bg + (1-fade)*s  of every frame; the per-pixel terms are then added in raster order
+// (result += score, :295-315 -- a strictly sequential fp32 chain whose rounding the outputs inherit).  There is no
+// operand reuse across mask pixels (not a GEMM, no MFMA): the kernel is bound by fp32 VALU issue, so the design
+// minimises instructions per evaluation and keeps everything else off the inner loop:
+//
+//   * one workgroup = (logo, group of G frames); it walks the logo's BANDS (<= 256 run slots = <= 512 raster-
+//     consecutive mask pixels and the <= 11 rectangle rows their windows touch) in order, because the sum is
+//     sequential over all mask pixels of the logo;
+//   * a thread owns one run slot: up to two horizontally adjacent mask pixels (97 % pair up along logo edges).  Its
+//     2 x 25 kernel taps, the 5x6 source window S and the 5x6 background-estimate window BG stay in VGPRs for the
+//     whole fade loop; the blend is recomputed in registers per fade, so the fade loop has NO LDS traffic and NO
+//     barrier -- only packed fp32 math (v_pk_mul/add_f32: the two pixels of a slot ride in the two halves of the
+//     64-bit operands; window columns are paired (1,2) (3,4) (0,5) so that every add/sub/mul of the reference's
+//     evaluation order is a packed op without register shuffles) and one 8-byte scale gather per pixel, whose
+//     latency is hidden behind the next fade's math;
+//   * LDS holds the band's rows once per (band, frame): s and bg = a*s + b*maxv, each computed by one thread;
+//   * per-pixel terms go to an LDS row per fade; one wave (rotating) adds each row front to back -- one lane per
+//     fade, the reference's order -- while the workgroup's next global loads are in flight.  Nothing but the final
+//     per-frame results touches HBM.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdlib>
+
+#include "eval_plan.h"
+#include "exact_math.h"
+
+namespace amt {
+
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef f4 __attribute__((aligned(4))) f4u;
+template <typename T> __device__ __forceinline__ T gld(gptr_t base, unsigned byteoff)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(base + byteoff);
+}
+__device__ __forceinline__ f2 bc_lo(f2 v) { return __builtin_shufflevector(v, v, 0, 0); }
+__device__ __forceinline__ f2 bc_hi(f2 v) { return __builtin_shufflevector(v, v, 1, 1); }
+// x / 25 for both halves (exact_math.h div25, packed)
+__device__ __forceinline__ f2 div25_pk(f2 x)
+{
+    const f2 z = {0.04f, 0.04f};
+    const f2 q = x * z;
+    const f2 r = __builtin_elementwise_fma(f2{-25.0f, -25.0f}, q, x);
+    return __builtin_elementwise_fma(r, z, q);
+}
+
+// four adjacent samples of a frame row in one load
+template <typename pix_t> struct Raw4;
+template <> struct Raw4<uint8_t> {
+    unsigned v;
+    __device__ __forceinline__ void load(gptr_t base, unsigned byteoff);
+    __device__ __forceinline__ int get(int k) const { return (int)((v >> (8 * k)) & 0xFFu); }
+};
+template <> struct Raw4<uint16_t> {
+    u2 v;
+    __device__ __forceinline__ void load(gptr_t base, unsigned byteoff);
+    __device__ __forceinline__ int get(int k) const { return (int)((v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu); }
+};
+
+__device__ __forceinline__ void Raw4<uint8_t>::load(gptr_t base, unsigned byteoff)
+{
+    typedef unsigned __attribute__((aligned(1))) ua_t;     // rectangle origins are even, not 4-byte aligned
+    v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
+}
+__device__ __forceinline__ void Raw4<uint16_t>::load(gptr_t base, unsigned byteoff)
+{
+    typedef u2 __attribute__((aligned(2))) ua_t;
+    v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
+}
+
+constexpr int kFusedWaves = kEvalThreads / 64;
+constexpr int kStageRows = 4;         // rows a staging wave handles per trip
+constexpr int kSumChunk = 16;          // floats a summing lane keeps in flight
+
+// Adds row[0..n) to acc strictly front to back.  Two register sets alternate (no copies): while one set's 16
+// dependent adds retire, the other set's four ds_read_b128 are in flight.  row is 16-byte aligned and readable up to
+// 2*kSumChunk floats past n.
+__device__ __forceinline__ void sum_load(float4 (&v)[kSumChunk / 4], const float* p)
+{
+#pragma unroll
+    for (int j = 0; j < kSumChunk / 4; ++j) v[j] = *reinterpret_cast<const float4*>(p + 4 * j);
+}
+__device__ __forceinline__ float sum_add(const float4 (&v)[kSumChunk / 4], float acc)
+{
+#pragma unroll
+    for (int j = 0; j < kSumChunk / 4; ++j) { acc += v[j].x; acc += v[j].y; acc += v[j].z; acc += v[j].w; }
+    return acc;
+}
+__device__ __forceinline__ float sum_add_n(const float4 (&v)[kSumChunk / 4], float acc, int rem)
+{
+#pragma unroll
+    for (int j = 0; j < kSumChunk / 4; ++j) {
+        if (4 * j + 0 < rem) acc += v[j].x;
+        if (4 * j + 1 < rem) acc += v[j].y;
+        if (4 * j + 2 < rem) acc += v[j].z;
+        if (4 * j + 3 < rem) acc += v[j].w;
+    }
+    return acc;
+}
+__device__ __forceinline__ float ordered_row_sum(const float* row, int n, float acc)
+{
+    float4 A[kSumChunk / 4], B[kSumChunk / 4];
+    sum_load(A, row);
+    int q = 0;
+    // sched_barrier: keep each set's reads ahead of the other set's adds (the scheduler otherwise sinks them and
+    // the chain waits a full LDS round trip per chunk)
+    for (; q + 2 * kSumChunk <= n; q += 2 * kSumChunk) {
+        sum_load(B, row + q + kSumChunk);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = sum_add(A, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        sum_load(A, row + q + 2 * kSumChunk);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = sum_add(B, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    sum_load(B, row + q + kSumChunk);
+    acc = sum_add_n(A, acc, n - q);
+    return sum_add_n(B, acc, n - q - kSumChunk);
+}
+
+template <typename pix_t>
+__device__ __forceinline__
+void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands,
+                          const float* __restrict__ fades, int nfades, int fade0,
+                          const pix_t* __restrict__ Y, const int* __restrict__ frame_map, long long frame_stride, int pitch,
+                          float maxv, int nframes, int G, int ngroups, float* __restrict__ out, int out_frame_stride,
+                          int take_abs, int plane_cap, int sc_pitch, int dbg)
+{
+    extern __shared__ float lds[];
+    float* const planeS = lds;                       // [plane_cap]  source pixels of the band's rows
+    float* const planeB = lds + plane_cap;           // [plane_cap]  background estimate a*s + b*maxv
+    float* const sc = lds + 2 * plane_cap;           // [nfades][sc_pitch]  per-pixel terms of the current (band, frame)
+    float* const accs = sc + nfades * sc_pitch;      // [G][nfades]  running sums
+
+    const int logo = blockIdx.x / ngroups;
+    const int grp = blockIdx.x - logo * ngroups;
+    const int F0 = grp * G;
+    const int gcount = min(G, nframes - F0);
+    const EvalLogoDev L = logos[logo];
+    const gptr_t gA = (gptr_t)L.a, gB = (gptr_t)L.b, gScales = (gptr_t)L.scales, gK = (gptr_t)L.kslot, gSlot = (gptr_t)L.slot2;
+    const unsigned cpad = (unsigned)L.count_pad;
+    const unsigned spad = (unsigned)L.nslots_pad;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int w = L.w, lp = L.lp;
+    constexpr unsigned ES = sizeof(pix_t);
+
+    if (tid < G * nfades) accs[tid] = 0.0f;          // G * nfades <= 256 (host)
+    const int fade_bits = __builtin_bit_cast(int, fades[fade0 + min(lane, nfades - 1)]);   // lane f holds fade f (nfades <= 64)
+
+#ifdef AMT_FUSED_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#define AMT_TICK(k) do { const long long t_ = clock64(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define AMT_TICK(k) do { } while (0)
+#endif
+    int it = 0;                                      // (band, frame) iterations done
+    int prev_npix = 0, prev_g = 0;
+    for (int bi = 0; bi < L.nbands; ++bi) {
+        const EvalBand B = bands[L.band0 + bi];
+        // ---- this thread's run slot: kernel taps as packed pairs, resident for all frames and fades of the band ----
+        const bool act = tid < B.nslots;
+        const unsigned slot = (unsigned)(B.s0 + (act ? tid : 0));
+        const u2 sl = gld<u2>(gSlot, slot * 8u);
+        const unsigned m0 = sl.x & 0x0FFFFFFFu;
+        const int npx = act ? (int)(sl.x >> 28) : 0;
+        const int woff = (int)sl.y;                  // LDS float offset of the window's top-left element
+        const int p0 = (int)m0 - B.m0;               // index of the slot's first pixel in the band's score rows
+        f2 K[25];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) K[t] = gld<f2>(gK, ((unsigned)t * spad + slot) * 8u);
+        const unsigned m1 = min(m0 + 1u, (unsigned)L.count - 1u);
+#ifdef AMT_FUSED_TIMING
+        if (K[24].x == 123456.0f) tacc[7] += 1;      // force the tap loads to land before the tick
+#endif
+        AMT_TICK(0);
+
+        for (int g = 0; g < gcount; ++g, ++it) {
+            // ---- 1. s and bg of the band's rows -> LDS.  A wave stages 4 consecutive rows x 256 columns at a time, a
+            //      lane four adjacent columns (one 4*sizeof(pix_t) load per raw row, 16-byte loads of a and b, 16-byte
+            //      LDS stores); the row is wave-uniform, so the address math is scalar, and the [1 2 1] vertical
+            //      blend of DeintY re-uses the 6 raw rows it loads ----
+            const int frame = F0 + g;
+            const int srcFrame = frame_map ? frame_map[frame] : frame;
+            const gptr_t src = (gptr_t)(Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx);
+            // Three waves stage (4 rows each per trip); the fourth -- the one that adds the previous iteration's
+            // score rows below -- stages nothing, so that the sum runs beside the staging loads' latency.
+            const int sumwave = (it + kFusedWaves - 1) & (kFusedWaves - 1);
+            const int worker = (wave - sumwave + kFusedWaves - 1) & (kFusedWaves - 1);       // 0..2 stage, 3 = sumwave
+            for (int rg = worker * kStageRows; rg < ((dbg & 2) || worker == kFusedWaves - 1 ? 0 : B.nrows); rg += kStageRows * (kFusedWaves - 1)) {
+                const int y = B.y0 + rg;                                     // logo row of the group's first row
+                for (int xg = 0; xg < w; xg += 256) {
+                    const int x = xg + 4 * lane;
+                    const int nv = min(4, w - x);                            // valid columns of this lane (<= 0: none)
+                    const int xl = nv >= 4 ? x : 0;                          // lanes at a ragged right edge go column by column
+                    Raw4<pix_t> raw[kStageRows + 2];
+                    f4 av[kStageRows], bv[kStageRows];
+                    if (L.deint) {
+#pragma unroll
+                        for (int j = 0; j < kStageRows + 2; ++j) raw[j].load(src, (unsigned)(min(max(y - 1 + j, 0), L.h - 1) * pitch + xl) * ES);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kStageRows; ++j) raw[j + 1].load(src, (unsigned)(min(y + j, L.h - 1) * L.row_step * pitch + xl) * ES);
+                        raw[0] = raw[1]; raw[kStageRows + 1] = raw[kStageRows];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kStageRows; ++j) {
+                        const unsigned o = (unsigned)(min(y + j, L.h - 1) * w + xl) * 4u;
+                        av[j] = gld<f4u>(gA, o);      // 8-byte aligned (w and x even), not 16
+                        bv[j] = gld<f4u>(gB, o);
+                    }
+                    if (nv >= 4) {
+#pragma unroll
+                        for (int j = 0; j < kStageRows; ++j) {
+                            const int yy = y + j;
+                            if (rg + j < B.nrows) {
+                                const bool blend = L.deint && yy != 0 && yy != L.h - 1;
+                                f4 sv, gv;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const float s1 = blend ? (float)(raw[j].get(k) + 2 * raw[j + 1].get(k) + raw[j + 2].get(k) + 2) / 4.0f
+                                                           : (float)raw[j + 1].get(k);
+                                    sv[k] = s1;
+                                    gv[k] = unblend_bg(av[j][k], bv[j][k], maxv, s1);
+                                }
+                                *reinterpret_cast<f4*>(planeS + (rg + j) * lp + x) = sv;
+                                *reinterpret_cast<f4*>(planeB + (rg + j) * lp + x) = gv;
+                            }
+                        }
+                    } else if (nv > 0) {
+                        for (int j = 0; j < kStageRows && rg + j < B.nrows; ++j) {
+                            const int yy = y + j;
+                            const bool blend = L.deint && yy != 0 && yy != L.h - 1;
+                            for (int k = 0; k < nv; ++k) {
+                                int q0, q1, q2;
+                                if (L.deint) {
+                                    q0 = gld<pix_t>(src, (unsigned)(max(yy - 1, 0) * pitch + x + k) * ES);
+                                    q1 = gld<pix_t>(src, (unsigned)(yy * pitch + x + k) * ES);
+                                    q2 = gld<pix_t>(src, (unsigned)(min(yy + 1, L.h - 1) * pitch + x + k) * ES);
+                                } else {
+                                    q0 = q2 = 0;
+                                    q1 = gld<pix_t>(src, (unsigned)(yy * L.row_step * pitch + x + k) * ES);
+                                }
+                                const float s1 = blend ? (float)(q0 + 2 * q1 + q2 + 2) / 4.0f : (float)q1;
+                                planeS[(rg + j) * lp + x + k] = s1;
+                                planeB[(rg + j) * lp + x + k] = unblend_bg(gld<float>(gA, (unsigned)(yy * w + x + k) * 4u),
+                                                                           gld<float>(gB, (unsigned)(yy * w + x + k) * 4u), maxv, s1);
+                            }
+                        }
+                    }
+                }
+            }
+            AMT_TICK(1);
+            // ---- 2. one wave adds the previous iteration's per-pixel terms in raster order (the others wait at B1, their
+            //         SIMDs run other workgroups' fade loops meanwhile) ----
+            if (!(dbg & 1) && it > 0 && wave == sumwave && lane < nfades) {
+                float* a = accs + prev_g * nfades + lane;
+                *a = ordered_row_sum(sc + lane * sc_pitch, prev_npix, *a);
+            }
+            AMT_TICK(2);
+            __syncthreads();                         // B1: planes complete, score rows free again
+            AMT_TICK(3);
+            // ---- 4. windows -> registers: per row the column pairs (1,2) (3,4) (0,5) ----
+            f2 S[15], BG[15];
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const float* ps = planeS + woff + r * lp;
+                    const float* pb = planeB + woff + r * lp;
+                    S[3 * r + 0] = f2{ps[1], ps[2]};  BG[3 * r + 0] = f2{pb[1], pb[2]};
+                    S[3 * r + 1] = f2{ps[3], ps[4]};  BG[3 * r + 1] = f2{pb[3], pb[4]};
+                    S[3 * r + 2] = f2{ps[0], ps[5]};  BG[3 * r + 2] = f2{pb[0], pb[5]};
+                }
+            }
+#ifdef AMT_FUSED_TIMING
+            if (act && S[14].x == 123456.0f) tacc[7] += 1;
+#endif
+            AMT_TICK(4);
+            // ---- 5. fade loop: registers only.  Two register sets alternate so that the scale gather issued by
+            //      evaluation f is consumed after evaluation f+1's math (a full iteration of latency cover, no copies) ----
+            if (act) {
+                auto eval = [&](int f, f2& R, f2& s0, f2& s1) {
+                    const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));   // no memory op in the loop
+                    const float omf = 1 - fade;
+                    f2 W[15];
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) W[i] = BG[i] * fade + S[i] * omf;      // fade*bg + (1-fade)*s
+                    // column sums ((r0+r1)+(r2+r3))+r4 for the column pairs
+                    const f2 CA = ((W[0] + W[3]) + (W[6] + W[9])) + W[12];               // cols 1,2
+                    const f2 CB = ((W[1] + W[4]) + (W[7] + W[10])) + W[13];              // cols 3,4
+                    const f2 CE = ((W[2] + W[5]) + (W[8] + W[11])) + W[14];              // cols 0,5
+                    f2 M;
+                    M.x = hsum5(CE.x, CA.x, CA.y, CB.x, CB.y);                          // pixel 0: cols 0..4
+                    M.y = hsum5(CA.x, CA.y, CB.x, CB.y, CE.y);                          // pixel 1: cols 1..5
+                    M = div25_pk(M);
+                    if (!(dbg & 8)) {
+                        s0 = gld<f2>(gScales, ((unsigned)score_bin(M.x) * cpad + m0) * 8u);
+                        s1 = gld<f2>(gScales, ((unsigned)score_bin(M.y) * cpad + m1) * 8u);
+                    } else { s0 = M; s1 = M; }
+                    f2 P[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        f2 T[5];
+#pragma unroll
+                        for (int r = 0; r < 5; ++r) {
+                            f2 wv;
+                            if (c == 0) wv = bc_lo(W[3 * r + 0]);        // window col 1: tap col 1 of px 0, 0 of px 1
+                            else if (c == 1) wv = bc_hi(W[3 * r + 0]);   // col 2
+                            else if (c == 2) wv = bc_lo(W[3 * r + 1]);   // col 3
+                            else if (c == 3) wv = bc_hi(W[3 * r + 1]);   // col 4
+                            else wv = W[3 * r + 2];                      // (col 0 for px 0, col 5 for px 1)
+                            T[r] = K[c * 5 + r] * (wv - M);
+                        }
+                        P[c] = ((T[0] + T[1]) + (T[2] + T[3])) + T[4];
+                    }
+                    R.x = hsum5(P[4].x, P[0].x, P[1].x, P[2].x, P[3].x);
+                    R.y = hsum5(P[0].y, P[1].y, P[2].y, P[3].y, P[4].y);
+                    __builtin_amdgcn_sched_barrier(0);       // what follows (an older gather's consumer) stays behind this math
+                };
+                auto consume = [&](int f, const f2& R, const f2& s0, const f2& s1) {
+                    float* row = sc + f * sc_pitch + p0;
+                    row[0] = score_term(R.x, s0.x, s0.y);
+                    if (npx > 1) row[1] = score_term(R.y, s1.x, s1.y);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                const int nfe = (dbg & 4) ? 0 : nfades;
+                if (nfe > 0) {
+                    f2 RA, a0, a1, RB, b0, b1;
+                    eval(0, RA, a0, a1);
+                    int f = 1;
+                    for (; f + 1 < nfe; f += 2) {
+                        eval(f, RB, b0, b1);
+                        consume(f - 1, RA, a0, a1);
+                        eval(f + 1, RA, a0, a1);
+                        consume(f, RB, b0, b1);
+                    }
+                    if (f < nfe) {
+                        eval(f, RB, b0, b1);
+                        consume(f - 1, RA, a0, a1);
+                        consume(f, RB, b0, b1);
+                    } else {
+                        consume(f - 1, RA, a0, a1);
+                    }
+                }
+            }
+            prev_npix = B.npix; prev_g = g;
+            AMT_TICK(5);
+            __syncthreads();                         // B0: score rows complete, windows consumed
+            AMT_TICK(6);
+        }
+    }
+    // ---- last iteration's sum, then the results ----
+    if (it > 0 && wave == ((it - 1) & (kFusedWaves - 1))) {
+        if (lane < nfades) {
+            float* a = accs + prev_g * nfades + lane;
+            *a = ordered_row_sum(sc + lane * sc_pitch, prev_npix, *a);
+        }
+    }
+    __syncthreads();
+#ifdef AMT_FUSED_TIMING
+    if (lane == 0 && blockIdx.x == gridDim.x / 2) {
+        long long* tb = reinterpret_cast<long long*>(out + (long long)nframes * out_frame_stride);   // host reserves room
+        for (int k = 0; k < 8; ++k) tb[wave * 8 + k] = tacc[k];
+    }
+#endif
+    if (tid < gcount * nfades) {
+        const int g = tid / nfades, f = tid - g * nfades;
+        float r = accs[tid] / L.blackScore;
+        if (take_abs) r = fabsf(r);
+        out[(long long)(F0 + g) * out_frame_stride + L.out_off + fade0 + f] = r;
+    }
+}
+
+// <= 256 VGPRs: two waves per SIMD, nothing spilled (the fade loop alone holds ~200 live registers: taps 50, the two
+// windows 60, their blend 30, two alternating result/gather sets).  Three waves per SIMD (<= 168) spills taps to
+// scratch inside the fade loop and measured 2.6x slower.
+template <typename pix_t>
+__global__ __launch_bounds__(kEvalThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void logo_eval_fused_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands, const float* __restrict__ fades,
+                            int nfades, int fade0, const pix_t* __restrict__ Y, const int* __restrict__ frame_map,
+                            long long frame_stride, int pitch, float maxv, int nframes, int G, int ngroups, float* __restrict__ out,
+                            int out_frame_stride, int take_abs, int plane_cap, int sc_pitch, int dbg)
+{
+    logo_eval_fused_body<pix_t>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, nframes, G, ngroups, out,
+                                out_frame_stride, take_abs, plane_cap, sc_pitch, dbg);
+}
+
+static size_t fused_lds_bytes(int plane_cap, int nfades, int sc_pitch, int G)
+{
+    return ((size_t)2 * plane_cap + (size_t)nfades * sc_pitch + (size_t)G * nfades + 2 * kSumChunk) * sizeof(float);
+}
+
+hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* dlogos, int nlogos, const EvalBand* dbands,
+                                  const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
+                                  long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
+                                  int take_abs, int plane_cap)
+{
+    if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
+    if (nfades > kEvalMaxFades || G * nfades > kEvalThreads || plane_cap > kEvalThreads * kEvalStage) return hipErrorInvalidValue;
+    // timing experiments only (tools/gpu_try2.sh): AMTGPU_DBG bit 0 skips the sum, 1 the staging, 2 the fade loop,
+    // 3 the scale gather; AMTGPU_LDSPAD inflates the LDS request to lower the occupancy
+    static const int dbg = std::getenv("AMTGPU_DBG") ? std::atoi(std::getenv("AMTGPU_DBG")) : 0;
+    static const int ldspad = std::getenv("AMTGPU_LDSPAD") ? std::atoi(std::getenv("AMTGPU_LDSPAD")) : 0;
+    const int ngroups = (nframes + G - 1) / G;
+    const float maxv = (float)((1 << bits) - 1);
+    const int sc_pitch = kEvalBandPixels + kEvalScorePad;
+    dim3 grid((unsigned)((long long)ngroups * nlogos));
+    const size_t lds = fused_lds_bytes(plane_cap, nfades, sc_pitch, G) + (size_t)ldspad;
+    if (bits <= 8)
+        hipLaunchKernelGGL((logo_eval_fused_kernel<uint8_t>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,
+                           (const uint8_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride,
+                           take_abs, plane_cap, sc_pitch, dbg);
+    else
+        hipLaunchKernelGGL((logo_eval_fused_kernel<uint16_t>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,
+                           (const uint16_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride,
+                           take_abs, plane_cap, sc_pitch, dbg);
+    return hipGetLastError();
+}
+
+} // namespace amt

@@ -1,8 +1,8 @@
 // stats_kernels.hip -- whole-frame field-difference / combing metrics (self-specified).
 //
 // HBM-bound streaming reduction over the Y plane: every byte of every frame is read from HBM once.
-// One workgroup owns a tile (16 rows x up to 2048 bytes) for a RUN of consecutive frames; each thread
-// owns a 16-byte-wide column of that tile, so the vertical neighbours (rows y-1, y+1) and the previous
+// A thread owns a 16-byte-wide column of a 16-row tile for a RUN of consecutive frames (tiles x columns are dealt
+// densely to the threads of the grid), so the vertical neighbours (rows y-1, y+1) and the previous
 // frame's rows are all in the thread's own registers -- no LDS staging, no re-reads except the two halo
 // rows per tile.  Loads are 16 B per lane, 64 lanes = 1 KiB contiguous per row.  The per-byte work is
 // done four pixels at a time with v_sad_u8 / v_lerp_u8 (two per instruction for 16-bit samples).
@@ -64,11 +64,14 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
                         unsigned long long* __restrict__ out)
 {
     constexpr int R = kStatTileRows + 2;
-    const int tile = blockIdx.x / col_groups;
-    const int cg = blockIdx.x - tile * col_groups;
+    // (tile, 16-byte column) pairs are dealt to threads densely -- `cols` columns per tile, no idle lanes when the
+    // row is not a multiple of the workgroup's span (1440 bytes = 90 columns); a wave may straddle two tiles
+    const int cols = col_groups;                                  // 16-byte columns per row
+    const int gid = blockIdx.x * kStatThreads + threadIdx.x;
+    const int tile = gid / cols;
     const int y0 = tile * kStatTileRows;
-    const int xb = (cg * kStatThreads + threadIdx.x) * 16;       // byte column of this thread
-    const int nvalid = min(16, row_bytes - xb);                   // <= 0: thread has no pixels
+    const int xb = (gid - tile * cols) * 16;                      // byte column of this thread
+    const int nvalid = y0 < H ? min(16, row_bytes - xb) : 0;      // <= 0: thread has no pixels
     const int n0 = blockIdx.y * kStatRun;
     const int n1 = min(nframes, n0 + kStatRun);
 
@@ -93,9 +96,8 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int r = 1; r <= kStatTileRows; ++r) {
-            const int y = y0 - 1 + r;
-            if (y >= H) break;
-            const bool odd = y & 1;
+            const int y = y0 - 1 + r;                  // rows >= H were loaded as zeros and add nothing
+            const bool odd = ((r - 1) & 1) != 0;       // tiles start on even rows: a constant once unrolled
             acc[odd ? 1 : 0] = sad16<ES>(cur[r], prev[r], acc[odd ? 1 : 0]);
             acc[5] = sad16<ES>(cur[r], zero, acc[5]);
             if (y >= 1 && y <= H - 2) {
@@ -137,11 +139,12 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     if (nframes <= 0) return hipSuccess;
     const int es = bits <= 8 ? 1 : 2;
     const int row_bytes = W * es;
-    const int col_groups = (row_bytes + kStatThreads * 16 - 1) / (kStatThreads * 16);
+    const int col_groups = (row_bytes + 15) / 16;                 // 16-byte columns per row
     const int tiles = (H + kStatTileRows - 1) / kStatTileRows;
     hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)(tiles * col_groups), (unsigned)((nframes + kStatRun - 1) / kStatRun)), block(kStatThreads);
+    dim3 grid((unsigned)((tiles * col_groups + kStatThreads - 1) / kStatThreads), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
+        block(kStatThreads);
     if (es == 1)
         hipLaunchKernelGGL(frame_stats_kernel<1>, grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es,
                            row_bytes, H, (const uint8_t*)dprevY, nframes, col_groups, dout);

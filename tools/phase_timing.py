@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-phase cycle counts of one workgroup of the fused evaluation kernel (instrumented build, -DAMT_FUSED_TIMING).
+
+  here (CPU box):   python tools/phase_timing.py --build
+  on the GPU box:   AMTGPU_LIB=amatsukaze_amd/libamt_gpu_timing.so python tools/phase_timing.py --what analyze
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--build", action="store_true")
+ap.add_argument("--what", default="analyze")
+ap.add_argument("--frames", type=int, default=2048)
+a = ap.parse_args()
+if a.build:
+    from amatsukaze_amd import build as b
+    print(b.build_variant("timing", ["AMT_FUSED_TIMING"]))
+    sys.exit(0)
+
+import torch
+
+import amt_synth as S
+from amatsukaze_amd import AMTAnalyzeLogo, Context, DeviceClip, Logo
+
+W, H, LW, LH, X, Y0 = 1440, 1080, 256, 128, 1120, 64
+dev = torch.device("cuda:0")
+data, alpha, alphaUV = S.make_logo(LW, LH)
+clip = S.make_clip_torch(a.frames, W, H, 0x5EED0002, alpha, alphaUV, X, Y0, dev, pitchY=1472, pitchUV=768)
+dclip = DeviceClip(clip["Y"], clip["U"], clip["V"], W, H, 8)
+ctx = Context(0)
+logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
+out = torch.zeros((a.frames + 8, 33), dtype=torch.float32, device=dev)     # the kernel dumps its counters past the results
+an = AMTAnalyzeLogo(ctx, logo, 0.35)
+for _ in range(2):
+    an.analyze_device(dclip.Y[: a.frames], 8, out)
+torch.cuda.synchronize()
+t = out[a.frames:].reshape(-1)[:64].contiguous().view(torch.int64).cpu().numpy().reshape(4, 8)
+names = ["band prologue (slot, taps)", "staging loads+LDS writes", "ordered sum (one wave)", "wait B1", "window reads", "fade loop",
+         "wait B0", "-"]
+tot = t[:, :7].sum(1)
+print("cycles (s_memtime ticks) of the middle workgroup, per wave:")
+for k in range(7):
+    print(f"  {names[k]:28s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
+print("  total                        " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
