@@ -70,7 +70,7 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         const MaskTables& T = S.tables;
         const int w = S.planes.w, h = S.planes.h;
         const int lp = lds_pitch(w);
-        if (w > 0xFFFF || h > 0xFFFF || T.count >= (1 << 28)) throw std::runtime_error("logo too large");
+        if (w > 0xFFFF || h > 0xFFFF || T.count >= (1 << 24) - kTablePad) throw std::runtime_error("logo too large");   // 24-bit table index math
         if (5 * lp > kPlaneCapMax) throw std::runtime_error("logo too wide for the evaluation kernel");
         const int cpad = std::max(kTablePad, (T.count + kTablePad - 1) / kTablePad * kTablePad);
 

@@ -305,8 +305,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                     M.y = hsum5(CA.x, CA.y, CB.x, CB.y, CE.y);                          // pixel 1: cols 1..5
                     M = div25_pk(M);
                     if (!(dbg & 8)) {
-                        s0 = gld<f2>(gScales, ((unsigned)score_bin(M.x) * cpad + m0) * 8u);
-                        s1 = gld<f2>(gScales, ((unsigned)score_bin(M.y) * cpad + m1) * 8u);
+                        s0 = gld<f2>(gScales, (__umul24((unsigned)score_bin(M.x), cpad) + m0) * 8u);     // bin < 32, count_pad < 2^24: full-rate multiply
+                        s1 = gld<f2>(gScales, (__umul24((unsigned)score_bin(M.y), cpad) + m1) * 8u);
                     } else { s0 = M; s1 = M; }
                     f2 P[5];
 #pragma unroll

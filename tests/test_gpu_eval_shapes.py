@@ -1,0 +1,54 @@
+"""GPU parity of the fused evaluation kernel on the shapes its fast paths special-case: logo widths that are not a
+multiple of 4 (ragged last lane of the staging), wider than 256 (second column group), rectangle origins that are even
+but not 4-byte aligned (unaligned 4-sample loads), 16-bit samples, several frames per workgroup with a short last group.
+Bit-exact against the CPU oracle, like tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from amtlib import _ptr
+from test_gpu_parity import gpu, make_case, oracle_eval_logos  # noqa: F401  (fixture + helpers)
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    # name: (W, H, LW, LH, IMGX, IMGY, N)
+    "w98_ragged": (352, 240, 98, 44, 222, 18, 9),
+    "w322_two_groups": (704, 240, 322, 40, 362, 26, 7),
+    "origin_mod4_2": (352, 240, 96, 48, 226, 22, 9),
+    "tall_narrow": (352, 288, 36, 200, 300, 40, 5),
+}
+
+
+@pytest.mark.parametrize("bits", [8, 10])
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_analyze_shapes_bit_exact(gpu, shape, bits):
+    from amatsukaze_amd import AMTAnalyzeLogo
+    W, H, LW, LH, X, Y0, N = SHAPES[shape]
+    cfg = dict(W=W, H=H, LW=LW, LH=LH, IMGX=X, IMGY=Y0, N=N, period=4, fade=2, flat=3)
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=32)
+    got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"])
+    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"])
+    Y = cs["clip"]["Y"]
+    want = np.zeros(N * 33, np.float32)
+    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], bits, N, _ptr(want))
+    assert got.reshape(-1).tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("group", [2, 3, 8])
+def test_frames_per_workgroup_bit_exact(gpu, group):
+    """G frames share a workgroup (taps loaded once per band); 40 frames leave a short last group for G=3."""
+    from amatsukaze_amd import AMTAnalyzeLogo
+    cfg = dict(W=352, H=240, LW=96, LH=48, IMGX=224, IMGY=18, N=40, period=16, fade=6, flat=3)
+    cs = make_case(gpu, cfg, bits=8, pitch_pad=0)
+    os.environ["AMTGPU_G"] = str(group)
+    try:
+        got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"])
+    finally:
+        del os.environ["AMTGPU_G"]
+    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"])
+    Y = cs["clip"]["Y"]
+    want = np.zeros(cfg["N"] * 33, np.float32)
+    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
+    assert got.reshape(-1).tobytes() == want.tobytes()
