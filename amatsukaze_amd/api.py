@@ -115,6 +115,21 @@ class DeviceClip:
         return int(self.U.stride(1))
 
 
+def weave_fields(ctx: "Context", srcY, srcU, srcV, dst: DeviceClip, top_index=None, bottom_index=None, nv12=False):
+    """AMTSource::MakeFrame -> MergeField (AMTSource.hpp:291-366) on decoded pictures in HBM.
+
+    srcY (P,H,pitch), srcU/srcV (P,H/2,pitch) torch tensors (srcU = the interleaved UV plane and srcV = None for NV12);
+    dst frame i = even rows of picture top_index[i], odd rows of picture bottom_index[i] (None = i)."""
+    es = dst.es
+    n = dst.num_frames
+    ti = (C.c_int * n)(*[int(v) for v in top_index]) if top_index is not None else None
+    bi = (C.c_int * n)(*[int(v) for v in bottom_index]) if bottom_index is not None else None
+    ctx.check(ctx.lib.amtgpu_weave_fields_batch(
+        ctx.h, _p(srcY), _p(srcU), _p(srcV) if srcV is not None else None, int(srcY.stride(0)) * es, int(srcU.stride(0)) * es,
+        int(srcY.stride(1)), int(srcU.stride(1)), int(srcY.shape[0]), ti, bi, 1 if nv12 else 0, dst.bits, dst.width, dst.height,
+        _p(dst.Y), _p(dst.U), _p(dst.V), dst.strideY, dst.strideUV, dst.pitchY, dst.pitchUV, n))
+
+
 class Logo:
     """logo::LogoData + LogoHeader (AMTLogo.hpp:19-280)."""
 

@@ -30,6 +30,8 @@ SIGNATURES = {
     "amtgpu_frames_upload": (c_i, [c_p, c_p, c_p, c_u64]),
     "amtgpu_frames_upload_wait": (c_i, [c_p]),
     "amtgpu_download": (c_i, [c_p, c_p, c_p, c_u64]),
+    "amtgpu_weave_fields_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
+                                        c_i64, c_i64, c_i, c_i, c_i]),
     "amtgpu_logo_load": (c_p, [c_p, c_s]),
     "amtgpu_logo_from_planes": (c_p, [c_p] + [c_i] * 8 + [c_p]),
     "amtgpu_logo_save": (c_i, [c_p, c_p, c_s, c_s, c_i]),

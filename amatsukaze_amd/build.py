@@ -16,10 +16,12 @@ SOURCES = [
     "amt_gpu.hip",
     "amt_gpu_erase_scan.hip",
     "amt_gpu_stats.hip",
+    "amt_gpu_ingest.hip",
     "eval_engine.hip",
     "eval_fused_kernels.hip",
     "erase_scan_kernels.hip",
     "stats_kernels.hip",
+    "ingest_kernels.hip",
     "logo_model.cpp",
     "logo_fit.cpp",
     "decisions.cpp",

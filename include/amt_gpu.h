@@ -66,6 +66,20 @@ int   amtgpu_frames_upload(AmtGpuContext* ctx, void* ddst, const void* hsrc, uin
 int   amtgpu_frames_upload_wait(AmtGpuContext* ctx);   /* make the compute stream wait for pending uploads */
 int   amtgpu_download(AmtGpuContext* ctx, void* hdst, const void* dsrc, uint64_t bytes);        /* synchronous */
 
+/* ---- frame assembly: replaces AMTSource::MakeFrame -> MergeField / Copy1 / Copy2 (AMTSource.hpp:291-366) on decoded
+ *      pictures already in HBM (uploaded with amtgpu_frames_upload): output frame i takes its even rows from picture
+ *      top_index[i] and its odd rows from picture bottom_index[i] (the same picture for frame-coded streams, two for
+ *      field-coded ones), plane by plane; nv12 != 0: the source chroma is ONE interleaved UV plane (dsrcU; dsrcV ignored)
+ *      that is split into planar U and V (Copy2).  Pitches in ELEMENTS, strides in bytes; top_index / bottom_index are
+ *      host arrays of nframes entries or NULL (= i).  The reference multiplies BYTE pitches into uint16_t pointers for
+ *      > 8-bit pictures (:303-306 with T = uint16_t, :345-350); this uses element pitches, as every consumer of the frame
+ *      does.  async unless index arrays are given ---- */
+int   amtgpu_weave_fields_batch(AmtGpuContext* ctx, const void* dsrcY, const void* dsrcU, const void* dsrcV,
+                                int64_t src_strideY, int64_t src_strideUV, int src_pitchY, int src_pitchUV, int num_pictures,
+                                const int* top_index, const int* bottom_index, int nv12, int bits, int width, int height,
+                                void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY, int pitchUV,
+                                int nframes);
+
 /* ---- logo model: replaces LogoData::Load / Save (AMTLogo.hpp:239-279), LogoFile_* getters
  *      (LogoGUISupport.hpp:254-275) ---- */
 AmtGpuLogo* amtgpu_logo_load(AmtGpuContext* ctx, const char* path);

@@ -993,6 +993,60 @@ void frame_metrics_t(const uint8_t* base, int64_t frame_stride, int pitch, int W
 }
 } // extern "C++"
 
+extern "C++" {
+// ---- AMTSource::MergeField / Copy1 / Copy2 (AMTSource.hpp:291-355): the frame AMTSource hands to AviSynth takes its
+// even rows from the `top` picture and its odd rows from the `bottom` picture (Copy1 :291-302: dst row y <- top row y,
+// dst row y+1 <- bottom row y+1), chroma planes likewise (:345-347), NV12 chroma de-interleaved (Copy2 :304-322, srcV =
+// srcU + 1 :330).  Restatement only: AMTSource.hpp needs FFmpeg/AviSynth and is not part of oracle/_ref.  Pitches are in
+// ELEMENTS here; the reference passes byte pitches into T* arithmetic, which is only right for T = uint8_t.
+template <typename T>
+static void copy1_t(T* dst, const T* top, const T* bottom, int w, int h, int dpitch, int tpitch, int bpitch)
+{
+    for (int y = 0; y < h; y += 2) {
+        memcpy(dst + (size_t)dpitch * (y + 0), top + (size_t)tpitch * (y + 0), sizeof(T) * w);
+        memcpy(dst + (size_t)dpitch * (y + 1), bottom + (size_t)bpitch * (y + 1), sizeof(T) * w);
+    }
+}
+template <typename T>
+static void copy2_t(T* dstU, T* dstV, const T* top, const T* bottom, int w, int h, int dpitch, int tpitch, int bpitch)
+{
+    for (int y = 0; y < h; y += 2) {
+        const T* src0 = top + (size_t)tpitch * (y + 0);
+        const T* src1 = bottom + (size_t)bpitch * (y + 1);
+        for (int x = 0; x < w; ++x) {
+            dstU[(size_t)dpitch * (y + 0) + x] = src0[x * 2 + 0];
+            dstV[(size_t)dpitch * (y + 0) + x] = src0[x * 2 + 1];
+            dstU[(size_t)dpitch * (y + 1) + x] = src1[x * 2 + 0];
+            dstV[(size_t)dpitch * (y + 1) + x] = src1[x * 2 + 1];
+        }
+    }
+}
+template <typename T>
+static void merge_field_t(const T* tY, const T* tU, const T* tV, const T* bY, const T* bU, const T* bV, int spitchY, int spitchUV,
+                          int nv12, int W, int H, T* dY, T* dU, T* dV, int pitchY, int pitchUV)
+{
+    copy1_t<T>(dY, tY, bY, W, H, pitchY, spitchY, spitchY);
+    const int wUV = W >> 1, hUV = H >> 1;                 // 4:2:0: log2_chroma_w = log2_chroma_h = 1
+    if (!nv12) {
+        copy1_t<T>(dU, tU, bU, wUV, hUV, pitchUV, spitchUV, spitchUV);
+        copy1_t<T>(dV, tV, bV, wUV, hUV, pitchUV, spitchUV, spitchUV);
+    } else {
+        copy2_t<T>(dU, dV, tU, bU, wUV, hUV, pitchUV, spitchUV, spitchUV);
+    }
+}
+} // extern "C++"
+
+void orc_merge_field(const void* tY, const void* tU, const void* tV, const void* bY, const void* bU, const void* bV, int spitchY,
+                     int spitchUV, int nv12, int bits, int W, int H, void* dY, void* dU, void* dV, int pitchY, int pitchUV)
+{
+    if (bits <= 8)
+        merge_field_t<uint8_t>((const uint8_t*)tY, (const uint8_t*)tU, (const uint8_t*)tV, (const uint8_t*)bY, (const uint8_t*)bU,
+                               (const uint8_t*)bV, spitchY, spitchUV, nv12, W, H, (uint8_t*)dY, (uint8_t*)dU, (uint8_t*)dV, pitchY, pitchUV);
+    else
+        merge_field_t<uint16_t>((const uint16_t*)tY, (const uint16_t*)tU, (const uint16_t*)tV, (const uint16_t*)bY, (const uint16_t*)bU,
+                                (const uint16_t*)bV, spitchY, spitchUV, nv12, W, H, (uint16_t*)dY, (uint16_t*)dU, (uint16_t*)dV, pitchY, pitchUV);
+}
+
 void orc_frame_metrics(const void* Y, int64_t frame_stride, int pitch, int bits, int W, int H, int nframes,
                        const void* prev_first, uint64_t* out)
 {

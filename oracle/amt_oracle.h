@@ -113,6 +113,9 @@ OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V,
 /* ---- SELF-SPECIFIED whole-frame metrics -- PARITY UNPINNED: the reference has no
  * in-tree arithmetic for them.  C restatement of oracle/frame_stats_oracle.py, used as
  * the CPU baseline leg for these passes.  out = nframes*8 uint64, layout AMTGPU_FS_*; prev_first may be NULL. */
+/* AMTSource::MergeField (AMTSource.hpp:291-355): weave one frame from a top and a bottom picture; pitches in elements */
+void orc_merge_field(const void* tY, const void* tU, const void* tV, const void* bY, const void* bU, const void* bV, int spitchY,
+                     int spitchUV, int nv12, int bits, int W, int H, void* dY, void* dU, void* dV, int pitchY, int pitchUV);
 void orc_frame_metrics(const void* Y, int64_t frame_stride, int pitch, int bits, int W, int H, int nframes,
                        const void* prev_first, uint64_t* out);
 

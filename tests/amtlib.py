@@ -88,6 +88,7 @@ class Oracle:
         d("orc_scan_sums", None, [c_p, c_p])
         d("orc_scan_get_logo", c_p, [c_p, c_i, c_i, c_i, c_i, c_i, c_i])
         d("orc_frame_metrics", None, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
+        d("orc_merge_field", None, [c_p] * 6 + [c_i] * 6 + [c_p] * 3 + [c_i] * 2)
         d("orc_scanlogo", c_p, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
 
     # ---- helpers ----
