@@ -1,0 +1,125 @@
+/*
+ * amt_avs_min.h -- the handful of AviSynth host types the filter layer in amt_filters.hpp is written against.
+ *
+ * On the reference's host (MSVC + AviSynthNeo, include/avisynth.h) a maintainer includes the real header instead and
+ * deletes this one: the names, members and call shapes below are the ones the reference's filters use
+ * (LogoScan.hpp:1106-1236, 1238-1519; CMAnalyze.hpp:273-317): PClip / IClip::GetFrame / GetVideoInfo, PVideoFrame with
+ * GetReadPtr / GetWritePtr / GetPitch / GetRowSize / GetHeight per plane, IScriptEnvironment::NewVideoFrame /
+ * MakeWritable / ThrowError (-> AvisynthError), GenericVideoFilter with `child` and `vi`.  Only what those filters touch
+ * is here; this is a stand-in for building and testing the layer on Linux, not an AviSynth implementation.
+ */
+#ifndef AMT_AVS_MIN_H
+#define AMT_AVS_MIN_H
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace amtavs {
+
+enum { PLANAR_Y = 1 << 0, PLANAR_U = 1 << 1, PLANAR_V = 1 << 2 };
+enum { CACHE_GET_MTMODE = 509, MT_NICE_FILTER = 1 };
+
+struct AvisynthError {
+    std::string msg;
+    explicit AvisynthError(std::string m) : msg(std::move(m)) {}
+};
+
+struct VideoInfo {
+    enum { CS_YV12 = 1, CS_YUV420P10 = 2, CS_YUV420P12 = 3, CS_YUV420P14 = 4, CS_YUV420P16 = 5, CS_BGR32 = 100 };
+    int width = 0, height = 0;
+    unsigned fps_numerator = 30000, fps_denominator = 1001;
+    int num_frames = 0;
+    int pixel_type = CS_YV12;
+
+    int BitsPerComponent() const
+    {
+        switch (pixel_type) {
+        case CS_YUV420P10: return 10;
+        case CS_YUV420P12: return 12;
+        case CS_YUV420P14: return 14;
+        case CS_YUV420P16: return 16;
+        default: return 8;
+        }
+    }
+    int ComponentSize() const { return BitsPerComponent() > 8 ? 2 : 1; }
+    bool IsPlanar() const { return pixel_type != CS_BGR32; }
+};
+
+/* planes are 64-byte aligned like AviSynth's (include/avs/config.h:45 FRAME_ALIGN) */
+class VideoFrame {
+    std::vector<uint8_t> buf_;
+    int off_[3] = {0, 0, 0}, pitch_[3] = {0, 0, 0}, row_[3] = {0, 0, 0}, rows_[3] = {0, 0, 0};
+    static int idx(int plane) { return plane == PLANAR_U ? 1 : plane == PLANAR_V ? 2 : 0; }
+public:
+    explicit VideoFrame(const VideoInfo& vi)
+    {
+        auto al = [](int v) { return (v + 63) & ~63; };
+        if (vi.IsPlanar()) {
+            const int es = vi.ComponentSize();
+            row_[0] = vi.width * es; rows_[0] = vi.height;
+            row_[1] = row_[2] = (vi.width >> 1) * es; rows_[1] = rows_[2] = vi.height >> 1;
+        } else {
+            row_[0] = vi.width * 4; rows_[0] = vi.height;
+        }
+        int o = 0;
+        for (int p = 0; p < 3; ++p) { pitch_[p] = row_[p] ? al(row_[p]) : 0; off_[p] = o; o += pitch_[p] * rows_[p]; }
+        buf_.assign((size_t)o + 64, 0);
+        const int shift = (int)((64 - (reinterpret_cast<uintptr_t>(buf_.data()) & 63)) & 63);
+        for (int p = 0; p < 3; ++p) off_[p] += shift;
+    }
+    const uint8_t* GetReadPtr(int plane = PLANAR_Y) const { return buf_.data() + off_[idx(plane)]; }
+    uint8_t* GetWritePtr(int plane = PLANAR_Y) { return buf_.data() + off_[idx(plane)]; }
+    int GetPitch(int plane = PLANAR_Y) const { return pitch_[idx(plane)]; }
+    int GetRowSize(int plane = PLANAR_Y) const { return row_[idx(plane)]; }
+    int GetHeight(int plane = PLANAR_Y) const { return rows_[idx(plane)]; }
+};
+typedef std::shared_ptr<VideoFrame> PVideoFrame;
+
+class IScriptEnvironment {
+public:
+    virtual ~IScriptEnvironment() {}
+    virtual PVideoFrame NewVideoFrame(const VideoInfo& vi) { return std::make_shared<VideoFrame>(vi); }
+    /* frames handed out by this stand-in are never shared with a cache: copy-on-write only when someone else holds it */
+    virtual bool MakeWritable(PVideoFrame* pf)
+    {
+        if (pf->use_count() > 1) *pf = std::make_shared<VideoFrame>(**pf);
+        return true;
+    }
+    [[noreturn]] virtual void ThrowError(const char* fmt, ...)
+    {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        throw AvisynthError(buf);
+    }
+};
+typedef IScriptEnvironment IScriptEnvironment2;
+
+class IClip {
+public:
+    virtual ~IClip() {}
+    virtual PVideoFrame GetFrame(int n, IScriptEnvironment* env) = 0;
+    virtual const VideoInfo& GetVideoInfo() = 0;
+    virtual int SetCacheHints(int, int) { return 0; }
+};
+typedef std::shared_ptr<IClip> PClip;
+
+class GenericVideoFilter : public IClip {
+protected:
+    PClip child;
+    VideoInfo vi;
+public:
+    explicit GenericVideoFilter(PClip c) : child(std::move(c)), vi(child->GetVideoInfo()) {}
+    PVideoFrame GetFrame(int n, IScriptEnvironment* env) override { return child->GetFrame(n, env); }
+    const VideoInfo& GetVideoInfo() override { return vi; }
+};
+
+} /* namespace amtavs */
+#endif /* AMT_AVS_MIN_H */

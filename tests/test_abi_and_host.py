@@ -129,3 +129,13 @@ def test_c_and_numpy_stat_oracles_agree():
         out = np.zeros((5, 8), np.uint64)
         orc.lib.orc_frame_metrics(_ptr(Y), Y.strides[0], Y.shape[2], bits, 96, 38, 5, None, _ptr(out))
         assert np.array_equal(out, FS.frame_metrics(Y[:, :, :96]))
+
+
+def test_cpp_filter_layer_builds():
+    """include/amt_filters.hpp (AMTAnalyzeLogo / AMTEraseLogo / LogoFrame over the C ABI) and its host test program compile
+    with plain g++ against the library; running it needs a GPU (tests/test_gpu_filters_cpp.py)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(root, "tests", "cpp", "filters_host_test"))
