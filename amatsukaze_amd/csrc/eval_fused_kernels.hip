@@ -26,6 +26,7 @@
 //     per-frame results touches HBM.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <algorithm>
 #include <cstdlib>
 
 #include "eval_plan.h"
@@ -128,7 +129,10 @@ __device__ __forceinline__ float ordered_row_sum(const float* row, int n, float 
     return sum_add_n(B, acc, n - q - kSumChunk);
 }
 
-template <typename pix_t>
+// FPI = frames per iteration: a band-frame costs ~8-10 k cycles besides its fade loop (staging round trip, window reads,
+// taps, two barriers) whatever the number of fades; passes with few fades (the 2-fade scan) stage and evaluate two frames
+// per iteration -- one staging latency, one pair of barriers, FPI*nfades score rows summed by as many lanes.
+template <typename pix_t, int FPI>
 __device__ __forceinline__
 void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands,
                           const float* __restrict__ fades, int nfades, int fade0,
@@ -137,10 +141,9 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                           int take_abs, int plane_cap, int sc_pitch, int dbg)
 {
     extern __shared__ float lds[];
-    float* const planeS = lds;                       // [plane_cap]  source pixels of the band's rows
-    float* const planeB = lds + plane_cap;           // [plane_cap]  background estimate a*s + b*maxv
-    float* const sc = lds + 2 * plane_cap;           // [nfades][sc_pitch]  per-pixel terms of the current (band, frame)
-    float* const accs = sc + nfades * sc_pitch;      // [G][nfades]  running sums
+    float* const planes = lds;                       // [FPI][S: source pixels | BG: a*s + b*maxv][plane_cap]  the band's rows
+    float* const sc = lds + 2 * FPI * plane_cap;     // [FPI][nfades][sc_pitch]  per-pixel terms of the current (band, frames)
+    float* const accs = sc + FPI * nfades * sc_pitch;  // [G][nfades]  running sums
 
     const int logo = blockIdx.x / ngroups;
     const int grp = blockIdx.x - logo * ngroups;
@@ -166,7 +169,7 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
 #define AMT_TICK(k) do { } while (0)
 #endif
     int it = 0;                                      // (band, frame) iterations done
-    int prev_npix = 0, prev_g = 0;
+    int prev_npix = 0, prev_g = 0, prev_rows = 0;    // the iteration waiting to be summed: its band's pixels, first frame, score rows
     for (int bi = 0; bi < L.nbands; ++bi) {
         const EvalBand B = bands[L.band0 + bi];
         // ---- this thread's run slot: kernel taps as packed pairs, resident for all frames and fades of the band ----
@@ -186,14 +189,19 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
 #endif
         AMT_TICK(0);
 
-        for (int g = 0; g < gcount; ++g, ++it) {
+        for (int g = 0; g < gcount; g += FPI, ++it) {
+            const int nfr = min(FPI, gcount - g);
             // ---- 1. s and bg of the band's rows -> LDS.  A wave stages 4 consecutive rows x 256 columns at a time, a
             //      lane four adjacent columns (one 4*sizeof(pix_t) load per raw row, 16-byte loads of a and b, 16-byte
             //      LDS stores); the row is wave-uniform, so the address math is scalar, and the [1 2 1] vertical
             //      blend of DeintY re-uses the 6 raw rows it loads ----
-            const int frame = F0 + g;
-            const int srcFrame = frame_map ? frame_map[frame] : frame;
-            const gptr_t src = (gptr_t)(Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx);
+            gptr_t src[FPI];
+#pragma unroll
+            for (int fr = 0; fr < FPI; ++fr) {
+                const int frame = F0 + min(g + fr, gcount - 1);
+                const int srcFrame = frame_map ? frame_map[frame] : frame;
+                src[fr] = (gptr_t)(Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx);
+            }
             // Three waves stage (4 rows each per trip); the fourth -- the one that adds the previous iteration's
             // score rows below -- stages nothing, so that the sum runs beside the staging loads' latency.
             const int sumwave = (it + kFusedWaves - 1) & (kFusedWaves - 1);
@@ -204,15 +212,21 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                     const int x = xg + 4 * lane;
                     const int nv = min(4, w - x);                            // valid columns of this lane (<= 0: none)
                     const int xl = nv >= 4 ? x : 0;                          // lanes at a ragged right edge go column by column
-                    Raw4<pix_t> raw[kStageRows + 2];
+                    Raw4<pix_t> raw[FPI][kStageRows + 2];
                     f4 av[kStageRows], bv[kStageRows];
-                    if (L.deint) {
+                    // all frames' loads first (one round trip), then the arithmetic and the LDS stores
 #pragma unroll
-                        for (int j = 0; j < kStageRows + 2; ++j) raw[j].load(src, (unsigned)(min(max(y - 1 + j, 0), L.h - 1) * pitch + xl) * ES);
-                    } else {
+                    for (int fr = 0; fr < FPI; ++fr) {
+                        if (L.deint) {
 #pragma unroll
-                        for (int j = 0; j < kStageRows; ++j) raw[j + 1].load(src, (unsigned)(min(y + j, L.h - 1) * L.row_step * pitch + xl) * ES);
-                        raw[0] = raw[1]; raw[kStageRows + 1] = raw[kStageRows];
+                            for (int j = 0; j < kStageRows + 2; ++j)
+                                raw[fr][j].load(src[fr], (unsigned)(min(max(y - 1 + j, 0), L.h - 1) * pitch + xl) * ES);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < kStageRows; ++j)
+                                raw[fr][j + 1].load(src[fr], (unsigned)(min(y + j, L.h - 1) * L.row_step * pitch + xl) * ES);
+                            raw[fr][0] = raw[fr][1]; raw[fr][kStageRows + 1] = raw[fr][kStageRows];
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < kStageRows; ++j) {
@@ -220,42 +234,48 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                         av[j] = gld<f4u>(gA, o);      // 8-byte aligned (w and x even), not 16
                         bv[j] = gld<f4u>(gB, o);
                     }
-                    if (nv >= 4) {
 #pragma unroll
-                        for (int j = 0; j < kStageRows; ++j) {
-                            const int yy = y + j;
-                            if (rg + j < B.nrows) {
-                                const bool blend = L.deint && yy != 0 && yy != L.h - 1;
-                                f4 sv, gv;
+                    for (int fr = 0; fr < FPI; ++fr) {
+                        if (fr >= nfr) break;
+                        float* const planeS = planes + fr * 2 * plane_cap;
+                        float* const planeB = planeS + plane_cap;
+                        if (nv >= 4) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    const float s1 = blend ? (float)(raw[j].get(k) + 2 * raw[j + 1].get(k) + raw[j + 2].get(k) + 2) / 4.0f
-                                                           : (float)raw[j + 1].get(k);
-                                    sv[k] = s1;
-                                    gv[k] = unblend_bg(av[j][k], bv[j][k], maxv, s1);
+                            for (int j = 0; j < kStageRows; ++j) {
+                                const int yy = y + j;
+                                if (rg + j < B.nrows) {
+                                    const bool blend = L.deint && yy != 0 && yy != L.h - 1;
+                                    f4 sv, gv;
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        const float s1 = blend ? (float)(raw[fr][j].get(k) + 2 * raw[fr][j + 1].get(k) + raw[fr][j + 2].get(k) + 2) / 4.0f
+                                                               : (float)raw[fr][j + 1].get(k);
+                                        sv[k] = s1;
+                                        gv[k] = unblend_bg(av[j][k], bv[j][k], maxv, s1);
+                                    }
+                                    *reinterpret_cast<f4*>(planeS + (rg + j) * lp + x) = sv;
+                                    *reinterpret_cast<f4*>(planeB + (rg + j) * lp + x) = gv;
                                 }
-                                *reinterpret_cast<f4*>(planeS + (rg + j) * lp + x) = sv;
-                                *reinterpret_cast<f4*>(planeB + (rg + j) * lp + x) = gv;
                             }
-                        }
-                    } else if (nv > 0) {
-                        for (int j = 0; j < kStageRows && rg + j < B.nrows; ++j) {
-                            const int yy = y + j;
-                            const bool blend = L.deint && yy != 0 && yy != L.h - 1;
-                            for (int k = 0; k < nv; ++k) {
-                                int q0, q1, q2;
-                                if (L.deint) {
-                                    q0 = gld<pix_t>(src, (unsigned)(max(yy - 1, 0) * pitch + x + k) * ES);
-                                    q1 = gld<pix_t>(src, (unsigned)(yy * pitch + x + k) * ES);
-                                    q2 = gld<pix_t>(src, (unsigned)(min(yy + 1, L.h - 1) * pitch + x + k) * ES);
-                                } else {
-                                    q0 = q2 = 0;
-                                    q1 = gld<pix_t>(src, (unsigned)(yy * L.row_step * pitch + x + k) * ES);
+                        } else if (nv > 0) {
+                            for (int j = 0; j < kStageRows && rg + j < B.nrows; ++j) {
+                                const int yy = y + j;
+                                const bool blend = L.deint && yy != 0 && yy != L.h - 1;
+                                for (int k = 0; k < nv; ++k) {
+                                    int q0, q1, q2;
+                                    if (L.deint) {
+                                        q0 = gld<pix_t>(src[fr], (unsigned)(max(yy - 1, 0) * pitch + x + k) * ES);
+                                        q1 = gld<pix_t>(src[fr], (unsigned)(yy * pitch + x + k) * ES);
+                                        q2 = gld<pix_t>(src[fr], (unsigned)(min(yy + 1, L.h - 1) * pitch + x + k) * ES);
+                                    } else {
+                                        q0 = q2 = 0;
+                                        q1 = gld<pix_t>(src[fr], (unsigned)(yy * L.row_step * pitch + x + k) * ES);
+                                    }
+                                    const float s1 = blend ? (float)(q0 + 2 * q1 + q2 + 2) / 4.0f : (float)q1;
+                                    planeS[(rg + j) * lp + x + k] = s1;
+                                    planeB[(rg + j) * lp + x + k] = unblend_bg(gld<float>(gA, (unsigned)(yy * w + x + k) * 4u),
+                                                                               gld<float>(gB, (unsigned)(yy * w + x + k) * 4u), maxv, s1);
                                 }
-                                const float s1 = blend ? (float)(q0 + 2 * q1 + q2 + 2) / 4.0f : (float)q1;
-                                planeS[(rg + j) * lp + x + k] = s1;
-                                planeB[(rg + j) * lp + x + k] = unblend_bg(gld<float>(gA, (unsigned)(yy * w + x + k) * 4u),
-                                                                           gld<float>(gB, (unsigned)(yy * w + x + k) * 4u), maxv, s1);
                             }
                         }
                     }
@@ -264,15 +284,20 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
             AMT_TICK(1);
             // ---- 2. one wave adds the previous iteration's per-pixel terms in raster order (the others wait at B1, their
             //         SIMDs run other workgroups' fade loops meanwhile) ----
-            if (!(dbg & 1) && it > 0 && wave == sumwave && lane < nfades) {
-                float* a = accs + prev_g * nfades + lane;
+            if (!(dbg & 1) && it > 0 && wave == sumwave && lane < prev_rows) {
+                float* a = accs + prev_g * nfades + lane;            // row fr*nfades + f belongs to frame prev_g + fr
                 *a = ordered_row_sum(sc + lane * sc_pitch, prev_npix, *a);
             }
             AMT_TICK(2);
             __syncthreads();                         // B1: planes complete, score rows free again
             AMT_TICK(3);
+#pragma unroll
+            for (int fr = 0; fr < FPI; ++fr) {
+            if (fr >= nfr) break;
             // ---- 4. windows -> registers: per row the column pairs (1,2) (3,4) (0,5) ----
             f2 S[15], BG[15];
+            const float* const planeS = planes + fr * 2 * plane_cap;
+            const float* const planeB = planeS + plane_cap;
             if (act) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
@@ -329,7 +354,7 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                     __builtin_amdgcn_sched_barrier(0);       // what follows (an older gather's consumer) stays behind this math
                 };
                 auto consume = [&](int f, const f2& R, const f2& s0, const f2& s1) {
-                    float* row = sc + f * sc_pitch + p0;
+                    float* row = sc + (fr * nfades + f) * sc_pitch + p0;
                     row[0] = score_term(R.x, s0.x, s0.y);
                     if (npx > 1) row[1] = score_term(R.y, s1.x, s1.y);
                     __builtin_amdgcn_sched_barrier(0);
@@ -354,7 +379,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                     }
                 }
             }
-            prev_npix = B.npix; prev_g = g;
+            }
+            prev_npix = B.npix; prev_g = g; prev_rows = nfr * nfades;
             AMT_TICK(5);
             __syncthreads();                         // B0: score rows complete, windows consumed
             AMT_TICK(6);
@@ -362,7 +388,7 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
     }
     // ---- last iteration's sum, then the results ----
     if (it > 0 && wave == ((it - 1) & (kFusedWaves - 1))) {
-        if (lane < nfades) {
+        if (lane < prev_rows) {
             float* a = accs + prev_g * nfades + lane;
             *a = ordered_row_sum(sc + lane * sc_pitch, prev_npix, *a);
         }
@@ -385,20 +411,20 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
 // <= 256 VGPRs: two waves per SIMD, nothing spilled (the fade loop alone holds ~200 live registers: taps 50, the two
 // windows 60, their blend 30, two alternating result/gather sets).  Three waves per SIMD (<= 168) spills taps to
 // scratch inside the fade loop and measured 2.6x slower.
-template <typename pix_t>
+template <typename pix_t, int FPI>
 __global__ __launch_bounds__(kEvalThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void logo_eval_fused_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands, const float* __restrict__ fades,
                             int nfades, int fade0, const pix_t* __restrict__ Y, const int* __restrict__ frame_map,
                             long long frame_stride, int pitch, float maxv, int nframes, int G, int ngroups, float* __restrict__ out,
                             int out_frame_stride, int take_abs, int plane_cap, int sc_pitch, int dbg)
 {
-    logo_eval_fused_body<pix_t>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, nframes, G, ngroups, out,
-                                out_frame_stride, take_abs, plane_cap, sc_pitch, dbg);
+    logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, nframes, G, ngroups, out,
+                                     out_frame_stride, take_abs, plane_cap, sc_pitch, dbg);
 }
 
-static size_t fused_lds_bytes(int plane_cap, int nfades, int sc_pitch, int G)
+static size_t fused_lds_bytes(int plane_cap, int nfades, int sc_pitch, int G, int fpi)
 {
-    return ((size_t)2 * plane_cap + (size_t)nfades * sc_pitch + (size_t)G * nfades + 2 * kSumChunk) * sizeof(float);
+    return ((size_t)2 * fpi * plane_cap + (size_t)fpi * nfades * sc_pitch + (size_t)G * nfades + 2 * kSumChunk) * sizeof(float);
 }
 
 hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* dlogos, int nlogos, const EvalBand* dbands,
@@ -416,15 +442,18 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
     const float maxv = (float)((1 << bits) - 1);
     const int sc_pitch = kEvalBandPixels + kEvalScorePad;
     dim3 grid((unsigned)((long long)ngroups * nlogos));
-    const size_t lds = fused_lds_bytes(plane_cap, nfades, sc_pitch, G) + (size_t)ldspad;
-    if (bits <= 8)
-        hipLaunchKernelGGL((logo_eval_fused_kernel<uint8_t>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,
-                           (const uint8_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride,
-                           take_abs, plane_cap, sc_pitch, dbg);
-    else
-        hipLaunchKernelGGL((logo_eval_fused_kernel<uint16_t>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,
-                           (const uint16_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride,
-                           take_abs, plane_cap, sc_pitch, dbg);
+    // two frames per iteration while the planes and score rows of both fit half a CU's LDS (two workgroups per CU)
+    const int fpi_env = std::getenv("AMTGPU_FPI") ? std::atoi(std::getenv("AMTGPU_FPI")) : 0;
+    int fpi = fpi_env > 0 ? std::min(2, fpi_env) : 2;
+    if (G < 2 || fused_lds_bytes(plane_cap, nfades, sc_pitch, G, 2) > 80 * 1024 - 512) fpi = 1;
+    const size_t lds = fused_lds_bytes(plane_cap, nfades, sc_pitch, G, fpi) + (size_t)ldspad;
+#define AMT_LAUNCH(T, F)                                                                                                          \
+    hipLaunchKernelGGL((logo_eval_fused_kernel<T, F>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,         \
+                       (const T*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, \
+                       plane_cap, sc_pitch, dbg)
+    if (fpi == 2) { if (bits <= 8) AMT_LAUNCH(uint8_t, 2); else AMT_LAUNCH(uint16_t, 2); }
+    else { if (bits <= 8) AMT_LAUNCH(uint8_t, 1); else AMT_LAUNCH(uint16_t, 1); }
+#undef AMT_LAUNCH
     return hipGetLastError();
 }
 

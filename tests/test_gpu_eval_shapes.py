@@ -52,3 +52,32 @@ def test_frames_per_workgroup_bit_exact(gpu, group):
     want = np.zeros(cfg["N"] * 33, np.float32)
     cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
     assert got.reshape(-1).tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("group,bits", [(4, 8), (3, 8), (5, 10), (2, 8)])
+def test_scan_two_frames_per_iteration_bit_exact(gpu, group, bits):
+    """The 2-fade scan stages and evaluates two frames per iteration (FPI=2: two plane buffers, 4 score rows, 4 summing lanes)
+    whenever a workgroup owns >= 2 frames; odd group sizes and the short last group of 40 frames end on a single-frame iteration."""
+    import ctypes as C
+    import amt_synth as S
+    from amatsukaze_amd import Logo, LogoFrame
+    cfg = dict(W=352, H=240, LW=96, LH=48, IMGX=224, IMGY=18, N=40, period=16, fade=6, flat=3)
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=0)
+    d2, _, _ = S.make_logo(cfg["LW"], cfg["LH"], seed=0x10600002, strength=0.5)
+    logo2 = Logo.from_planes(gpu["ctx"], d2, cfg["LW"], cfg["LH"], cfg["W"], cfg["H"], cfg["IMGX"], cfg["IMGY"])
+    os.environ["AMTGPU_G"] = str(group)
+    try:
+        lf = LogoFrame(gpu["ctx"], [cs["logo"], logo2], 0.35)
+        lf.scanFrames(cs["dclip"], batch=23)
+        got = lf.evalResults
+    finally:
+        del os.environ["AMTGPU_G"]
+    orc = cs["orc"]
+    lo2 = orc.make_logo(d2, cfg["LW"], cfg["LH"], cfg["W"], cfg["H"], cfg["IMGX"], cfg["IMGY"])
+    hs = []
+    for l in (cs["lo"], lo2):
+        d = orc.lib.orc_logo_deint(l); orc.lib.orc_logo_create_mask(d, 0.35, 1); hs.append(d)
+    Y = cs["clip"]["Y"]
+    want = np.zeros(cfg["N"] * 2 * 2, np.float32)
+    orc.lib.orc_logoframe_scan((C.c_void_p * 2)(*hs), 2, _ptr(Y), Y.strides[0], Y.shape[2], bits, cfg["W"], cfg["H"], cfg["N"], _ptr(want))
+    assert got.reshape(-1).tobytes() == want.tobytes()

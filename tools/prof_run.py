@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--what", default="analyze")
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--logos", type=int, default=1, help="candidate logos of the LogoFrame scan (bench.py: 3)")
 a = ap.parse_args()
 W, H, LW, LH, X, Y0 = 1440, 1080, 256, 128, 1120, 64
 dev = torch.device("cuda:0")
@@ -30,7 +31,9 @@ logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
 out = torch.empty((a.frames, 33), dtype=torch.float32, device=dev)
 st = torch.empty((a.frames, 8), dtype=torch.int64, device=dev)
 an = AMTAnalyzeLogo(ctx, logo, 0.35)
-lf = LogoFrame(ctx, [logo], 0.35)
+cands = [logo] + [Logo.from_planes(ctx, S.make_logo(LW, LH, seed=0x10600002 + k, strength=0.5 + 0.1 * k)[0], LW, LH, W, H, X, Y0)
+                  for k in range(a.logos - 1)]
+lf = LogoFrame(ctx, cands, 0.35)
 lf.begin(W, H, 8, a.frames)
 fs = FrameStats(ctx, W, H, 8)
 ctx.profile(True)
