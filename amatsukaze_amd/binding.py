@@ -74,6 +74,8 @@ SIGNATURES = {
     "amtgpu_cm_scene_changes": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "amtgpu_kfm_cadence": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "amtgpu_kfm_write_durations": (c_i, [c_p, c_p, c_i, c_s, c_p]),
+    "amtgpu_kfm_write_timecode": (c_i, [c_p, c_p, c_i, c_i, c_i, c_s, c_p]),
+    "amtgpu_cm_write_chapter_exe": (c_i, [c_p, c_i, c_i, c_s]),
 }
 
 _lib = None

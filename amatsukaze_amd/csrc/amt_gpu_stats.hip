@@ -73,4 +73,43 @@ int amtgpu_kfm_write_durations(const uint8_t* cadence, const uint8_t* phase, int
     } catch (...) { return 0; }
 }
 
+// KFM timecode contract (FilteredSource.hpp:163-188): one integer per output frame = its start in ms (atoi'ed), comment lines
+// start with '#'; a "# total: <seconds>" line ends the parse and gives the duration.  Output frame k starts at the sum of
+// the 60p ticks of frames 0..k-1; a tick is fps_den / (2 * fps_num) seconds (1001/60000 for 29.97 fps sources).
+int amtgpu_kfm_write_timecode(const uint8_t* cadence, const uint8_t* phase, int nframes, int fps_num, int fps_den, const char* path,
+                              int* nout)
+{
+    try {
+        if (fps_num <= 0 || fps_den <= 0) return 0;
+        const std::vector<int> d = cadence_durations(cadence, phase, nframes);
+        FILE* fp = std::fopen(path, "w");
+        if (!fp) return 0;
+        std::fprintf(fp, "# timecode format v2\n");
+        const double tick_ms = 1000.0 * fps_den / (2.0 * fps_num);
+        long long ticks = 0;
+        for (int v : d) {
+            std::fprintf(fp, "%lld\n", (long long)(ticks * tick_ms + 0.5));
+            ticks += v;
+        }
+        std::fprintf(fp, "# total: %.6f\n", ticks * tick_ms / 1000.0);
+        std::fclose(fp);
+        if (nout) *nout = (int)d.size();
+        return 1;
+    } catch (...) { return 0; }
+}
+
+// chapter_exe's output as CMAnalyze::readSceneChanges parses it (CMAnalyze.hpp:411-439): everything up to a line that
+// starts with "----" is header; then "SCPos: <frame>" lines (and "mute<k>: <a> - <b>" lines, which this build never
+// writes: audio silence detection is out of scope).  The raw file also goes to join_logo_scp (:346-347).
+int amtgpu_cm_write_chapter_exe(const int* scene_changes, int nsc, int nframes, const char* path)
+{
+    FILE* fp = std::fopen(path, "w");
+    if (!fp) return 0;
+    std::fprintf(fp, "amtgpu scene changes (self-specified field-difference detector), %d frames\n", nframes);
+    std::fprintf(fp, "----------------------------------------\n");
+    for (int i = 0; i < nsc; ++i) std::fprintf(fp, "\tSCPos: %d %d\n", scene_changes[i], scene_changes[i]);
+    std::fclose(fp);
+    return 1;
+}
+
 } // extern "C"

@@ -197,6 +197,13 @@ int  amtgpu_kfm_cadence(const uint64_t* metrics, int nframes, int width, int hei
 /* KFM output-file contract (AMTDecimate, FilteredSource.hpp:645-654): one integer per output frame = how many
  * frames of the 60p clip it spans; sum == 2*nframes.  *nout = output frames written. */
 int  amtgpu_kfm_write_durations(const uint8_t* cadence, const uint8_t* phase, int nframes, const char* path, int* nout);
+/* KFM timecode contract (readTimecodeFile / readTimecode, FilteredSource.hpp:163-212): "# timecode format v2", one integer
+ * start time in ms per output frame, "# total: <seconds>".  fps_num/fps_den = the SOURCE frame rate (30000/1001). */
+int  amtgpu_kfm_write_timecode(const uint8_t* cadence, const uint8_t* phase, int nframes, int fps_num, int fps_den, const char* path,
+                               int* nout);
+/* chapter_exe output contract (CMAnalyze::readSceneChanges, CMAnalyze.hpp:411-439): header, a "----" line, "SCPos: <frame>"
+ * lines; no "mute" lines (audio is out of scope) */
+int  amtgpu_cm_write_chapter_exe(const int* scene_changes, int nsc, int nframes, const char* path);
 
 #ifdef __cplusplus
 }

@@ -139,3 +139,63 @@ def test_cpp_filter_layer_builds():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp")], stdout=subprocess.DEVNULL)
     assert os.path.exists(os.path.join(root, "tests", "cpp", "filters_host_test"))
+
+
+def test_kfm_and_cm_output_file_contracts(tmp_path):
+    """The files the reference READS back from the external detectors, written by this build and parsed here exactly as the
+    reference parses them: chapter_exe output (CMAnalyze.hpp:411-439), KFM timecode (FilteredSource.hpp:163-212: integer ms
+    per frame, '# total:', base fps = the one of 60/120/240 x 1000/1001 with the smallest rounding error), durations."""
+    import ctypes as C
+    import re
+    from amatsukaze_amd import binding
+    lib = binding.load()
+    # cadence: 40 frames of 3:2 film (phase advancing), 20 of 30p, 20 of 60i
+    n = 80
+    cad = np.array([1] * 40 + [2] * 20 + [0] * 20, np.uint8)
+    ph = np.array([i % 5 for i in range(40)] + [0] * 40, np.uint8)
+    dur_path, tc_path, ch_path = (str(tmp_path / f) for f in ("k.duration.txt", "k.timecode.txt", "chapter_exe.txt"))
+    nout, nout2 = C.c_int(), C.c_int()
+    assert lib.amtgpu_kfm_write_durations(cad.ctypes.data, ph.ctypes.data, n, dur_path.encode(), C.byref(nout)) == 1
+    assert lib.amtgpu_kfm_write_timecode(cad.ctypes.data, ph.ctypes.data, n, 30000, 1001, tc_path.encode(), C.byref(nout2)) == 1
+    durs = [int(x) for x in open(dur_path).read().split()]
+    assert sum(durs) == 2 * n and len(durs) == nout.value == nout2.value
+    # --- readTimecodeFile ---
+    tcs, total = [], None
+    for line in open(tc_path).read().splitlines():
+        if not line:
+            continue
+        m = re.search(r"#\s*total:\s*([+-]?([0-9]*[.])?[0-9]+).*", line)
+        if m:
+            total = float(m.group(1)) * 1000
+            break
+        if line[0] != "#":
+            tcs.append(int(line))
+    assert total is not None and len(tcs) == len(durs)
+    tick = 1001.0 / 60.0
+    want, t = [], 0
+    for d in durs:
+        want.append(int(t * tick + 0.5)); t += d
+    assert tcs == want
+    assert abs(total - n * 1001.0 / 30.0) < 1e-3                 # same duration as the source: within 0.1 s (FilteredSource.hpp:592-594)
+    # --- readTimecode: base fps inference ---
+    codes = tcs + [total]
+    best, mind = None, codes[-1]
+    for fps in (60, 120, 240):
+        mult = fps / 1001.0
+        diff = sum(abs(round(ts * mult) / mult - ts) for ts in codes)
+        if diff < mind - len(codes) * 10e-10:
+            best, mind = fps, diff
+    assert best == 60
+    # --- chapter_exe: readSceneChanges ---
+    sc = np.array([97, 194, 900], np.int32)
+    assert lib.amtgpu_cm_write_chapter_exe(sc.ctypes.data, len(sc), 1000, ch_path.encode()) == 1
+    lines = open(ch_path).read().splitlines()
+    k = next(i for i, l in enumerate(lines) if l.startswith("----"))
+    got = []
+    for l in lines[k + 1:]:
+        if re.search(r"mute\s*(\d+):\s*(\d+)\s*-\s*(\d+).*", l):
+            continue
+        m = re.search(r"\s*SCPos:\s*(\d+).*", l)
+        if m:
+            got.append(int(m.group(1)))
+    assert got == sc.tolist()
