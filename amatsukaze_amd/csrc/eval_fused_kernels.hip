@@ -45,6 +45,14 @@ template <typename T> __device__ __forceinline__ T gld(gptr_t base, unsigned byt
 }
 __device__ __forceinline__ f2 bc_lo(f2 v) { return __builtin_shufflevector(v, v, 0, 0); }
 __device__ __forceinline__ f2 bc_hi(f2 v) { return __builtin_shufflevector(v, v, 1, 1); }
+// exact_math.h score_bin in 5 instructions: clamping to [0,255] BEFORE the truncation gives the same bin as cvttss2si + clamp
+// for everything below 2^31 (negative and NaN -> 0: v_med3_f32 returns the minimum when an input is NaN); at and above 2^31
+// cvttss2si yields INT_MIN, i.e. bin 0, not 31
+__device__ __forceinline__ int score_bin_dev(float mean)
+{
+    const int bin = (int)__builtin_amdgcn_fmed3f(mean, 0.0f, 255.0f) >> 3;
+    return mean >= 2147483648.0f ? 0 : bin;
+}
 // x / 25 for both halves (exact_math.h div25, packed)
 __device__ __forceinline__ f2 div25_pk(f2 x)
 {
@@ -329,10 +337,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                     M.x = hsum5(CE.x, CA.x, CA.y, CB.x, CB.y);                          // pixel 0: cols 0..4
                     M.y = hsum5(CA.x, CA.y, CB.x, CB.y, CE.y);                          // pixel 1: cols 1..5
                     M = div25_pk(M);
-                    if (!(dbg & 8)) {
-                        s0 = gld<f2>(gScales, (__umul24((unsigned)score_bin(M.x), cpad) + m0) * 8u);     // bin < 32, count_pad < 2^24: full-rate multiply
-                        s1 = gld<f2>(gScales, (__umul24((unsigned)score_bin(M.y), cpad) + m1) * 8u);
-                    } else { s0 = M; s1 = M; }
+                    s0 = gld<f2>(gScales, (__umul24((unsigned)score_bin_dev(M.x), cpad) + m0) * 8u);   // bin < 32, count_pad < 2^24: full-rate multiply
+                    s1 = gld<f2>(gScales, (__umul24((unsigned)score_bin_dev(M.y), cpad) + m1) * 8u);
                     f2 P[5];
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
@@ -435,7 +441,7 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
     if (nfades > kEvalMaxFades || G * nfades > kEvalThreads || plane_cap > kEvalThreads * kEvalStage) return hipErrorInvalidValue;
     // timing experiments only (tools/gpu_try2.sh): AMTGPU_DBG bit 0 skips the sum, 1 the staging, 2 the fade loop,
-    // 3 the scale gather; AMTGPU_LDSPAD inflates the LDS request to lower the occupancy
+    // AMTGPU_LDSPAD inflates the LDS request to lower the occupancy
     static const int dbg = std::getenv("AMTGPU_DBG") ? std::atoi(std::getenv("AMTGPU_DBG")) : 0;
     static const int ldspad = std::getenv("AMTGPU_LDSPAD") ? std::atoi(std::getenv("AMTGPU_LDSPAD")) : 0;
     const int ngroups = (nframes + G - 1) / G;

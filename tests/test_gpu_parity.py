@@ -308,3 +308,26 @@ def test_empty_and_error_paths(gpu):
     with pytest.raises(AmtError):
         lf.begin(SMALL["W"], SMALL["H"], 8, 4)
         lf.scan_batch(cs["dclip"].Y, 8, 2)                  # range outside the declared clip
+
+
+def test_score_bin_edge_means(gpu):
+    """CorrelationScore picks its scale row by (int)avg clamped to [0,255] >> 3 (LogoScan.hpp:304) with x86 conversion
+    semantics; window means outside [0,256) -- negative, huge, infinite -- come from absurd but legal logo planes.  The kernel's
+    5-instruction bin must land on the same row as the oracle for all of them (whole outputs compared, NaNs included)."""
+    from amatsukaze_amd import AMTAnalyzeLogo, Logo
+    cfg = dict(SMALL, N=6)
+    for scale_a, scale_b in ((1.0, -40.0), (1.0, 300.0), (3.0e7, 0.0), (1.0, 3.0e37), (-1.0e30, 1.0e30)):
+        cs = make_case(gpu, cfg, bits=8)
+        data = cs["data"].copy()
+        n = cfg["LW"] * cfg["LH"]
+        data[:n] *= scale_a                      # A plane of luma
+        data[n:2 * n] = data[n:2 * n] * 0 + scale_b / 255.0 * (1 + np.arange(n, dtype=np.float32) % 7)   # B plane
+        logo = Logo.from_planes(gpu["ctx"], data, cfg["LW"], cfg["LH"], cfg["W"], cfg["H"], cfg["IMGX"], cfg["IMGY"])
+        got = AMTAnalyzeLogo(gpu["ctx"], logo, 0.35).analyze(cs["dclip"])
+        orc = cs["orc"]
+        lo = orc.make_logo(data, cfg["LW"], cfg["LH"], cfg["W"], cfg["H"], cfg["IMGX"], cfg["IMGY"])
+        d, t, b = oracle_eval_logos(orc, lo)
+        Y = cs["clip"]["Y"]
+        want = np.zeros(cfg["N"] * 33, np.float32)
+        orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
+        assert got.reshape(-1).tobytes() == want.tobytes(), (scale_a, scale_b)
