@@ -24,10 +24,11 @@ struct EraseGeom {
 // One workgroup = kDelogoRows consecutive rectangle rows (luma rows first, then U, then V) of one frame; a
 // thread owns PAIRS of horizontally adjacent samples (the rectangle origin and width are even, LogoScan.hpp:69,
 // so a luma pair is one aligned 2*sizeof(pix_t) access; chroma pairs are used when the chroma origin, width and
-// pitch are even too, otherwise that plane goes sample by sample).  16 workgroups per frame at 256x128 instead of
-// one per row: the pass is a read-modify-write of 48 KiB per frame and wants few, fat workgroups.
+// pitch are even too, otherwise that plane goes sample by sample), for kDelogoFrames consecutive frames: the pass is a
+// read-modify-write of 48 KiB per frame against 384 KiB of logo coefficients, which are therefore loaded once per group.
 constexpr int kDelogoRows = 16;
 constexpr int kDelogoThreads = 256;
+constexpr int kDelogoFrames = 8;       // frames a workgroup walks through with the row's logo coefficients in registers
 
 template <typename pix_t> struct PixPair;
 template <> struct PixPair<uint8_t> { typedef uint16_t type; };
@@ -45,49 +46,72 @@ template <typename pix_t>
 __global__ __launch_bounds__(kDelogoThreads)
 void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restrict__ V, long long strideY,
                    long long strideUV, int pitchY, int pitchUV, const float* __restrict__ planes, EraseGeom g,
-                   float maxv, const float2* __restrict__ fades, int pairY, int pairUV)
+                   float maxv, const float2* __restrict__ fades, int pairY, int pairUV, int nframes)
 {
     typedef typename PixPair<pix_t>::type pair_t;
     constexpr int SH = 8 * sizeof(pix_t);
-    const int frame = blockIdx.y;
-    const float2 fd = fades[frame];
-    const bool frameMode = fd.x == fd.y;
+    const int f0 = blockIdx.y * kDelogoFrames;
+    const int f1 = min(nframes, f0 + kDelogoFrames);
     const size_t ysz = (size_t)g.w * g.h, csz = (size_t)g.wUV * g.hUV;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int rend = min(g.h + 2 * g.hUV, (int)(blockIdx.x + 1) * kDelogoRows);
     for (int r = blockIdx.x * kDelogoRows + wv; r < rend; r += kDelogoThreads / 64) {
-        pix_t* row;
+        // the row's geometry and logo coefficients are the same for every frame of the group: the logo planes are
+        // 8 B per sample against 2 B of frame traffic, so they are read once and kept in registers
+        pix_t* row0;
         const float *A, *B;
-        int roww, paired;
-        float fade;
+        int roww, paired, y, pl;
+        long long stride;
         if (r < g.h) {
-            const int y = r;
-            roww = g.w; paired = pairY;
-            row = Y + (long long)frame * strideY + (long long)(g.imgy + y) * pitchY + g.imgx;
+            y = r; pl = 0;
+            roww = g.w; paired = pairY; stride = strideY;
+            row0 = Y + (long long)(g.imgy + y) * pitchY + g.imgx;
             A = planes + (size_t)y * g.w; B = planes + ysz + (size_t)y * g.w;
-            fade = frameMode ? fd.x : ((y & 1) ? fd.y : fd.x);
         } else {
-            const int pl = (r - g.h) >= g.hUV ? 1 : 0;
-            const int y = r - g.h - pl * g.hUV;
-            roww = g.wUV; paired = pairUV;
-            if (!frameMode && y >= 2 * (g.hUV / 2)) continue;
-            row = (pl ? V : U) + (long long)frame * strideUV + (long long)(g.cy + y) * pitchUV + g.cx;
-            const float* base = planes + 2 * ysz + (size_t)pl * 2 * csz;
+            pl = (r - g.h) >= g.hUV ? 2 : 1;
+            y = r - g.h - (pl - 1) * g.hUV;
+            roww = g.wUV; paired = pairUV; stride = strideUV;
+            row0 = (pl == 2 ? V : U) + (long long)(g.cy + y) * pitchUV + g.cx;
+            const float* base = planes + 2 * ysz + (size_t)(pl - 1) * 2 * csz;
             A = base + (size_t)y * g.wUV; B = base + csz + (size_t)y * g.wUV;
-            fade = frameMode ? fd.x : (((y & 1) == g.uvparity) ? fd.x : fd.y);
         }
+        auto fade_of = [&](float2 fd, bool& skip) {
+            const bool frameMode = fd.x == fd.y;
+            skip = pl != 0 && !frameMode && y >= 2 * (g.hUV / 2);   // field mode leaves an odd last chroma row alone
+            if (frameMode) return fd.x;
+            return pl == 0 ? ((y & 1) ? fd.y : fd.x) : (((y & 1) == g.uvparity) ? fd.x : fd.y);
+        };
         if (paired) {
             for (int x = 2 * lane; x < roww; x += 128) {
-                const pair_t p = *reinterpret_cast<const pair_t*>(row + x);
                 const float2 a = *reinterpret_cast<const float2*>(A + x);
                 const float2 b = *reinterpret_cast<const float2*>(B + x);
-                const float r0 = delogo_px((float)(pix_t)p, a.x, b.x, maxv, fade);
-                const float r1 = delogo_px((float)(pix_t)(p >> SH), a.y, b.y, maxv, fade);
-                *reinterpret_cast<pair_t*>(row + x) = (pair_t)((pair_t)(pix_t)r0 | ((pair_t)(pix_t)r1 << SH));
+                pair_t v[kDelogoFrames];                                 // all frames' loads in flight before the first use
+#pragma unroll
+                for (int k = 0; k < kDelogoFrames; ++k)
+                    v[k] = *reinterpret_cast<const pair_t*>(row0 + (long long)min(f0 + k, f1 - 1) * stride + x);
+#pragma unroll
+                for (int k = 0; k < kDelogoFrames; ++k) {
+                    const int f = f0 + k;
+                    if (f >= f1) break;
+                    bool skip;
+                    const float fade = fade_of(fades[f], skip);
+                    if (skip) continue;
+                    const float r0 = delogo_px((float)(pix_t)v[k], a.x, b.x, maxv, fade);
+                    const float r1 = delogo_px((float)(pix_t)(v[k] >> SH), a.y, b.y, maxv, fade);
+                    *reinterpret_cast<pair_t*>(row0 + (long long)f * stride + x) = (pair_t)((pair_t)(pix_t)r0 | ((pair_t)(pix_t)r1 << SH));
+                }
             }
         } else {
-            for (int x = lane; x < roww; x += 64)
-                row[x] = (pix_t)delogo_px((float)row[x], A[x], B[x], maxv, fade);
+            for (int x = lane; x < roww; x += 64) {
+                const float a = A[x], b = B[x];
+                for (int f = f0; f < f1; ++f) {
+                    bool skip;
+                    const float fade = fade_of(fades[f], skip);
+                    if (skip) continue;
+                    pix_t* p = row0 + (long long)f * stride + x;
+                    *p = (pix_t)delogo_px((float)*p, a, b, maxv, fade);
+                }
+            }
         }
     }
 }
@@ -97,7 +121,7 @@ hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV,
 {
     if (nframes <= 0) return hipSuccess;
     const int rows = g.h + 2 * g.hUV;
-    dim3 grid((unsigned)((rows + kDelogoRows - 1) / kDelogoRows), (unsigned)nframes), block(kDelogoThreads);
+    dim3 grid((unsigned)((rows + kDelogoRows - 1) / kDelogoRows), (unsigned)((nframes + kDelogoFrames - 1) / kDelogoFrames)), block(kDelogoThreads);
     const float maxv = (float)((1 << bits) - 1);
     const int es = bits <= 8 ? 1 : 2;
     auto even = [](long long v) { return (v & 1) == 0; };
@@ -108,10 +132,10 @@ hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV,
                        ((uintptr_t)dV % (2 * es) == 0);
     if (bits <= 8)
         hipLaunchKernelGGL(delogo_kernel<uint8_t>, grid, block, 0, st, (uint8_t*)dY, (uint8_t*)dU, (uint8_t*)dV, strideY,
-                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV);
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes);
     else
         hipLaunchKernelGGL(delogo_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)dY, (uint16_t*)dU, (uint16_t*)dV, strideY,
-                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV);
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes);
     return hipGetLastError();
 }
 
