@@ -25,7 +25,7 @@ if a.build:
 import torch
 
 import amt_synth as S
-from amatsukaze_amd import AMTAnalyzeLogo, Context, DeviceClip, Logo
+from amatsukaze_amd import AMTAnalyzeLogo, Context, DeviceClip, Logo, LogoFrame
 
 W, H, LW, LH, X, Y0 = 1440, 1080, 256, 128, 1120, 64
 dev = torch.device("cuda:0")
@@ -34,12 +34,23 @@ clip = S.make_clip_torch(a.frames, W, H, 0x5EED0002, alpha, alphaUV, X, Y0, dev,
 dclip = DeviceClip(clip["Y"], clip["U"], clip["V"], W, H, 8)
 ctx = Context(0)
 logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
-out = torch.zeros((a.frames + 8, 33), dtype=torch.float32, device=dev)     # the kernel dumps its counters past the results
-an = AMTAnalyzeLogo(ctx, logo, 0.35)
-for _ in range(2):
-    an.analyze_device(dclip.Y[: a.frames], 8, out)
-torch.cuda.synchronize()
-t = out[a.frames:].reshape(-1)[:64].contiguous().view(torch.int64).cpu().numpy().reshape(4, 8)
+if a.what == "scan":
+    # the kernel dumps its counters past the results of the frames it was given: declare a longer clip, scan its head
+    import numpy as np
+    lf = LogoFrame(ctx, [logo], 0.35)
+    lf.begin(W, H, 8, a.frames + 64)
+    for _ in range(2):
+        lf.scan_batch(dclip.Y[: a.frames], 8, 0, a.frames)
+    torch.cuda.synchronize()
+    r = np.ascontiguousarray(lf.evalResults.reshape(-1)[a.frames * 2:a.frames * 2 + 64])
+    t = r.view(np.int64).reshape(4, 8)
+else:
+    out = torch.zeros((a.frames + 8, 33), dtype=torch.float32, device=dev)     # the kernel dumps its counters past the results
+    an = AMTAnalyzeLogo(ctx, logo, 0.35)
+    for _ in range(2):
+        an.analyze_device(dclip.Y[: a.frames], 8, out)
+    torch.cuda.synchronize()
+    t = out[a.frames:].reshape(-1)[:64].contiguous().view(torch.int64).cpu().numpy().reshape(4, 8)
 names = ["band prologue (slot, taps)", "staging loads+LDS writes", "ordered sum (one wave)", "wait B1", "window reads", "fade loop",
          "wait B0", "-"]
 tot = t[:, :7].sum(1)
