@@ -97,7 +97,45 @@ def cpu_baseline(nframes, logos, alpha, alphaUV, min_seconds=12.0):
         frames_timed += nframes
         for k, dt in zip(detail, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
             detail[k] += dt
+    detail["reference_check"] = reference_logo_passes(orc, hs, Y, U, V, nframes)
     return frames_timed / total, detail, frames_timed
+
+
+def reference_logo_passes(orc, hs, Y, U, V, nframes):
+    """The REAL reference (oracle/_ref/libamt_ref.so: LogoScan.hpp / ComputeKernel.cpp compiled through oracle/ref_shim) on the
+    same sample, once, for the two passes it has: LogoFrame scan and AMTAnalyzeLogo.  Shows what the port's timing stands for;
+    None where the library was never built (it needs /root/reference at build time)."""
+    import tempfile
+    from amtlib import Ref
+    if not Ref.available():
+        return None
+    ref = Ref()
+    tmp = tempfile.mkdtemp()
+    paths = []
+    for i, h in enumerate(hs):
+        p = os.path.join(tmp, f"logo{i}.lgd").encode()
+        if not orc.lib.orc_logo_save(h, p, b"bench", 1):
+            return None
+        paths.append(p)
+    ev = np.zeros(nframes * 3 * 2, np.float32)
+    best, ratio = C.c_int(), C.c_float()
+    text = C.create_string_buffer(1 << 20)
+    t0 = time.perf_counter()
+    ok = ref.lib.ref_logoframe((C.c_char_p * 3)(*paths), 3, MASKRATIO, _ptr_np(Y), Y.strides[0], Y.shape[2], 8, W, H, nframes, 30000, 1001,
+                               _ptr_np(ev), 3, C.byref(best), C.byref(ratio), -1, os.path.join(tmp, "logof.txt").encode(), text, len(text))
+    t1 = time.perf_counter()
+    an = np.zeros(nframes * 33, np.float32)
+    ok2 = ref.lib.ref_analyze(paths[0], MASKRATIO, _ptr_np(Y), _ptr_np(U), _ptr_np(V), Y.strides[0], U.strides[0], Y.shape[2], U.shape[2], 8,
+                              W, H, nframes, _ptr_np(an))
+    t2 = time.perf_counter()
+    if ok != 1 or ok2 != 1:
+        return None
+    return {"kind": "reference", "frames": nframes, "scan_s": t1 - t0, "analyze_s": t2 - t1,
+            "note": "includes the one-off CreateLogoMask setup of each filter instance"}
+
+
+def _ptr_np(a):
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def main():
