@@ -171,7 +171,7 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
     if (frame_stride_bytes % es) throw std::runtime_error("frame stride not a multiple of the sample size");
     // frames per workgroup: amortises the per-band tap loads; keep >= ~2k workgroups per launch
     const int nl = (int)specs_.size();
-    int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(4LL, (long long)nframes * nl / 2048));
+    int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
     const int nf_all = (int)fades_.size();
     for (int f0 = 0; f0 < nf_all; f0 += kEvalMaxFades) {
         const int nf = std::min(kEvalMaxFades, nf_all - f0);
