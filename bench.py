@@ -267,7 +267,7 @@ def main():
         else:
             roofline = None
         cpu = None
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:        # the CPU baseline is reported at N=1 only
             cfps, detail, ctimed = cpu_baseline(args.cpu_frames, logos_np, alpha, alphaUV, args.cpu_seconds)
             cpu = {"value": cfps, "unit": "frames/sec", "cores": 1, "kind": "port",
                    "sample": f"{ctimed} frames ({args.cpu_frames} distinct 1440x1080 8-bit frames, pass repeated), same pass (scan 3 logos + "
