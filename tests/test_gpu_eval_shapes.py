@@ -81,3 +81,36 @@ def test_scan_two_frames_per_iteration_bit_exact(gpu, group, bits):
     want = np.zeros(cfg["N"] * 2 * 2, np.float32)
     orc.lib.orc_logoframe_scan((C.c_void_p * 2)(*hs), 2, _ptr(Y), Y.strides[0], Y.shape[2], bits, cfg["W"], cfg["H"], cfg["N"], _ptr(want))
     assert got.reshape(-1).tobytes() == want.tobytes()
+
+
+def test_widest_supported_logo_and_too_wide(gpu):
+    """A band must hold the 5 rows of a window in its LDS plane (3072 floats): 576 columns is the widest logo that fits (row
+    pitch 584, one mask row per band, three 256-column staging groups); wider logos are refused, not mis-evaluated."""
+    from amatsukaze_amd import AMTAnalyzeLogo, AmtError
+    W, H, LW, LH, X, Y0, N = 704, 96, 576, 24, 100, 30, 5
+    cfg = dict(W=W, H=H, LW=LW, LH=LH, IMGX=X, IMGY=Y0, N=N, period=4, fade=2, flat=3)
+    cs = make_case(gpu, cfg, bits=8, pitch_pad=0)
+    got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"])
+    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"])
+    Y = cs["clip"]["Y"]
+    want = np.zeros(N * 33, np.float32)
+    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, N, _ptr(want))
+    assert got.reshape(-1).tobytes() == want.tobytes()
+    cfg2 = dict(W=800, H=96, LW=680, LH=24, IMGX=60, IMGY=30, N=2, period=4, fade=2, flat=3)
+    cs2 = make_case(gpu, cfg2, bits=8, pitch_pad=0)
+    with pytest.raises(AmtError, match="too wide"):
+        AMTAnalyzeLogo(gpu["ctx"], cs2["logo"], 0.35)
+
+
+@pytest.mark.parametrize("maskratio", [0.02, 1.0])
+def test_mask_ratio_extremes(gpu, maskratio):
+    """maskratio 1.0 selects every pixel (mask pixels = w*h, LogoScan.hpp:172; runs are whole rows); 0.02 leaves a few dozen."""
+    from amatsukaze_amd import AMTAnalyzeLogo
+    cfg = dict(W=352, H=240, LW=96, LH=48, IMGX=224, IMGY=18, N=6, period=4, fade=2, flat=3)
+    cs = make_case(gpu, cfg, bits=8, pitch_pad=0)
+    got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], maskratio).analyze(cs["dclip"])
+    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"], maskratio)
+    Y = cs["clip"]["Y"]
+    want = np.zeros(cfg["N"] * 33, np.float32)
+    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
+    assert got.reshape(-1).tobytes() == want.tobytes()
