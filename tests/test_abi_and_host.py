@@ -131,7 +131,7 @@ def test_c_and_numpy_stat_oracles_agree():
         assert np.array_equal(out, FS.frame_metrics(Y[:, :, :96]))
 
 
-def test_cpp_filter_layer_builds():
+def test_cpp_filter_layer_builds(lib):
     """include/amt_filters.hpp (AMTAnalyzeLogo / AMTEraseLogo / LogoFrame over the C ABI) and its host test program compile
     with plain g++ against the library; running it needs a GPU (tests/test_gpu_filters_cpp.py)."""
     import os
@@ -141,14 +141,12 @@ def test_cpp_filter_layer_builds():
     assert os.path.exists(os.path.join(root, "tests", "cpp", "filters_host_test"))
 
 
-def test_kfm_and_cm_output_file_contracts(tmp_path):
+def test_kfm_and_cm_output_file_contracts(tmp_path, lib):
     """The files the reference READS back from the external detectors, written by this build and parsed here exactly as the
     reference parses them: chapter_exe output (CMAnalyze.hpp:411-439), KFM timecode (FilteredSource.hpp:163-212: integer ms
     per frame, '# total:', base fps = the one of 60/120/240 x 1000/1001 with the smallest rounding error), durations."""
     import ctypes as C
     import re
-    from amatsukaze_amd import binding
-    lib = binding.load()
     # cadence: 40 frames of 3:2 film (phase advancing), 20 of 30p, 20 of 60i
     n = 80
     cad = np.array([1] * 40 + [2] * 20 + [0] * 20, np.uint8)
