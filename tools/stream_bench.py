@@ -74,11 +74,14 @@ def compute_only():
 
 
 def pipelined():
+    done = [torch.cuda.Event(), torch.cuda.Event()]            # compute on a buffer finished
     upload(0)
     for k in range(a.batches):
         compute(k)                                              # launches are asynchronous ...
+        done[k & 1].record()
         if k + 1 < a.batches:
-            torch.cuda.current_stream().synchronize() if k >= 1 else None   # batch k-1's buffer is free before it is overwritten
+            if k >= 1:
+                done[(k + 1) & 1].synchronize()                 # batch k-1 has released the buffer batch k+1 goes into
             upload(k + 1)                                       # ... so this host copy + DMA runs beside batch k's kernels
 
 
