@@ -54,3 +54,45 @@ def test_gpu_reproduces_reference_golden(tmp_path):
     dst = tmp_path / "scan.lgd"
     assert ScanLogo(ctx, dc2, 1041, dst, X, Y0, LW, LH, 12, 25)
     assert dst.read_bytes() == g["scanlogo_lgd"].tobytes()
+
+
+@pytest.mark.parametrize("name", ["sd10", "sd12", "hd8", "fhd10"])
+def test_gpu_reproduces_reference_golden_hibit_hd(name):
+    """> 8-bit containers (10/12-bit in uint16) and HD frame sizes against outputs of the REAL reference."""
+    import torch
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Context, DeviceClip, Logo, LogoFrame
+    cases, logof_text = G.load_v2()
+    c = cases[name]
+    W, H, bits, LW, LH, X, Y0, N = (c[k] for k in ("W", "H", "bits", "LW", "LH", "X", "Y0", "N"))
+    dev = torch.device("cuda:0")
+    ctx = Context(0)
+    Y, U, V = G.frames_v2(c, pitch_pad=32)
+    tt = (lambda a: torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(dev))
+    mk = lambda: DeviceClip(tt(Y), tt(U), tt(V), W, H, bits)
+    logo = Logo.from_planes(ctx, c["logo"], LW, LH, W, H, X, Y0)
+    an = AMTAnalyzeLogo(ctx, logo, 0.35).analyze(mk())
+    assert an.tobytes() == c["analysis"].tobytes()
+    for tag in ("nolf", "lf"):
+        if f"erase_{tag}_fades" not in c:
+            continue
+        dc = mk()
+        er = AMTEraseLogo(ctx, logo, logof_text.decode() if tag == "lf" else "", 0, 16)
+        fades = er.calc_fades(an, N)
+        assert fades.tobytes() == c[f"erase_{tag}_fades"].tobytes()
+        er.erase(dc, fades)
+        ctx.synchronize()
+        gy, gu, gv = (t.cpu().numpy().view(Y.dtype) for t in (dc.Y, dc.U, dc.V))
+        assert np.array_equal(gy[:, Y0:Y0 + LH, X:X + LW], c[f"erase_{tag}_Y"])
+        assert np.array_equal(gu[:, Y0 // 2:Y0 // 2 + LH // 2, X // 2:X // 2 + LW // 2], c[f"erase_{tag}_U"])
+        assert np.array_equal(gv[:, Y0 // 2:Y0 // 2 + LH // 2, X // 2:X // 2 + LW // 2], c[f"erase_{tag}_V"])
+    if "logoframe_evals" in c:
+        lf = LogoFrame(ctx, [logo], 0.35)
+        lf.scanFrames(mk())
+        assert lf.evalResults.tobytes() == c["logoframe_evals"].tobytes()
+    if "logoframe_evals_bytepitch" in c:
+        # LogoFrame::ScanFrame<uint16_t>'s byte-pitch stride (LogoScan.hpp:1547,1561) reproduced by passing a doubled pitch
+        Yq = tt(G.quirk_frames_v2(c))
+        lf = LogoFrame(ctx, [logo], 0.35)
+        lf.begin(W, H, bits, N)
+        ctx.check(ctx.lib.amtgpu_logoframe_scan_batch(lf.h, Yq.data_ptr(), int(Yq.stride(0)) * 2, 2 * int(Yq.stride(1)), 0, N))
+        assert lf.evalResults.tobytes() == c["logoframe_evals_bytepitch"].tobytes()

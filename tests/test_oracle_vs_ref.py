@@ -264,3 +264,118 @@ def test_scanlogo_full_pipeline(env):
     true_aY = env["data"][:LW * LH].reshape(LH, LW)
     m = alpha > 0.3
     assert np.abs(aY[m] - true_aY[m]).mean() < 0.35
+
+
+# ------------------------------------------------------------------------------------------------
+# > 8-bit clips and HD frame sizes: AMTAnalyzeLogo / AMTEraseLogo are correct for 16-bit containers in the
+# reference (LogoScan.hpp:1130-1161 divides the byte pitch, :1343-1400), so the oracle is pinned there too.
+# ------------------------------------------------------------------------------------------------
+def _oracle_logos(orc, lo, maskratio=0.35):
+    d = orc.lib.orc_logo_deint(lo); orc.lib.orc_logo_create_mask(d, maskratio, 1)
+    t = orc.lib.orc_logo_field(lo, 0); orc.lib.orc_logo_create_mask(t, maskratio, 1)
+    b = orc.lib.orc_logo_field(lo, 1); orc.lib.orc_logo_create_mask(b, maskratio, 1)
+    return d, t, b
+
+
+def _analyze_erase_both(orc, ref, lo, path, clip, w, h, bits, n, logof_text=b"", tmp=None):
+    """(reference, oracle) x (analysis, fades, erased Y/U/V) on the same clip"""
+    Yr, Ur, Vr = clip["Y"].copy(), clip["U"].copy(), clip["V"].copy()
+    an_r = np.zeros(n * 33, np.float32)
+    assert ref.lib.ref_analyze(path, 0.35, _ptr(Yr), _ptr(Ur), _ptr(Vr), Yr.strides[0], Ur.strides[0], Yr.shape[2], Ur.shape[2],
+                               bits, w, h, n, _ptr(an_r)) == 1, ref.lib.ref_last_error()
+    logof = b""
+    if logof_text:
+        p = tmp / f"lf_{bits}_{w}.txt"
+        p.write_bytes(logof_text)
+        logof = str(p).encode()
+    fades_r = np.zeros(n * 2, np.float32)
+    assert ref.lib.ref_erase(path, logof, 16, 0.35, _ptr(Yr), _ptr(Ur), _ptr(Vr), Yr.strides[0], Ur.strides[0], Yr.shape[2], Ur.shape[2],
+                             bits, w, h, n, _ptr(fades_r)) == 1, ref.lib.ref_last_error()
+    d, t, b = _oracle_logos(orc, lo)
+    Y, U, V = clip["Y"].copy(), clip["U"].copy(), clip["V"].copy()
+    an_o = np.zeros(n * 33, np.float32)
+    orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], bits, n, _ptr(an_o))
+    fr = np.zeros(n, np.int32)
+    if logof_text:
+        assert orc.lib.orc_read_logoframe(logof_text, n, _ptr(fr)) == 0
+    fades_o = np.zeros(n * 2, np.float32)
+    for i in range(n):
+        ft, fb = C.c_float(), C.c_float()
+        orc.lib.orc_calc_fade(_ptr(fr), 1 if logof_text else 0, 16, _ptr(an_o), n, i, C.byref(ft), C.byref(fb))
+        fades_o[2 * i], fades_o[2 * i + 1] = ft.value, fb.value
+        orc.lib.orc_erase_frame(lo, _ptr(Y[i]), _ptr(U[i]), _ptr(V[i]), Y.shape[2], U.shape[2], bits, ft.value, fb.value)
+    return (an_r, fades_r, Yr, Ur, Vr), (an_o, fades_o, Y, U, V)
+
+
+@pytest.mark.parametrize("bits", [10, 12])
+def test_analyze_erase_16bit_containers(env, bits):
+    orc, ref = env["orc"], env["ref"]
+    n = 27
+    clip = S.make_clip_np(n, W, H, 0x5EED0005, env["alpha"], env["alphaUV"], IMGX, IMGY, bits=bits, period=12, fade=5, flat_every=4)
+    assert clip["Y"].dtype == np.uint16 and int(clip["Y"].max()) > 255
+    r, o = _analyze_erase_both(orc, ref, env["lo"], env["path"], clip, W, H, bits, n)
+    assert r[0].tobytes() == o[0].tobytes()                 # 33 floats per frame
+    assert r[1].tobytes() == o[1].tobytes()                 # CalcFade / CalcFade2
+    assert np.array_equal(r[2], o[2]) and np.array_equal(r[3], o[3]) and np.array_equal(r[4], o[4])
+    assert not np.array_equal(o[2], clip["Y"]) and len(set(o[1].tolist())) > 2
+    # with a logoframe file on top (ReadLogoFrameFile, :1421-1461)
+    text = b"     6 S 0 ALL      4      8\n    11 E 0 ALL     10     12\n    24 S 0 ALL     23     25\n    26 E 0 ALL     26     26\n"
+    r, o = _analyze_erase_both(orc, ref, env["lo"], env["path"], clip, W, H, bits, n, text, env["tmp"])
+    assert r[1].tobytes() == o[1].tobytes()
+    assert np.array_equal(r[2], o[2]) and np.array_equal(r[3], o[3]) and np.array_equal(r[4], o[4])
+
+
+@pytest.mark.parametrize("bits", [10, 16])
+def test_logoframe_scan_16bit_arithmetic_through_the_pitch_quirk(env, bits):
+    """LogoFrame::ScanFrame<uint16_t> multiplies the BYTE pitch into a uint16_t pointer (LogoScan.hpp:1547,1561-1562):
+    it reads rectangle row y at frame row 2*(imgy+y).  The oracle (and the product) use the element pitch; called with a
+    doubled pitch the oracle addresses exactly what the reference does, which pins its 16-bit DeintY / EvaluateLogo / maxv
+    arithmetic to the reference's own (the corrected addressing itself is a documented divergence)."""
+    orc, ref = env["orc"], env["ref"]
+    assert (W * 2) % 64 == 0 and 2 * (IMGY + LH) <= H        # shim frame pitch == 2*W bytes; doubled rows stay inside the frame
+    n = 9
+    clip = S.make_clip_np(n, W, H, 0x5EED0003, env["alpha"], env["alphaUV"], IMGX, IMGY, bits=bits, period=4, fade=2)
+    Y = clip["Y"]
+    ev_r = np.zeros(n * 2, np.float32)
+    best, ratio = C.c_int(), C.c_float()
+    text = C.create_string_buffer(1 << 16)
+    ok = ref.lib.ref_logoframe((C.c_char_p * 1)(env["path"]), 1, 0.35, _ptr(Y), Y.strides[0], Y.shape[2], bits, W, H, n, 30000, 1001,
+                               _ptr(ev_r), -1, C.byref(best), C.byref(ratio), 0, str(env["tmp"] / "lf16.txt").encode(), text, len(text))
+    assert ok == 1, ref.lib.ref_last_error()
+    d = orc.lib.orc_logo_deint(env["lo"]); orc.lib.orc_logo_create_mask(d, 0.35, 1)
+    ev_o = np.zeros(n * 2, np.float32)
+    orc.lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], 2 * Y.shape[2], bits, W, H, n, _ptr(ev_o))
+    assert ev_r.tobytes() == ev_o.tobytes()
+    assert np.isfinite(ev_o).all() and len(set(ev_o.tolist())) > n
+
+
+HD_CASES = [  # (W, H, pitchY, pitchUV, bits, LW, LH, IMGX, IMGY, frames) -- BASELINE configs 2/4 (1440x1080 8-bit) and 5 (1920x1080 10-bit)
+    (1440, 1080, 1472, 768, 8, 256, 128, 1120, 64, 10),
+    (1920, 1080, 1920, 960, 10, 256, 128, 1600, 64, 6),
+]
+
+
+@pytest.mark.parametrize("case", HD_CASES, ids=["1440x1080_8bit", "1920x1080_10bit"])
+def test_hd_frames_scan_analyze_erase(env, case):
+    w, h, py, puv, bits, lw, lh, ix, iy, n = case
+    orc, ref = env["orc"], env["ref"]
+    data, alpha, alphaUV = S.make_logo(lw, lh)
+    lo = orc.make_logo(data, lw, lh, w, h, ix, iy)
+    path = str(env["tmp"] / f"hd_{w}.lgd").encode()
+    assert orc.lib.orc_logo_save(lo, path, b"hd", 1) == 1
+    clip = S.make_clip_np(n, w, h, 0x5EED0002, alpha, alphaUV, ix, iy, bits=bits, period=4, fade=3, flat_every=3, pitchY=py, pitchUV=puv)
+    r, o = _analyze_erase_both(orc, ref, lo, path, clip, w, h, bits, n)
+    assert r[0].tobytes() == o[0].tobytes()
+    assert r[1].tobytes() == o[1].tobytes()
+    assert np.array_equal(r[2], o[2]) and np.array_equal(r[3], o[3]) and np.array_equal(r[4], o[4])
+    if bits == 8:                                            # the all-frames scan (8-bit: no pitch quirk)
+        Y = clip["Y"]
+        ev_r = np.zeros(n * 2, np.float32)
+        best, ratio = C.c_int(), C.c_float()
+        text = C.create_string_buffer(1 << 16)
+        assert ref.lib.ref_logoframe((C.c_char_p * 1)(path), 1, 0.35, _ptr(Y), Y.strides[0], Y.shape[2], 8, w, h, n, 30000, 1001, _ptr(ev_r),
+                                     -1, C.byref(best), C.byref(ratio), 0, str(env["tmp"] / "lfhd.txt").encode(), text, len(text)) == 1
+        d = orc.lib.orc_logo_deint(lo); orc.lib.orc_logo_create_mask(d, 0.35, 1)
+        ev_o = np.zeros(n * 2, np.float32)
+        orc.lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], Y.shape[2], 8, w, h, n, _ptr(ev_o))
+        assert ev_r.tobytes() == ev_o.tobytes()

@@ -108,5 +108,87 @@ def main():
     print("wrote tests/golden/logo_path_v1.npz", os.path.getsize(os.path.join(ROOT, "tests", "golden", "logo_path_v1.npz")), "bytes")
 
 
+# ------------------------------------------------------------------------------------------------
+# v2: > 8-bit containers and HD frame sizes (BASELINE configs 2/4: 1440x1080 8-bit; config 5: 1920x1080 10-bit)
+# ------------------------------------------------------------------------------------------------
+V2_CASES = [
+    # name, W, H, bits, LW, LH, X, Y0, N, seed, period, fade, flat_every
+    ("sd10", 352, 240, 10, 96, 48, 224, 18, 24, 0x5EED0005, 12, 5, 4),
+    ("sd12", 352, 240, 12, 96, 48, 224, 18, 24, 0x5EED0006, 12, 5, 4),
+    ("hd8", 1440, 1080, 8, 256, 128, 1120, 64, 6, 0x5EED0002, 3, 2, 3),
+    ("fhd10", 1920, 1080, 10, 256, 128, 1600, 64, 4, 0x5EED0007, 2, 2, 3),
+]
+V2_LOGOF = b"     6 S 0 ALL      4      8\n    11 E 0 ALL     10     12\n    20 S 0 ALL     19     21\n    23 E 0 ALL     23     23\n"
+
+
+def crops_of(clip, X, Y0, LW, LH):
+    return (clip["Y"][:, Y0:Y0 + LH, X:X + LW].copy(), clip["U"][:, Y0 // 2:Y0 // 2 + LH // 2, X // 2:X // 2 + LW // 2].copy(),
+            clip["V"][:, Y0 // 2:Y0 // 2 + LH // 2, X // 2:X // 2 + LW // 2].copy())
+
+
+def frames_of(cy, cu, cv, W, H, X, Y0):
+    n, LH, LW = cy.shape
+    Y = np.zeros((n, H, W), cy.dtype); U = np.zeros((n, H // 2, W // 2), cy.dtype); V = np.zeros_like(U)
+    Y[:, Y0:Y0 + LH, X:X + LW] = cy
+    U[:, Y0 // 2:Y0 // 2 + LH // 2, X // 2:X // 2 + LW // 2] = cu
+    V[:, Y0 // 2:Y0 // 2 + LH // 2, X // 2:X // 2 + LW // 2] = cv
+    return Y, U, V
+
+
+def main_v2():
+    assert Ref.available(), "build oracle/_ref first (oracle/build_ref.sh)"
+    ref, orc = Ref(), Oracle()
+    tmp = "/tmp/amt_golden"
+    os.makedirs(tmp, exist_ok=True)
+    out = {"cases": np.array([c[0] for c in V2_CASES]), "logof_text": np.frombuffer(V2_LOGOF, np.uint8)}
+    for name, W, H, bits, LW, LH, X, Y0, N, seed, period, fade, flat in V2_CASES:
+        data, alpha, alphaUV = S.make_logo(LW, LH)
+        lo = orc.make_logo(data, LW, LH, W, H, X, Y0)
+        path = os.path.join(tmp, f"{name}.lgd").encode()
+        assert orc.lib.orc_logo_save(lo, path, b"golden", 1041) == 1
+        clip = S.make_clip_np(N, W, H, seed, alpha, alphaUV, X, Y0, bits=bits, period=period, fade=fade, flat_every=flat)
+        cy, cu, cv = crops_of(clip, X, Y0, LW, LH)
+        Y, U, V = frames_of(cy, cu, cv, W, H, X, Y0)
+        out[f"{name}_geom"] = np.array([W, H, bits, LW, LH, X, Y0, N], np.int32)
+        out[f"{name}_logo"] = data
+        out[f"{name}_crop_y"], out[f"{name}_crop_u"], out[f"{name}_crop_v"] = cy, cu, cv
+        an = np.zeros(N * 33, np.float32)
+        assert ref.lib.ref_analyze(path, 0.35, _ptr(Y), _ptr(U), _ptr(V), Y.strides[0], U.strides[0], W, W // 2, bits, W, H, N, _ptr(an)) == 1
+        out[f"{name}_analysis"] = an.reshape(N, 33)
+        tags = (("nolf", b""), ("lf", os.path.join(tmp, "lf2_in.txt").encode())) if N >= 24 else (("nolf", b""),)
+        open(os.path.join(tmp, "lf2_in.txt"), "wb").write(V2_LOGOF)
+        for tag, lf in tags:
+            Ye, Ue, Ve = Y.copy(), U.copy(), V.copy()
+            fades = np.zeros(N * 2, np.float32)
+            assert ref.lib.ref_erase(path, lf, 16, 0.35, _ptr(Ye), _ptr(Ue), _ptr(Ve), Ye.strides[0], Ue.strides[0], W, W // 2, bits, W, H, N,
+                                     _ptr(fades)) == 1, ref.lib.ref_last_error()
+            out[f"{name}_erase_{tag}_fades"] = fades.reshape(N, 2)
+            ey, eu, ev_ = crops_of({"Y": Ye, "U": Ue, "V": Ve}, X, Y0, LW, LH)
+            out[f"{name}_erase_{tag}_Y"], out[f"{name}_erase_{tag}_U"], out[f"{name}_erase_{tag}_V"] = ey, eu, ev_
+        best, ratio = C.c_int(), C.c_float()
+        text = C.create_string_buffer(1 << 16)
+        if bits == 8:
+            ev = np.zeros(N * 2, np.float32)
+            assert ref.lib.ref_logoframe((C.c_char_p * 1)(path), 1, 0.35, _ptr(Y), Y.strides[0], W, 8, W, H, N, 30000, 1001, _ptr(ev), -1,
+                                         C.byref(best), C.byref(ratio), 0, os.path.join(tmp, "lf2.txt").encode(), text, len(text)) == 1
+            out[f"{name}_logoframe_evals"] = ev.reshape(N, 1, 2)
+        elif 2 * (Y0 + LH) <= H and (W * 2) % 64 == 0:
+            # LogoFrame::ScanFrame<uint16_t> uses the BYTE pitch as element stride (LogoScan.hpp:1547,1561): it reads rectangle
+            # row y at frame row 2*(Y0+y).  Stored with the band of rows it touches; consumers pass a doubled pitch.
+            band = clip["Y"][:, 2 * Y0:2 * (Y0 + LH), X:X + LW].copy()
+            Yq = np.zeros((N, H, W), np.uint16)
+            Yq[:, 2 * Y0:2 * (Y0 + LH), X:X + LW] = band
+            ev = np.zeros(N * 2, np.float32)
+            assert ref.lib.ref_logoframe((C.c_char_p * 1)(path), 1, 0.35, _ptr(Yq), Yq.strides[0], W, bits, W, H, N, 30000, 1001, _ptr(ev), -1,
+                                         C.byref(best), C.byref(ratio), 0, os.path.join(tmp, "lf2.txt").encode(), text, len(text)) == 1
+            out[f"{name}_quirk_band"] = band
+            out[f"{name}_logoframe_evals_bytepitch"] = ev.reshape(N, 1, 2)
+    dst = os.path.join(ROOT, "tests", "golden", "logo_path_v2_hibit_hd.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--v2-only" not in sys.argv:
+        main()
+    main_v2()
