@@ -41,8 +41,12 @@ class Context:
             raise AmtError(f"amtgpu_context_create({device}) failed: no usable HIP device")
         self.device = device
         if use_torch_stream:
+            # Launch on torch's current stream so that kernels are stream-ordered with torch fills / copies / reads of the
+            # same tensors.  torch's default stream is the legacy null stream (handle 0), which the ABI spells
+            # AMTGPU_STREAM_LEGACY_DEFAULT (NULL would select the context's own non-blocking stream).
             import torch
-            self.lib.amtgpu_context_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+            hs = int(torch.cuda.current_stream(device).cuda_stream)
+            self.lib.amtgpu_context_set_stream(self.h, C.c_void_p(hs if hs else 1))
 
     def check(self, ok, what=""):
         if not ok:

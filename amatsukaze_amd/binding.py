@@ -13,6 +13,14 @@ LIB_PATH = os.environ.get("AMTGPU_LIB") or os.path.join(HERE, "libamt_gpu.so")  
 c_i, c_f, c_p, c_s = C.c_int, C.c_float, C.c_void_p, C.c_char_p
 c_i64, c_u64 = C.c_int64, C.c_uint64
 CB = C.CFUNCTYPE(c_i, c_f, c_i, c_i, c_i)
+ALLGATHER_CB = C.CFUNCTYPE(c_i, c_p, c_p, c_p, c_i64)            # (user, send, recv, bytes)
+ALLREDUCE_CB = C.CFUNCTYPE(c_i, c_p, c_p, c_i64)                 # (user, buf int64*, count)
+
+
+class Collectives(C.Structure):
+    """AmtGpuCollectives (include/amt_gpu.h)"""
+    _fields_ = [("rank", c_i), ("world", c_i), ("allgather", ALLGATHER_CB), ("allreduce_sum_i64", ALLREDUCE_CB), ("user", c_p)]
+
 
 # name -> (restype, argtypes); mirrors include/amt_gpu.h one to one
 SIGNATURES = {
@@ -28,6 +36,7 @@ SIGNATURES = {
     "amtgpu_device_alloc": (c_p, [c_p, c_u64]),
     "amtgpu_device_free": (None, [c_p, c_p]),
     "amtgpu_frames_upload": (c_i, [c_p, c_p, c_p, c_u64]),
+    "amtgpu_frames_upload_strided": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_u64, c_i]),
     "amtgpu_frames_upload_wait": (c_i, [c_p]),
     "amtgpu_download": (c_i, [c_p, c_p, c_p, c_u64]),
     "amtgpu_weave_fields_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
@@ -68,6 +77,8 @@ SIGNATURES = {
     "amtgpu_logoscan_set_sums": (c_i, [c_p, c_p, c_p, c_i]),
     "amtgpu_logoscan_get_logo": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i, c_i]),
     "amtgpu_scanlogo": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
+    "amtgpu_logoframe_allgather_results": (c_i, [c_p, c_p, c_i, c_i]),
+    "amtgpu_scanlogo_sharded": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
     "amtgpu_framestats_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
     "amtgpu_framestats_destroy": (None, [c_p]),
     "amtgpu_framestats_batch": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_i, c_p]),

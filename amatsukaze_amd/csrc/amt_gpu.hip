@@ -57,7 +57,9 @@ const char* amtgpu_last_error(const AmtGpuContext* c) { return c ? c->err.c_str(
 int amtgpu_context_set_stream(AmtGpuContext* c, void* s)
 {
     if (!c) return 0;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (s == AMTGPU_STREAM_LEGACY_DEFAULT) c->stream = nullptr;          // HIP's legacy default ("null") stream
+    else c->stream = s ? (hipStream_t)s : c->own_stream;
     return 1;
 }
 void* amtgpu_context_get_stream(AmtGpuContext* c) { return c ? (void*)c->stream : nullptr; }
@@ -132,6 +134,40 @@ int amtgpu_frames_upload(AmtGpuContext* c, void* ddst, const void* hsrc, uint64_
             AMT_HIP(hipEventRecord(c->slot_free[s], c->copy_stream));
             c->next_slot ^= 1;
             done += n;
+        }
+        AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
+        c->copies_pending = true;
+    });
+}
+
+// the same ring for `nchunks` equally sized pieces that sit `dst_stride` apart on the device (e.g. the logo rectangle's rows of
+// every frame of a batch: the logo passes read nothing else of a frame): pieces are packed into the pinned slot and leave
+// as ONE 2-D copy per slot
+int amtgpu_frames_upload_strided(AmtGpuContext* c, void* ddst, int64_t dst_stride, const void* hsrc, int64_t src_stride,
+                                 uint64_t chunk_bytes, int nchunks)
+{
+    return guard(c, [&] {
+        c->bind();
+        const size_t slot_bytes = 32u << 20;
+        if (chunk_bytes == 0 || nchunks <= 0) return;
+        if (chunk_bytes > slot_bytes) throw std::runtime_error("chunk larger than a staging slot");
+        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
+        if (!c->pinned) {
+            AMT_HIP(hipHostMalloc(&c->pinned, slot_bytes * 2, hipHostMallocDefault));
+            c->pinned_bytes = slot_bytes;
+        }
+        const int per_slot = (int)(slot_bytes / chunk_bytes);
+        for (int i0 = 0; i0 < nchunks; i0 += per_slot) {
+            const int n = std::min(per_slot, nchunks - i0);
+            const int s = c->next_slot;
+            AMT_HIP(hipEventSynchronize(c->slot_free[s]));
+            uint8_t* stage = (uint8_t*)c->pinned + (size_t)s * slot_bytes;
+            for (int i = 0; i < n; ++i)
+                std::memcpy(stage + (size_t)i * chunk_bytes, (const uint8_t*)hsrc + (size_t)(i0 + i) * src_stride, chunk_bytes);
+            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
+                                     hipMemcpyHostToDevice, c->copy_stream));
+            AMT_HIP(hipEventRecord(c->slot_free[s], c->copy_stream));
+            c->next_slot ^= 1;
         }
         AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
         c->copies_pending = true;
@@ -293,7 +329,8 @@ int amtgpu_logoframe_begin(AmtGpuLogoFrame* lf, int width, int height, int bits,
             specs.push_back(std::move(S));
             lf->slotOfEngineLogo.push_back(i);
         }
-        lf->engine.reset(specs.empty() ? nullptr : new EvalEngine(lf->ctx, std::move(specs), {0.0f, 1.0f}, false, nl * 2));
+        lf->engine.reset(specs.empty() ? nullptr : new EvalEngine(lf->ctx, std::move(specs), {0.0f, 1.0f}, false, nl * 2,
+                                                                        "logo_eval_fused_kernel.scan"));
         // invalid / mismatching logos keep {corr0, corr1} = {0, -1}
         lf->results.assign((size_t)num_frames * nl * 2, 0.0f);
         for (size_t i = 0; i < (size_t)num_frames * nl; ++i) lf->results[i * 2 + 1] = -1.0f;
@@ -348,6 +385,36 @@ int amtgpu_logoframe_set_results(AmtGpuLogoFrame* lf, int first, int nframes, co
         if (nframes)
             AMT_HIP(hipMemcpyAsync(lf->dResults.get() + (size_t)first * nl * 2, evals, (size_t)nframes * nl * 2 * sizeof(float),
                                    hipMemcpyHostToDevice, lf->ctx->stream));
+        AMT_HIP(hipStreamSynchronize(lf->ctx->stream));
+        lf->selected = false;
+    });
+}
+
+int amtgpu_logoframe_allgather_results(AmtGpuLogoFrame* lf, const AmtGpuCollectives* coll, int first, int nlocal)
+{
+    return guard(lf->ctx, [&] {
+        if (first < 0 || nlocal < 0 || first + nlocal > lf->numFrames) throw std::runtime_error("frame range outside the clip");
+        if (!coll || coll->world <= 1) return;
+        if (!coll->allgather) throw std::runtime_error("AmtGpuCollectives incomplete");
+        logoframe_sync_results(lf);
+        const size_t rec = lf->logos.size() * 2;                               // floats per frame
+        // ragged shards: gather {first, nlocal}, then records padded to the largest shard
+        const int64_t mine[2] = {first, nlocal};
+        std::vector<int64_t> ranges((size_t)coll->world * 2);
+        if (!coll->allgather(coll->user, mine, ranges.data(), sizeof mine)) throw std::runtime_error("allgather failed");
+        int64_t nmax = 0;
+        for (int r = 0; r < coll->world; ++r) nmax = std::max(nmax, ranges[2 * r + 1]);
+        if (nmax == 0 || rec == 0) return;
+        std::vector<float> send((size_t)nmax * rec, 0.0f), recv((size_t)nmax * rec * coll->world);
+        std::memcpy(send.data(), lf->results.data() + (size_t)first * rec, (size_t)nlocal * rec * sizeof(float));
+        if (!coll->allgather(coll->user, send.data(), recv.data(), (int64_t)(send.size() * sizeof(float)))) throw std::runtime_error("allgather failed");
+        for (int r = 0; r < coll->world; ++r) {
+            const int64_t f = ranges[2 * r], n = ranges[2 * r + 1];
+            if (f < 0 || n < 0 || f + n > lf->numFrames) throw std::runtime_error("a rank reported a frame range outside the clip");
+            std::memcpy(lf->results.data() + (size_t)f * rec, recv.data() + (size_t)r * nmax * rec, (size_t)n * rec * sizeof(float));
+        }
+        lf->ctx->bind();
+        AMT_HIP(hipMemcpyAsync(lf->dResults.get(), lf->results.data(), lf->results.size() * sizeof(float), hipMemcpyHostToDevice, lf->ctx->stream));
         AMT_HIP(hipStreamSynchronize(lf->ctx->stream));
         lf->selected = false;
     });
@@ -411,7 +478,7 @@ static AmtGpuAnalyze* analyze_new(AmtGpuContext* c, LogoPlanes logo, float maskr
     }
     std::vector<float> fades(AMTGPU_NUM_FADE);
     for (int f = 0; f < AMTGPU_NUM_FADE; ++f) fades[f] = (float)f / 10.0f;
-    an->engine.reset(new EvalEngine(c, std::move(specs), fades, true, AMTGPU_ANALYZE_FLOATS));
+    an->engine.reset(new EvalEngine(c, std::move(specs), fades, true, AMTGPU_ANALYZE_FLOATS, "logo_eval_fused_kernel.analysis"));
     return an.release();
 }
 

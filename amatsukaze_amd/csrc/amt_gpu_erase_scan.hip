@@ -115,6 +115,7 @@ int amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t st
         if (nframes <= 0) return;
         const LogoPlanes& P = er->logo;
         const int es = bits <= 8 ? 1 : 2;
+        if (strideY % es || strideUV % es) throw std::runtime_error("frame stride not a multiple of the sample size");
         er->ctx->bind();
         if (er->dFades.size() < (size_t)nframes) er->dFades.alloc(nframes);
         AMT_HIP(hipMemcpyAsync(er->dFades.get(), fades, (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
@@ -163,6 +164,7 @@ static int logoscan_add(AmtGpuLogoScan* s, const void* dY, const void* dU, const
 {
     if (bits < 8 || bits > 12) throw std::runtime_error("[LogoScan] 8..12 bit only");
     const int es = bits <= 8 ? 1 : 2;
+    if (strideY % es || strideUV % es) throw std::runtime_error("frame stride not a multiple of the sample size");
     ScanSums& S = s->sums;
     const int wUV = S.w >> S.logUVx, hUV = S.h >> S.logUVy;
     const int cx = imgx >> S.logUVx, cy = imgy >> S.logUVy;
@@ -283,30 +285,88 @@ AmtGpuLogo* amtgpu_logoscan_get_logo(AmtGpuLogoScan* s, int maxv, int clean, int
 // LogoAnalyzer::ScanLogo (LogoScan.hpp:1058-1079): initial logo from every flat-bordered frame (stop at
 // numMaxFrames), then twice: evaluate 20 fades per kept frame, re-accumulate only frames whose best fade
 // index is > 8, regress again with clean-up; save.
-int amtgpu_scanlogo(AmtGpuContext* c, const void* dY, const void* dU, const void* dV, int64_t strideY, int64_t strideUV,
-                    int pitchY, int pitchUV, int imgw, int imgh, int nframes, int serviceid, const char* dstpath, int imgx,
-                    int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb)
+//
+// coll != nullptr: this rank holds one contiguous shard of the stream.  What is global in the reference's three
+// sequential rounds is (a) which valid frames fall inside the numMaxFrames quota ("first N in stream order", :885) and
+// (b) the accumulators each regression reads -- both integers, so an all-gather of valid counts and an all-reduce of
+// int64 sums reproduce the single-GPU result exactly; the regression then runs redundantly on every rank.
+} // extern "C" (helpers)
+
+namespace {
+
+// sums of all ranks -> every rank (px sums, plane sums, frame count, and a cancel flag riding along)
+void reduce_scan(AmtGpuLogoScan* s, const AmtGpuCollectives* coll, int64_t& cancel)
+{
+    if (!coll || coll->world <= 1) return;
+    logoscan_pull(s);
+    std::vector<int64_t> buf(s->sums.px.begin(), s->sums.px.end());
+    for (int k = 0; k < 6; ++k) buf.push_back(s->sums.plane[k]);
+    buf.push_back(s->sums.nframes);
+    buf.push_back(cancel);
+    if (!coll->allreduce_sum_i64(coll->user, buf.data(), (int64_t)buf.size())) throw std::runtime_error("allreduce_sum_i64 failed");
+    const size_t npx = s->sums.px.size();
+    cancel = buf[npx + 7];
+    if (!amtgpu_logoscan_set_sums(s, buf.data(), buf.data() + npx, (int)buf[npx + 6])) throw std::runtime_error(s->ctx->err);
+}
+
+int scanlogo_impl(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* dY, const void* dU, const void* dV, int64_t strideY,
+                  int64_t strideUV, int pitchY, int pitchUV, int imgw, int imgh, int nframes, int serviceid, const char* dstpath,
+                  int imgx, int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb)
 {
     return guard(c, [&] {
+        const bool sharded = coll && coll->world > 1;
+        if (sharded && (!coll->allgather || !coll->allreduce_sum_i64 || coll->rank < 0 || coll->rank >= coll->world))
+            throw std::runtime_error("AmtGpuCollectives incomplete");
+        int64_t cancel = 0;
         auto progress = [&](float p, int nread, int total, int ngather) {
-            if (cb && !cb(p, nread, total, ngather)) throw std::runtime_error("Cancel requested");
+            if (cb && !cb(p, nread, total, ngather)) {
+                if (!sharded) throw std::runtime_error("Cancel requested");
+                cancel = 1;                                     // the other ranks learn about it with the next reduction
+            }
         };
         if (imgx < 0 || imgy < 0 || imgx + w > imgw || imgy + h > imgh) throw std::runtime_error("scan rectangle outside the frame");
         const int bits = 8;                                   // the reference's scan path is 8-bit only (:813)
         std::unique_ptr<AmtGpuLogoScan> scan(logoscan_new(c, w, h, 1, 1, thy));
-        // round 0: every frame in stream order until numMaxFrames are kept
-        std::vector<int> kept;              // frame index of every kept frame
+        std::vector<int> kept;              // frame index (within this rank's frames) of every kept frame
         std::vector<int4> keptVerdict;      // its {1,bgY,bgU,bgV}
         const int chunk = 4096;
-        for (int f0 = 0; f0 < nframes && (int)kept.size() < numMaxFrames; f0 += chunk) {
-            const int n = std::min(chunk, nframes - f0);
-            std::vector<uint8_t> valid(n);
-            logoscan_add(scan.get(), (const uint8_t*)dY + f0 * strideY, (const uint8_t*)dU + f0 * strideUV, (const uint8_t*)dV + f0 * strideUV,
-                         strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, n, numMaxFrames - (int)kept.size(), nullptr, valid.data(),
-                         nullptr, nullptr);
-            for (int i = 0; i < n; ++i)
-                if (valid[i]) { kept.push_back(f0 + i); keptVerdict.push_back(scan->lastVerdicts[i]); }
-            progress(50.0f * (f0 + n) / std::max(1, nframes), f0 + n, 0, (int)kept.size());
+        auto at = [&](const void* base, int64_t stride, int f0) { return (const void*)((const uint8_t*)base + (int64_t)f0 * stride); };
+        if (!sharded) {
+            // round 0: every frame in stream order until numMaxFrames are kept
+            for (int f0 = 0; f0 < nframes && (int)kept.size() < numMaxFrames; f0 += chunk) {
+                const int n = std::min(chunk, nframes - f0);
+                std::vector<uint8_t> valid(n);
+                logoscan_add(scan.get(), at(dY, strideY, f0), at(dU, strideUV, f0), at(dV, strideUV, f0), strideY, strideUV, pitchY, pitchUV,
+                             bits, imgx, imgy, n, numMaxFrames - (int)kept.size(), nullptr, valid.data(), nullptr, nullptr);
+                for (int i = 0; i < n; ++i)
+                    if (valid[i]) { kept.push_back(f0 + i); keptVerdict.push_back(scan->lastVerdicts[i]); }
+                progress(50.0f * (f0 + n) / std::max(1, nframes), f0 + n, 0, (int)kept.size());
+            }
+        } else {
+            // round 0, sharded: border verdicts of every local frame (nothing accepted yet: max_valid = 0) ...
+            for (int f0 = 0; f0 < nframes; f0 += chunk) {
+                const int n = std::min(chunk, nframes - f0);
+                logoscan_add(scan.get(), at(dY, strideY, f0), at(dU, strideUV, f0), at(dV, strideUV, f0), strideY, strideUV, pitchY, pitchUV,
+                             bits, imgx, imgy, n, 0, nullptr, nullptr, nullptr, nullptr);
+                for (int i = 0; i < n; ++i)
+                    if (scan->lastVerdicts[i].x) { kept.push_back(f0 + i); keptVerdict.push_back(scan->lastVerdicts[i]); }
+                progress(50.0f * (f0 + n) / std::max(1, nframes), f0 + n, 0, (int)kept.size());
+            }
+            // ... this rank's share of "the first numMaxFrames valid frames of the stream" ...
+            std::vector<int64_t> counts(coll->world, 0);
+            const int64_t mine = (int64_t)kept.size();
+            if (!coll->allgather(coll->user, &mine, counts.data(), sizeof(int64_t))) throw std::runtime_error("allgather failed");
+            int64_t before = 0;
+            for (int r = 0; r < coll->rank; ++r) before += counts[r];
+            const int quota = (int)std::max<int64_t>(0, std::min<int64_t>(mine, (int64_t)numMaxFrames - before));
+            kept.resize(quota);
+            keptVerdict.resize(quota);
+            // ... accumulated locally, summed over ranks
+            if (quota)
+                logoscan_add(scan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, quota, quota, nullptr, nullptr,
+                             kept.data(), keptVerdict.data());
+            reduce_scan(scan.get(), coll, cancel);
+            if (cancel) throw std::runtime_error("Cancel requested");
         }
         const int numFrames = (int)kept.size();
         std::unique_ptr<AmtGpuLogo> logo(amtgpu_logoscan_get_logo(scan.get(), 255, 0, imgw, imgh, imgx, imgy));
@@ -325,7 +385,7 @@ int amtgpu_scanlogo(AmtGpuContext* c, const void* dY, const void* dU, const void
             S.imgx = imgx; S.imgy = imgy; S.row0 = 0; S.row_step = 1; S.deint = 1; S.out_off = 0;
             std::vector<EvalLogoSpec> specs;
             specs.push_back(std::move(S));
-            EvalEngine eng(c, std::move(specs), fades, true, 20);
+            EvalEngine eng(c, std::move(specs), fades, true, 20, "logo_eval_fused_kernel.remake");
             std::vector<uint8_t> use(numFrames, 0);
             if (numFrames) {
                 eng.run(dY, strideY, pitchY, bits, numFrames, dEval.get(), dMap.get());
@@ -344,12 +404,35 @@ int amtgpu_scanlogo(AmtGpuContext* c, const void* dY, const void* dU, const void
             if (numFrames)
                 logoscan_add(rescan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, numFrames, numFrames,
                              use.data(), nullptr, kept.data(), keptVerdict.data());
+            reduce_scan(rescan.get(), coll, cancel);
+            if (cancel) throw std::runtime_error("Cancel requested");
             logo.reset(amtgpu_logoscan_get_logo(rescan.get(), 255, 1, imgw, imgh, imgx, imgy));
             if (!logo) throw std::runtime_error(c->err);
         }
         progress(1, numFrames, numFrames, numFrames);
-        save_lgd(logo->planes, dstpath, "No Name", serviceid);
+        if (dstpath && (!sharded || coll->rank == 0)) save_lgd(logo->planes, dstpath, "No Name", serviceid);
     });
+}
+
+} // namespace
+
+extern "C" {
+
+int amtgpu_scanlogo(AmtGpuContext* c, const void* dY, const void* dU, const void* dV, int64_t strideY, int64_t strideUV,
+                    int pitchY, int pitchUV, int imgw, int imgh, int nframes, int serviceid, const char* dstpath, int imgx,
+                    int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb)
+{
+    return scanlogo_impl(c, nullptr, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, imgw, imgh, nframes, serviceid, dstpath, imgx, imgy,
+                         w, h, thy, numMaxFrames, cb);
+}
+
+int amtgpu_scanlogo_sharded(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* dY, const void* dU, const void* dV,
+                            int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int imgw, int imgh, int nframes_local,
+                            int serviceid, const char* dstpath, int imgx, int imgy, int w, int h, int thy, int numMaxFrames,
+                            AMTGPU_LOGO_ANALYZE_CB cb)
+{
+    return scanlogo_impl(c, coll, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, imgw, imgh, nframes_local, serviceid, dstpath, imgx,
+                         imgy, w, h, thy, numMaxFrames, cb);
 }
 
 } // extern "C"

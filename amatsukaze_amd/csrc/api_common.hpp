@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <exception>
+#include <mutex>
 #include <string>
 
 #include "decisions.hpp"
@@ -16,6 +17,9 @@ struct AmtGpuLogo {
 // run f(); on any exception keep the message on the context and return 0 (no exceptions cross the ABI)
 template <typename F> inline int guard(AmtGpuContext* c, F&& f)
 {
+    // calls on one context are serialised: its stream, staging ring, error string and timing spans are shared state
+    std::unique_lock<std::recursive_mutex> lk;
+    if (c) lk = std::unique_lock<std::recursive_mutex>(c->mu);
     try {
         f();
         return 1;

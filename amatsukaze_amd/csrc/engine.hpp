@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -30,6 +31,9 @@ struct AmtGpuContext {
     hipEvent_t slot_free[2] = {nullptr, nullptr};
     int next_slot = 0;
     std::string err;
+    // One context may be shared by several filter instances whose GetFrame runs on different AviSynth threads
+    // (MT_NICE_FILTER): the staging ring, the error string and the timing spans are guarded by this lock.
+    std::recursive_mutex mu;
 
     // optional per-kernel timing with HIP events on the launch stream (amtgpu_profile_*)
     struct ProfSpan { int name; hipEvent_t a, b; };
@@ -83,7 +87,9 @@ struct EvalLogoSpec {
 // out[frame*out_frame_stride + spec.out_off + f] = (|.|) CorrelationScore / blackScore.
 class EvalEngine {
 public:
-    EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std::vector<float> fades, bool take_abs, int out_frame_stride);
+    // prof_name: label of this engine's launches in amtgpu_profile_report (no spaces)
+    EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std::vector<float> fades, bool take_abs, int out_frame_stride,
+               const char* prof_name = "logo_eval_fused_kernel");
     // async on ctx->stream; dout device, nframes*out_frame_stride floats
     // dframe_map (device, optional): batch frame i reads source frame dframe_map[i] of dY
     void run(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout,
@@ -99,6 +105,7 @@ private:
     std::vector<float> fades_;
     bool take_abs_;
     int out_frame_stride_;
+    std::string prof_name_;
     int plane_cap_ = 0;
     int group_frames_ = 0;   // frames per workgroup (0 = pick per batch; AMTGPU_G overrides)
     std::vector<EvalBand> bands_;

@@ -155,16 +155,19 @@ __device__ void border_plane(const pix_t* __restrict__ p, int pitch, int w, int 
     const int tid = threadIdx.x;
     for (int i = tid; i < nbins; i += kBorderThreads) hist[i] = 0;
     __syncthreads();
+    // samples above the declared depth (a 10-bit clip in uint16 containers is not guaranteed to stay below 1 << bits) are
+    // counted in the top bin instead of indexing past the histogram
+    const int top = nbins - 1;
     for (int x = tid; x < w; x += kBorderThreads) {
-        atomicAdd(&hist[p[x]], 1);
-        atomicAdd(&hist[p[x + (long long)(h - 1) * pitch]], 1);
+        atomicAdd(&hist[min((int)p[x], top)], 1);
+        atomicAdd(&hist[min((int)p[x + (long long)(h - 1) * pitch], top)], 1);
     }
     for (int y = 1 + tid; y < h - 1; y += kBorderThreads) {
-        atomicAdd(&hist[p[(long long)y * pitch]], 1);
-        atomicAdd(&hist[p[w - 1 + (long long)y * pitch]], 1);
+        atomicAdd(&hist[min((int)p[(long long)y * pitch], top)], 1);
+        atomicAdd(&hist[min((int)p[w - 1 + (long long)y * pitch], top)], 1);
     }
     __syncthreads();
-    const int n = 2 * w + 2 * (h - 2);
+    const int n = 2 * w + 2 * max(0, h - 2);     // a one-row plane (chroma of a 2-row rectangle) pushes its row twice (:616-635)
     const int lo = n / 4, hi = n - n / 4;
     // each thread owns nbins/256 consecutive bins; exclusive prefix of the per-thread counts through LDS
     const int per = (nbins + kBorderThreads - 1) / kBorderThreads;

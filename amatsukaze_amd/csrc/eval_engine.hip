@@ -55,11 +55,14 @@ int lds_pitch(int w) { return ((w + 31) & ~31) + 8; }
 }
 
 EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std::vector<float> fades, bool take_abs,
-                       int out_frame_stride)
-    : ctx_(ctx), specs_(std::move(specs)), fades_(std::move(fades)), take_abs_(take_abs), out_frame_stride_(out_frame_stride)
+                       int out_frame_stride, const char* prof_name)
+    : ctx_(ctx), specs_(std::move(specs)), fades_(std::move(fades)), take_abs_(take_abs), out_frame_stride_(out_frame_stride),
+      prof_name_(prof_name)
 {
     ctx_->bind();
-    if (const char* e = std::getenv("AMTGPU_G")) group_frames_ = std::atoi(e);       // experiments
+#ifdef AMT_EXPERIMENT
+    if (const char* e = std::getenv("AMTGPU_G")) group_frames_ = std::atoi(e);       // instrumented builds only
+#endif
     constexpr int kPlaneCapMax = kEvalThreads * kEvalStage;                            // floats per LDS plane
     const int nl = (int)specs_.size();
     std::vector<EvalLogoDev> hl(nl);
@@ -144,12 +147,14 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         D.out_off = S.out_off;
         D.lp = lp;
     }
+#ifdef AMT_EXPERIMENT
     if (std::getenv("AMTGPU_VERBOSE")) {
         for (int i = 0; i < nl; ++i)
             fprintf(stderr, "[amtgpu] eval logo %d: %dx%d count=%d bands=%d lp=%d\n", i, hl[i].w, hl[i].h, hl[i].count, hl[i].nbands, hl[i].lp);
         for (const EvalBand& B : bands_)
             fprintf(stderr, "[amtgpu]   band logo=%d slots=%d npix=%d y0=%d nrows=%d\n", B.logo, B.nslots, B.npix, B.y0, B.nrows);
     }
+#endif
     d_logos_.upload(hl, ctx_->stream);
     d_bands_.upload(bands_, ctx_->stream);
     d_fades_.upload(fades_, ctx_->stream);
@@ -176,7 +181,7 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
     for (int f0 = 0; f0 < nf_all; f0 += kEvalMaxFades) {
         const int nf = std::min(kEvalMaxFades, nf_all - f0);
         G = std::max(1, std::min(G, kEvalThreads / nf));
-        const int sp = ctx_->prof_begin("logo_eval_fused_kernel");
+        const int sp = ctx_->prof_begin(prof_name_.c_str());
         AMT_HIP(launch_logo_eval_fused(ctx_->stream, bits, d_logos_.get(), nl, d_bands_.get(), d_fades_.get(), nf, f0, dY, dframe_map,
                                        frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0,
                                        plane_cap_));

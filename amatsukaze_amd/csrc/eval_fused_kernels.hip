@@ -146,8 +146,14 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                           const float* __restrict__ fades, int nfades, int fade0,
                           const pix_t* __restrict__ Y, const int* __restrict__ frame_map, long long frame_stride, int pitch,
                           float maxv, int nframes, int G, int ngroups, float* __restrict__ out, int out_frame_stride,
-                          int take_abs, int plane_cap, int sc_pitch, int dbg)
+                          int take_abs, int plane_cap, int sc_pitch, int dbg_in)
 {
+#ifdef AMT_EXPERIMENT
+    const int dbg = dbg_in;      // timing ablations of instrumented builds only (amatsukaze_amd/build.py build_variant)
+#else
+    constexpr int dbg = 0;
+    (void)dbg_in;
+#endif
     extern __shared__ float lds[];
     float* const planes = lds;                       // [FPI][S: source pixels | BG: a*s + b*maxv][plane_cap]  the band's rows
     float* const sc = lds + 2 * FPI * plane_cap;     // [FPI][nfades][sc_pitch]  per-pixel terms of the current (band, frames)
@@ -440,16 +446,21 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
 {
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
     if (nfades > kEvalMaxFades || G * nfades > kEvalThreads || plane_cap > kEvalThreads * kEvalStage) return hipErrorInvalidValue;
-    // timing experiments only (tools/gpu_try2.sh): AMTGPU_DBG bit 0 skips the sum, 1 the staging, 2 the fade loop,
-    // AMTGPU_LDSPAD inflates the LDS request to lower the occupancy
+    // Instrumented builds only (-DAMT_EXPERIMENT, build.py build_variant): AMTGPU_DBG bit 0 skips the sum, 1 the staging,
+    // 2 the fade loop (timing ablations, WRONG results); AMTGPU_LDSPAD inflates the LDS request to lower the occupancy;
+    // AMTGPU_FPI=1 forces one frame per iteration.  The release library reads no environment variable here.
+#ifdef AMT_EXPERIMENT
     static const int dbg = std::getenv("AMTGPU_DBG") ? std::atoi(std::getenv("AMTGPU_DBG")) : 0;
     static const int ldspad = std::getenv("AMTGPU_LDSPAD") ? std::atoi(std::getenv("AMTGPU_LDSPAD")) : 0;
+    static const int fpi_env = std::getenv("AMTGPU_FPI") ? std::atoi(std::getenv("AMTGPU_FPI")) : 0;
+#else
+    constexpr int dbg = 0, ldspad = 0, fpi_env = 0;
+#endif
     const int ngroups = (nframes + G - 1) / G;
     const float maxv = (float)((1 << bits) - 1);
     const int sc_pitch = kEvalBandPixels + kEvalScorePad;
     dim3 grid((unsigned)((long long)ngroups * nlogos));
     // two frames per iteration while the planes and score rows of both fit half a CU's LDS (two workgroups per CU)
-    const int fpi_env = std::getenv("AMTGPU_FPI") ? std::atoi(std::getenv("AMTGPU_FPI")) : 0;
     int fpi = fpi_env > 0 ? std::min(2, fpi_env) : 2;
     if (G < 2 || fused_lds_bytes(plane_cap, nfades, sc_pitch, G, 2) > 80 * 1024 - 512) fpi = 1;
     const size_t lds = fused_lds_bytes(plane_cap, nfades, sc_pitch, G, fpi) + (size_t)ldspad;

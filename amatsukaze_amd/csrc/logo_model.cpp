@@ -215,6 +215,9 @@ float correlation_score_host(const MaskTables& t, const float* work)
 
 MaskTables build_mask_tables(const LogoPlanes& L, float maskratio)
 {
+    // maskratio arrives from the user's script (AMTAnalyzeLogo's [maskratio], CMAnalyze's setting): a negative or NaN value
+    // would turn into a negative pixel count below
+    if (!(maskratio >= 0.0f) || !std::isfinite(maskratio)) throw std::runtime_error("maskratio must be a finite value >= 0");
     MaskTables T;
     const int w = T.w = L.w, h = T.h = L.h;
     const int npx = w * h;

@@ -20,7 +20,8 @@ namespace amt {
 
 constexpr int kStatThreads = 128;
 constexpr int kStatTileRows = 16;
-constexpr int kStatRun = 16;          // frames a workgroup walks through
+constexpr int kStatRun = 32;          // frames a workgroup walks through (the frame before a run is its one re-read: 1/32)
+constexpr int kStatXcds = 8;          // MI355X: 8 XCDs, workgroups are dealt to them round-robin by linear workgroup id
 constexpr int kStatWords = 8;
 
 template <int ES> struct Px;
@@ -67,7 +68,13 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     // (tile, 16-byte column) pairs are dealt to threads densely -- `cols` columns per tile, no idle lanes when the
     // row is not a multiple of the workgroup's span (1440 bytes = 90 columns); a wave may straddle two tiles
     const int cols = col_groups;                                  // 16-byte columns per row
-    const int gid = blockIdx.x * kStatThreads + threadIdx.x;
+    // XCD-aware tile order: gridDim.x is a multiple of 8, so workgroup x of a frame run lands on XCD x % 8.  Giving XCD k the
+    // CONTIGUOUS tile groups [k*per, (k+1)*per) makes vertically adjacent tiles -- which share their two halo rows --
+    // neighbours on one XCD, running at the same time: the halo re-read is an L2 hit there instead of a second HBM fetch
+    // (each XCD has a private L2; adjacent blockIdx.x would put every halo on a different one).
+    const int per = gridDim.x / kStatXcds;
+    const int wg = (blockIdx.x % kStatXcds) * per + blockIdx.x / kStatXcds;
+    const int gid = wg * kStatThreads + threadIdx.x;
     const int tile = gid / cols;
     const int y0 = tile * kStatTileRows;
     const int xb = (gid - tile * cols) * 16;                      // byte column of this thread
@@ -89,7 +96,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         const uint8_t* p = n0 > 0 ? Y + (long long)(n0 - 1) * frame_stride : (prevY ? prevY : Y);
         load_rows(p, prev);
     }
-    __shared__ unsigned red[kStatThreads / 64][kStatWords];
     for (int n = n0; n < n1; ++n) {
         load_rows(Y + (long long)n * frame_stride, cur);
         unsigned acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -130,7 +136,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
 #pragma unroll
         for (int r = 0; r < R; ++r) prev[r] = cur[r];
     }
-    (void)red;
 }
 
 hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long long frame_stride_bytes, int pitch_elems, int W,
@@ -143,8 +148,9 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     const int tiles = (H + kStatTileRows - 1) / kStatTileRows;
     hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)((tiles * col_groups + kStatThreads - 1) / kStatThreads), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
-        block(kStatThreads);
+    const int wgs = (tiles * col_groups + kStatThreads - 1) / kStatThreads;
+    dim3 grid((unsigned)((wgs + kStatXcds - 1) / kStatXcds * kStatXcds), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
+        block(kStatThreads);                                      // surplus workgroups of the round-up find nvalid <= 0
     if (es == 1)
         hipLaunchKernelGGL(frame_stats_kernel<1>, grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es,
                            row_bytes, H, (const uint8_t*)dprevY, nframes, col_groups, dout);

@@ -12,8 +12,13 @@ Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests).
 """
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import binding
 
 FADE_HALO = 8   # CalcFade2 looks at frames n-8 .. n+8
 
@@ -53,7 +58,8 @@ def stream_order_quota(local_valid: int, max_valid: int, group=None) -> int:
     t = t.to(dev)
     bufs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(bufs, t, group=group)
-    before = sum(int(b.item()) for b in bufs[:rank])
+    counts = torch.cat(bufs).tolist()                 # one device -> host transfer for all ranks' counts
+    before = sum(counts[:rank])
     return max(0, min(local_valid, max_valid - before))
 
 
@@ -66,3 +72,66 @@ def allreduce_scan_sums(sums: torch.Tensor, plane_sums: torch.Tensor, nframes: i
     dist.all_reduce(plane_sums, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     return sums, plane_sums, int(n.item())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The C ABI's sharded drivers (amtgpu_scanlogo_sharded, amtgpu_logoframe_allgather_results) take two host-memory
+# collectives as callbacks; this is their torch.distributed implementation (RCCL with the nccl backend, gloo on CPU).
+# ------------------------------------------------------------------------------------------------------------------
+class TorchCollectives:
+    """AmtGpuCollectives over a torch.distributed process group.  Keep the object alive while the C side may call it."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self.device = device
+        self.error = None
+
+        def allgather(user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), (nbytes,))
+                dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), (nbytes * self.world,))
+                t = torch.from_numpy(src.copy()).to(self.device)
+                out = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(out, t, group=self.group)
+                dst[:] = out.cpu().numpy()
+                return 1
+            except Exception as e:       # no exception may cross the C boundary
+                self.error = e
+                return 0
+
+        def allreduce(user, buf, count):
+            try:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int64)), (count,))
+                t = torch.from_numpy(a.copy()).to(self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)       # exact: int64
+                a[:] = t.cpu().numpy()
+                return 1
+            except Exception as e:
+                self.error = e
+                return 0
+
+        self._ag, self._ar = binding.ALLGATHER_CB(allgather), binding.ALLREDUCE_CB(allreduce)
+        self.struct = binding.Collectives(self.rank, self.world, self._ag, self._ar, None)
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def logoframe_allgather(lf, first: int, nlocal: int, coll: TorchCollectives):
+    """after lf.scan_batch over this rank's frames [first, first+nlocal): every rank gets the whole clip's records"""
+    lf.ctx.check(lf.ctx.lib.amtgpu_logoframe_allgather_results(lf.h, coll.ref(), first, nlocal))
+
+
+def scan_logo_sharded(ctx, clip_local, serviceid, dstpath, imgx, imgy, w, h, thy, numMaxFrames, coll: TorchCollectives, cb=None):
+    """ScanLogo (LogoScan.hpp:1083-1098) over a stream whose frames are sharded by contiguous range: clip_local holds this
+    rank's frames.  Rank 0 writes dstpath; returns True/False like the reference's export."""
+    from .api import _p
+    cbf = binding.CB(cb) if cb else binding.CB(lambda p, a, b, c: 1)
+    ok = ctx.lib.amtgpu_scanlogo_sharded(ctx.h, coll.ref(), _p(clip_local.Y), _p(clip_local.U), _p(clip_local.V), clip_local.strideY,
+                                         clip_local.strideUV, clip_local.pitchY, clip_local.pitchUV, clip_local.width, clip_local.height,
+                                         clip_local.num_frames, serviceid, str(dstpath).encode() if dstpath else None, imgx, imgy, w, h,
+                                         thy, numMaxFrames, cbf)
+    return bool(ok)

@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the logo + CM + KFM analysis pass on synthetic 1440x1080i YUV420 (BASELINE.json).
 
-One "step" = one pass of the hot path over one HBM-resident batch of frames (config.workload):
-    LogoFrame scan (2 candidate logos + 1 erase logo, LogoScan.hpp:1543-1568)
- -> AMTAnalyzeLogo (33 evaluations per frame, :1119-1161)
+One "step" = one pass of the hot path over one HBM-resident batch of frames (config.workload, BASELINE configs[1]):
+    AMTAnalyzeLogo (33 evaluations per frame, LogoScan.hpp:1119-1161)
+ -> LogoFrame scan (2 candidate logos + 1 erase logo, :1543-1568) and the whole-frame field-difference / combing
+    metrics (self-specified CM / KFM pass) on the source frames, while the host turns the analysis records into fades
  -> CalcFade on the host (:1317-1341)  -> AMTEraseLogo in place (:1248-1261, :1374-1397)
- -> whole-frame field-difference / combing metrics (self-specified CM / KFM pass)
-Inputs are already in HBM when the timed region starts.  With --gpus N (launched by torch.distributed.run, one
-rank per GPU) every rank owns its own batch (frames are independent: weak scaling) and the per-frame logo
-scores are all-gathered over RCCL, the one real exchange of the all-frames scan (rank 0 decides).
+Inputs are already in HBM when the timed region starts.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel, timed with HIP events on the launch
-stream inside the timed steps; `cpu_baseline` is the CPU oracle (restatement of the reference, pinned against
-the real reference sources) on a bounded sample of the same workload, single thread.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
+
+--gpus N > 1 without a torch.distributed environment re-executes itself under torch.distributed.run (one rank per GPU,
+RCCL); the driver's own `python -m torch.distributed.run ... bench.py --gpus N` is used as it comes.
+  * weak (default): every rank owns its own 10 000-frame batch; the scan's {corr0,corr1} records are all-gathered
+    (the one real exchange of the all-frames scan; rank 0 decides).
+  * strong: BASELINE configs[3] -- the 107 892-frame (60 min) Y-only LogoFrame scan sharded by contiguous frame range,
+    records all-gathered, rank 0 runs selectLogo / writeResult; total work fixed as N grows.  The same measurement is
+    also attached to the default line as `strong_scan`.
+
+After the timed steps the batch is regenerated and ONE more step at the same launch geometry is checked against the
+CPU oracle on sampled frame blocks (`verified`); a mismatch exits non-zero.  Prints ONE JSON line (rank 0).
+`roofline` describes the dominant kernel, timed with HIP events on the launch stream inside the timed steps;
+`cpu_baseline` is the CPU oracle (restatement of the reference, pinned against the real reference sources) on a bounded
+sample of the same workload: single thread (`value`) and all host cores (`all_cores`).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,19 +50,41 @@ MASKRATIO = 0.35                       # CMAnalyze.hpp:291 / AMTAnalyzeLogo defa
 FLOPS_PER_MASK_PIXEL = 101             # mean 20+4 adds + 1 div, corr 25 sub + 25 mul + 20+4 adds, score 2 mul
 FLOPS_PER_RECT_PIXEL = 6               # EvaluateLogo's unblend per rectangle pixel per evaluation (LogoScan.hpp:244-249)
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
-FP32_PEAK_TFLOPS = 157.3               # fp32 vector peak == dense fp32 MFMA peak
+FP32_PEAK_TFLOPS = 157.3               # fp32 vector peak (FMA counted as 2)
+STRONG_FRAMES = 107892                 # BASELINE configs[3]: 60 min at 29.97 fps
+PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
+EVAL = "logo_eval_fused_kernel"
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=320, help="timed steps (default: a >= 5 s timed region)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU batch (BASELINE configs[1]: 10k)")
-    ap.add_argument("--cpu-frames", type=int, default=256, help="distinct frames of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat the CPU sample until this much CPU work is timed")
+    ap.add_argument("--strong-frames", type=int, default=STRONG_FRAMES, help="frames of the sharded all-frames scan (configs[3])")
+    ap.add_argument("--strong-steps", type=int, default=20)
+    ap.add_argument("--no-strong", action="store_true", help="skip the attached strong-scaling scan measurement")
+    ap.add_argument("--cpu-frames", type=int, default=300, help="distinct frames of the CPU baseline sample (configs[0]: 300; 0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="repeat the CPU sample until this much CPU work is timed")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive (streamed) measurement")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-erase", action="store_true")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with no rendezvous environment: start N ranks (one per GPU) and relay their exit code"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def make_logos():
@@ -60,51 +95,142 @@ def make_logos():
     return (main, cand2, cand3), alpha, alphaUV
 
 
-def cpu_baseline(nframes, logos, alpha, alphaUV, min_seconds=12.0):
-    """the oracle on a bounded sample of the same workload, one thread; returns (fps, detail, frames_timed)"""
+def _ptr_np(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleLogos:
+    """the checker's evaluation logos: deint of every candidate + top/bottom field logos of the erase logo"""
+
+    def __init__(self, logos_np):
+        from amtlib import Oracle
+        self.orc = orc = Oracle()
+        self.hs = [orc.make_logo(d, LW, LH, W, H, IMGX, IMGY) for d in logos_np]
+        self.deints = []
+        for h in self.hs:
+            d = orc.lib.orc_logo_deint(h)
+            orc.lib.orc_logo_create_mask(d, MASKRATIO, 1)
+            self.deints.append(d)
+        self.top = orc.lib.orc_logo_field(self.hs[0], 0); orc.lib.orc_logo_create_mask(self.top, MASKRATIO, 1)
+        self.bot = orc.lib.orc_logo_field(self.hs[0], 1); orc.lib.orc_logo_create_mask(self.bot, MASKRATIO, 1)
+        self.deint_arr = (C.c_void_p * len(self.deints))(*self.deints)
+
+    def scan(self, Y, n):
+        ev = np.zeros(n * len(self.deints) * 2, np.float32)
+        self.orc.lib.orc_logoframe_scan(self.deint_arr, len(self.deints), _ptr_np(Y), Y.strides[0], Y.shape[2], 8, W, H, n, _ptr_np(ev))
+        return ev
+
+    def analyze(self, Y, n):
+        an = np.zeros(n * 33, np.float32)
+        self.orc.lib.orc_analyze_frames(self.deints[0], self.top, self.bot, _ptr_np(Y), Y.strides[0], Y.shape[2], 8, n, _ptr_np(an))
+        return an
+
+    def fade(self, an, n, i):
+        ft, fb = C.c_float(), C.c_float()
+        self.orc.lib.orc_calc_fade(None, 0, 16, _ptr_np(an), n, i, C.byref(ft), C.byref(fb))
+        return ft.value, fb.value
+
+    def erase(self, Y, U, V, i, ft, fb):
+        self.orc.lib.orc_erase_frame(self.hs[0], _ptr_np(Y[i]), _ptr_np(U[i]), _ptr_np(V[i]), Y.shape[2], U.shape[2], 8, ft, fb)
+
+    def metrics(self, Y, n, prev=None):
+        fs = np.zeros((n, 8), np.uint64)
+        self.orc.lib.orc_frame_metrics(_ptr_np(Y), Y.strides[0], Y.shape[2], 8, W, H, n, _ptr_np(prev), _ptr_np(fs))
+        return fs
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same pass
+# --------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(nframes, logos_np, alpha, alphaUV, min_seconds):
+    """Returns the `cpu_baseline` object.  Single thread: the reference's own loops are serial (LogoScan.hpp:1577).
+    All cores: the same per-frame work dealt over threads (ctypes releases the GIL; the oracle keeps no shared state)."""
     import amt_synth as S
-    from amtlib import Oracle, _ptr
-    orc = Oracle()
-    clip = S.make_clip_np(nframes, W, H, 0x5EED0002, alpha, alphaUV, IMGX, IMGY, period=24, fade=6, pitchY=PITCH_Y, pitchUV=PITCH_UV)
-    Y, U, V = clip["Y"], clip["U"], clip["V"]
-    hs = [orc.make_logo(d, LW, LH, W, H, IMGX, IMGY) for d in logos]
-    deints = []
-    for h in hs:
-        d = orc.lib.orc_logo_deint(h)
-        orc.lib.orc_logo_create_mask(d, MASKRATIO, 1)
-        deints.append(d)
-    t = orc.lib.orc_logo_field(hs[0], 0); orc.lib.orc_logo_create_mask(t, MASKRATIO, 1)
-    b = orc.lib.orc_logo_field(hs[0], 1); orc.lib.orc_logo_create_mask(b, MASKRATIO, 1)
-    ev = np.zeros(nframes * 3 * 2, np.float32)
-    an = np.zeros(nframes * 33, np.float32)
-    fs = np.zeros((nframes, 8), np.uint64)
+    from concurrent.futures import ThreadPoolExecutor
+    ol = OracleLogos(logos_np)
+    orc = ol.orc
+    clip = S.make_clip_np(nframes, W, H, 0x5EED0001, alpha, alphaUV, IMGX, IMGY, period=24, fade=6, pitchY=PITCH_Y, pitchUV=PITCH_UV)
+    Y0, U0, V0 = clip["Y"], clip["U"], clip["V"]
+    Y, U, V = Y0.copy(), U0.copy(), V0.copy()
     detail = {"scan_s": 0.0, "analyze_s": 0.0, "fade_erase_s": 0.0, "frame_metrics_s": 0.0}
     total, frames_timed = 0.0, 0
-    while total < min_seconds:           # the whole pass over the sample, repeated (erase rewrites the sample in place)
+    first = None
+    while total < min_seconds:           # the whole pass over the sample, repeated
+        np.copyto(Y, Y0); np.copyto(U, U0); np.copyto(V, V0)   # erase rewrites the sample in place (untimed restore)
         t0 = time.perf_counter()
-        orc.lib.orc_logoframe_scan((C.c_void_p * 3)(*deints), 3, _ptr(Y), Y.strides[0], Y.shape[2], 8, W, H, nframes, _ptr(ev))
+        ev = ol.scan(Y, nframes)
         t1 = time.perf_counter()
-        orc.lib.orc_analyze_frames(deints[0], t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, nframes, _ptr(an))
+        an = ol.analyze(Y, nframes)
         t2 = time.perf_counter()
-        for i in range(nframes):
-            ft, fb = C.c_float(), C.c_float()
-            orc.lib.orc_calc_fade(None, 0, 16, _ptr(an), nframes, i, C.byref(ft), C.byref(fb))
-            orc.lib.orc_erase_frame(hs[0], _ptr(Y[i]), _ptr(U[i]), _ptr(V[i]), Y.shape[2], U.shape[2], 8, ft.value, fb.value)
+        fs = ol.metrics(Y, nframes)
         t3 = time.perf_counter()
-        orc.lib.orc_frame_metrics(_ptr(Y), Y.strides[0], Y.shape[2], 8, W, H, nframes, None, _ptr(fs))
+        for i in range(nframes):
+            ft, fb = ol.fade(an, nframes, i)
+            ol.erase(Y, U, V, i, ft, fb)
         t4 = time.perf_counter()
         total += t4 - t0
         frames_timed += nframes
-        for k, dt in zip(detail, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+        for k, dt in zip(detail, (t1 - t0, t2 - t1, t4 - t3, t3 - t2)):
             detail[k] += dt
-    detail["reference_check"] = reference_logo_passes(orc, hs, Y, U, V, nframes)
-    return frames_timed / total, detail, frames_timed
+        if first is None:
+            first = (ev, an)
+    single = frames_timed / total
+    logo_only = frames_timed / (detail["scan_s"] + detail["analyze_s"] + detail["fade_erase_s"])
+
+    # ---- all host cores: frames dealt round-robin to threads, two phases (fades need every frame's analysis) ----
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    T = max(1, min(ncpu, nframes))
+    an_all = np.zeros(nframes * 33, np.float32)
+    ev_all = np.zeros(nframes * len(ol.deints) * 2, np.float32)
+    fs_all = np.zeros((nframes, 8), np.uint64)
+    nl = len(ol.deints)
+
+    def phase1(t):
+        for i in range(t, nframes, T):
+            orc.lib.orc_logoframe_scan(ol.deint_arr, nl, _ptr_np(Y0[i]), Y0.strides[0], Y0.shape[2], 8, W, H, 1,
+                                       C.c_void_p(ev_all.ctypes.data + i * nl * 8))
+            orc.lib.orc_analyze_frames(ol.deints[0], ol.top, ol.bot, _ptr_np(Y0[i]), Y0.strides[0], Y0.shape[2], 8, 1,
+                                       C.c_void_p(an_all.ctypes.data + i * 33 * 4))
+            orc.lib.orc_frame_metrics(_ptr_np(Y0[i]), Y0.strides[0], Y0.shape[2], 8, W, H, 1, _ptr_np(Y0[max(0, i - 1)]),
+                                      C.c_void_p(fs_all.ctypes.data + i * 64))
+
+    def phase2(t):
+        y = np.empty_like(Y0[0]); u = np.empty_like(U0[0]); v = np.empty_like(V0[0])
+        for i in range(t, nframes, T):
+            ft, fb = ol.fade(an_all, nframes, i)
+            np.copyto(y, Y0[i]); np.copyto(u, U0[i]); np.copyto(v, V0[i])      # MakeWritable's copy (LogoScan.hpp:1361)
+            orc.lib.orc_erase_frame(ol.hs[0], _ptr_np(y), _ptr_np(u), _ptr_np(v), Y0.shape[2], U0.shape[2], 8, ft, fb)
+
+    mt_total, mt_frames = 0.0, 0
+    with ThreadPoolExecutor(T) as ex:
+        while mt_total < max(2.0, min_seconds / 3):
+            t0 = time.perf_counter()
+            list(ex.map(phase1, range(T)))
+            list(ex.map(phase2, range(T)))
+            mt_total += time.perf_counter() - t0
+            mt_frames += nframes
+    assert an_all.tobytes() == first[1].tobytes() and ev_all.tobytes() == first[0].tobytes(), "threaded oracle differs from the serial one"
+
+    ref_check = reference_logo_passes(orc, ol.hs, Y0, U0, V0, min(nframes, 64), first)
+    return {"value": single, "unit": "frames/sec", "cores": 1, "kind": "port",
+            "sample": f"{frames_timed} frames ({nframes} distinct 1440x1080 8-bit frames = BASELINE configs[0]'s clip length, pass repeated), same "
+                      "pass as the GPU step (scan 3 logos + analyze + frame metrics + fade/erase), oracle/libamt_oracle.so -O2 -mavx, "
+                      "single thread (the reference's loops are serial, LogoScan.hpp:1577)",
+            "logo_passes_only_fps": logo_only,
+            "all_cores": {"value": mt_frames / mt_total, "unit": "frames/sec", "cores": T, "host_cpus": os.cpu_count(),
+                          "sample": f"{mt_frames} frames, frames dealt over {T} threads (ctypes releases the GIL), two phases "
+                                    "(scan+analysis+metrics, then fade+erase on a copy of the frame)"},
+            "detail_s": detail, "reference_check": ref_check}
 
 
-def reference_logo_passes(orc, hs, Y, U, V, nframes):
+def reference_logo_passes(orc, hs, Y, U, V, nframes, oracle_out):
     """The REAL reference (oracle/_ref/libamt_ref.so: LogoScan.hpp / ComputeKernel.cpp compiled through oracle/ref_shim) on the
-    same sample, once, for the two passes it has: LogoFrame scan and AMTAnalyzeLogo.  Shows what the port's timing stands for;
-    None where the library was never built (it needs /root/reference at build time)."""
+    first `nframes` frames of the sample: LogoFrame scan and AMTAnalyzeLogo, timed AND byte-compared with the oracle's output
+    for the same frames.  None where the library was never built (it needs /root/reference at build time)."""
     import tempfile
     from amtlib import Ref
     if not Ref.available():
@@ -117,39 +243,79 @@ def reference_logo_passes(orc, hs, Y, U, V, nframes):
         if not orc.lib.orc_logo_save(h, p, b"bench", 1):
             return None
         paths.append(p)
-    ev = np.zeros(nframes * 3 * 2, np.float32)
+    nl = len(hs)
+    ev = np.zeros(nframes * nl * 2, np.float32)
     best, ratio = C.c_int(), C.c_float()
     text = C.create_string_buffer(1 << 20)
     t0 = time.perf_counter()
-    ok = ref.lib.ref_logoframe((C.c_char_p * 3)(*paths), 3, MASKRATIO, _ptr_np(Y), Y.strides[0], Y.shape[2], 8, W, H, nframes, 30000, 1001,
-                               _ptr_np(ev), 3, C.byref(best), C.byref(ratio), -1, os.path.join(tmp, "logof.txt").encode(), text, len(text))
+    ok = ref.lib.ref_logoframe((C.c_char_p * nl)(*paths), nl, MASKRATIO, _ptr_np(Y), Y.strides[0], Y.shape[2], 8, W, H, nframes, 30000, 1001,
+                               _ptr_np(ev), nl, C.byref(best), C.byref(ratio), -1, os.path.join(tmp, "logof.txt").encode(), text, len(text))
     t1 = time.perf_counter()
     an = np.zeros(nframes * 33, np.float32)
     ok2 = ref.lib.ref_analyze(paths[0], MASKRATIO, _ptr_np(Y), _ptr_np(U), _ptr_np(V), Y.strides[0], U.strides[0], Y.shape[2], U.shape[2], 8,
                               W, H, nframes, _ptr_np(an))
     t2 = time.perf_counter()
     if ok != 1 or ok2 != 1:
-        return None
-    return {"kind": "reference", "frames": nframes, "scan_s": t1 - t0, "analyze_s": t2 - t1,
-            "note": "includes the one-off CreateLogoMask setup of each filter instance"}
+        raise SystemExit("reference_check: the reference build failed to run: " + str(ref.lib.ref_last_error()))
+    same_scan = ev.tobytes() == oracle_out[0][:nframes * nl * 2].tobytes()
+    same_an = an.tobytes() == oracle_out[1][:nframes * 33].tobytes()
+    if not (same_scan and same_an):
+        raise SystemExit(f"reference_check FAILED at 1440x1080: oracle != real reference (scan equal: {same_scan}, analysis equal: {same_an})")
+    return {"kind": "reference", "frames": nframes, "scan_s": t1 - t0, "analyze_s": t2 - t1, "oracle_equals_reference": True,
+            "note": "real LogoScan.hpp/ComputeKernel.cpp through oracle/ref_shim; includes each filter instance's one-off CreateLogoMask; "
+                    "outputs byte-compared with the oracle's for the same 1440x1080 frames"}
 
 
-def _ptr_np(a):
-    return a.ctypes.data_as(C.c_void_p)
+# --------------------------------------------------------------------------------------------------------------------
+# verification of the bench's own outputs (outside the timed region)
+# --------------------------------------------------------------------------------------------------------------------
+def verify_step(N, blocks, outputs, pristine, logos_np, erase):
+    """outputs: scan records (N,3,2), analysis (N,33), fades (N,2), erased device clip, metrics (N,8) of ONE step over the
+    freshly generated batch at the bench's launch geometry; pristine: {block: (Y,U,V,prevY)} host copies taken before that
+    step.  Compares the frames of every block with the CPU oracle, bytes."""
+    ol = OracleLogos(logos_np)
+    ev_g, an_g, fades_g, dclip, st_g = outputs
+    res = {"frames": 0, "blocks": [list(b) for b in blocks], "scan": True, "analysis": True, "fades": True, "erase": True, "metrics": True}
+    for (b0, bn) in blocks:
+        Y, U, V, prevY = pristine[(b0, bn)]
+        res["frames"] += bn
+        res["scan"] &= ol.scan(Y, bn).tobytes() == np.ascontiguousarray(ev_g[b0:b0 + bn]).tobytes()
+        an = ol.analyze(Y, bn)
+        res["analysis"] &= an.tobytes() == np.ascontiguousarray(an_g[b0:b0 + bn]).tobytes()
+        res["metrics"] &= ol.metrics(Y, bn, prevY).tobytes() == np.ascontiguousarray(st_g[b0:b0 + bn]).tobytes()
+        if not erase:
+            continue
+        # CalcFade2 looks at frames n-8..n+8 (LogoScan.hpp:1265-1285): inside a block only frames whose window stays inside
+        # it (or is clamped at the true clip start / end exactly like in the whole clip) are comparable
+        lo = 0 if b0 == 0 else 8
+        hi = bn if b0 + bn == N else bn - 8
+        eY = dclip.Y[b0:b0 + bn].cpu().numpy(); eU = dclip.U[b0:b0 + bn].cpu().numpy(); eV = dclip.V[b0:b0 + bn].cpu().numpy()
+        for i in range(lo, hi):
+            ft, fb = ol.fade(an, bn, i)
+            res["fades"] &= (np.float32(ft).tobytes() + np.float32(fb).tobytes()) == np.ascontiguousarray(fades_g[b0 + i]).tobytes()
+            ol.erase(Y, U, V, i, ft, fb)
+            res["erase"] &= np.array_equal(Y[i], eY[i]) and np.array_equal(U[i], eU[i]) and np.array_equal(V[i], eV[i])
+    res["ok"] = all(res[k] for k in ("scan", "analysis", "fades", "erase", "metrics"))
+    return res
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"--gpus {world}: only {torch.cuda.device_count()} HIP devices visible (one rank per GPU)")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+        assert dist.get_world_size() == world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -157,13 +323,121 @@ def main():
     from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Context, DeviceClip, FrameStats, Logo, LogoFrame
     from amatsukaze_amd import sharding as SH
 
-    N = args.frames
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     logos_np, alpha, alphaUV = make_logos()
-    clip = S.make_clip_torch(N, W, H, 0x5EED0002 + rank, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12,
-                             pitchY=PITCH_Y, pitchUV=PITCH_UV, start=rank * N)
-    dclip = DeviceClip(clip["Y"], clip["U"], clip["V"], W, H, 8)
-    ctx = Context(local_rank)
+    ctx = Context(local_rank)          # launches on torch's current stream: stream-ordered with the torch copies below
     logos = [Logo.from_planes(ctx, d, LW, LH, W, H, IMGX, IMGY) for d in logos_np]
+
+    # ================================================================================================================
+    # strong scaling: BASELINE configs[3] -- the all-frames LogoFrame scan of a 60-minute stream, frames sharded
+    # ================================================================================================================
+    def strong_scan():
+        NT = args.strong_frames
+        f0, f1 = SH.shard_range(NT, rank, world)
+        nloc = f1 - f0
+        t0 = time.perf_counter()
+        Yl = S.make_clip_torch(nloc, W, H, 0x5EED0004, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12, pitchY=PITCH_Y,
+                               start=f0, chroma=False)["Y"]
+        torch.cuda.synchronize()
+        gen_s = time.perf_counter() - t0
+        lf = LogoFrame(ctx, logos, MASKRATIO)
+        lf.begin(W, H, 8, NT)
+        gathered = [None]
+
+        def sstep():
+            lf.scan_batch(Yl, 8, f0, nloc)                            # this rank's frames [f0, f1) of the clip
+            if world > 1:
+                local = torch.from_numpy(lf.evalResults[f0:f1]).to(dev)
+                full = SH.gather_frame_records(local, NT)             # RCCL all_gather of 8 B per frame per logo
+                gathered[0] = full
+                if rank == 0:
+                    lf.set_results(0, full.cpu().numpy())
+            if rank == 0:
+                lf.selectLogo(len(logos))                             # host decisions over the whole clip (LogoScan.hpp:1647-1682)
+
+        for _ in range(2):
+            sstep()
+        fence()
+        ctx.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.strong_steps):
+            sstep()
+        fence()
+        el = max_over_ranks(time.perf_counter() - t0)
+        prof = ctx.profile_report()
+        ctx.profile(False)
+        out = None
+        if rank == 0:
+            rec = lf.evalResults                                      # (NT, 3, 2): the whole clip's records on rank 0
+            # sharded == unsharded on sampled frames: regenerate blocks that straddle shard boundaries (frames are a function
+            # of their absolute index), scan them in one single-GPU launch, compare bytes; and with the CPU oracle
+            probes = sorted({0, NT - 16} | {max(0, min(NT - 16, SH.shard_range(NT, r, world)[0] - 8)) for r in range(1, world)} |
+                            {max(0, min(NT - 16, (NT * k) // 8 - 8)) for k in range(1, 8)})
+            lf2 = LogoFrame(ctx, logos, MASKRATIO)
+            lf2.begin(W, H, 8, 16)
+            same, same_cpu = True, True
+            ol = OracleLogos(logos_np) if not args.no_verify else None
+            for p0 in probes:
+                Yp = S.make_clip_torch(16, W, H, 0x5EED0004, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12, pitchY=PITCH_Y,
+                                       start=p0, chroma=False)["Y"]
+                lf2.scan_batch(Yp, 8, 0, 16)
+                same &= lf2.evalResults.tobytes() == np.ascontiguousarray(rec[p0:p0 + 16]).tobytes()
+                if ol is not None:
+                    same_cpu &= ol.scan(Yp.cpu().numpy(), 16).tobytes() == np.ascontiguousarray(rec[p0:p0 + 16]).tobytes()
+            if not (same and same_cpu):
+                raise SystemExit(f"strong_scan verification FAILED: sharded == single-launch: {same}, == CPU oracle: {same_cpu}")
+            calls, ms = prof.get(EVAL + ".scan", (0, 0.0))
+            out = {"workload": f"BASELINE configs[3]: {NT}-frame (60 min) 1440x1080i Y-only LogoFrame scan, 3 logos, frames sharded "
+                               f"over {world} GPU(s) by contiguous range, all_gather of the records, selectLogo on rank 0",
+                   "frames_total": NT, "frames_per_gpu": nloc, "n_gpus": world, "steps": args.strong_steps,
+                   "value": NT * args.strong_steps / el, "unit": "frames/sec", "ms_per_step": el / args.strong_steps * 1e3,
+                   "scaling": "strong", "scan_kernel_ms_rank0": ms / max(1, calls),
+                   "records_sha256": hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest(),
+                   "best_logo": lf.getBestLogo(), "logo_ratio": lf.getLogoRatio(),
+                   "verified": {"probe_blocks": len(probes), "frames": 16 * len(probes), "sharded_equals_single_launch": bool(same),
+                                "equals_cpu_oracle": bool(same_cpu) if ol is not None else None},
+                   "clip_generation_s": gen_s,
+                   "note": "records_sha256 is the hash of all gathered {corr0,corr1} records: identical at every N means the sharded "
+                           "scan reproduces the single-GPU scan bit for bit"}
+        del Yl
+        torch.cuda.empty_cache()
+        return out
+
+    if args.scaling == "strong":
+        ss = strong_scan()
+        if rank == 0:
+            line = {"metric": "frames/sec 1440x1080i logo+CM+KFM pass", "value": ss["value"], "unit": "frames/sec", "n_gpus": world,
+                    "steps": args.strong_steps, "warmup": 2, "ms_per_step": ss["ms_per_step"], "higher_is_better": True,
+                    "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": ss["workload"], "frames_total": ss["frames_total"], "logo": f"{LW}x{LH}@({IMGX},{IMGY})",
+                               "maskratio": MASKRATIO, "parallelism": f"frames sharded x{world}"},
+                    "strong_scan": ss}
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ================================================================================================================
+    # the headline pass (BASELINE configs[1]); with N ranks every rank owns its own batch (weak scaling)
+    # ================================================================================================================
+    N = args.frames
+    gen = lambda: S.make_clip_torch(N, W, H, 0x5EED0002 + rank, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12,
+                                    pitchY=PITCH_Y, pitchUV=PITCH_UV, start=rank * N)
+    clip = gen()
+    dclip = DeviceClip(clip["Y"], clip["U"], clip["V"], W, H, 8)
     lf = LogoFrame(ctx, logos, MASKRATIO)
     lf.begin(W, H, 8, N)
     analyzer = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO)
@@ -172,24 +446,23 @@ def main():
     d_analysis = torch.empty((N, 33), dtype=torch.float32, device=dev)
     d_stats = torch.empty((N, 8), dtype=torch.int64, device=dev)
     h_analysis = torch.empty((N, 33), dtype=torch.float32).pin_memory()
+    an_ready = torch.cuda.Event()
+    last = {}
 
-    def step():
-        lf.scan_batch(dclip.Y, 8, 0, N)                              # a9: all-frames scan, 3 logos x 2 fades
+    def step(collective=True):
         analyzer.analyze_device(dclip.Y, 8, d_analysis)              # a11: 33 evaluations per frame
-        h_analysis.copy_(d_analysis, non_blocking=False)             # decisions are host logic (tiny)
+        h_analysis.copy_(d_analysis, non_blocking=True)              # stream-ordered behind the analysis kernel
+        an_ready.record()
+        lf.scan_batch(dclip.Y, 8, 0, N)                              # a9: all-frames scan, 3 logos x 2 fades
+        stats.run_device(dclip.Y, d_stats)                           # CM field-diff + KFM comb metrics (source frames)
         if not args.no_erase:
+            an_ready.synchronize()                                   # the host decides while the scan / metrics kernels run
             fades = eraser.calc_fades(h_analysis.numpy(), N)         # a12 CalcFade / CalcFade2
             eraser.erase(dclip, fades)                               # a12 Delogo, in place
-        stats.run_device(dclip.Y, d_stats)                           # CM field-diff + KFM comb metrics
-        if world > 1:
+            last["fades"] = fades
+        if world > 1 and collective:
             ev = torch.from_numpy(lf.evalResults).to(dev)
             SH.gather_frame_records(ev, N * world)                   # the scan's one exchange step (RCCL all_gather)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -202,95 +475,215 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_report()
     ctx.profile(False)
+    elapsed = max_over_ranks(elapsed)
+
+    # ---- verification (untimed): fresh frames, one more step at the same launch geometry, sampled blocks vs the oracle ----
+    verified = None
+    if not args.no_verify and rank == 0:
+        del clip
+        clip = gen()
+        dclip.Y.copy_(clip["Y"]); dclip.U.copy_(clip["U"]); dclip.V.copy_(clip["V"])
+        del clip
+        blocks = [(0, 40), (max(0, min(N - 64, 864)), 64), (max(0, N - 40), 40)] if N >= 200 else [(0, N)]
+        pristine = {}
+        for (b0, bn) in blocks:
+            pristine[(b0, bn)] = (dclip.Y[b0:b0 + bn].cpu().numpy(), dclip.U[b0:b0 + bn].cpu().numpy(), dclip.V[b0:b0 + bn].cpu().numpy(),
+                                  dclip.Y[b0 - 1].cpu().numpy() if b0 > 0 else None)
+        step(collective=False)                                       # rank 0 alone
+        torch.cuda.synchronize()
+        outputs = (lf.evalResults, h_analysis.numpy(), last.get("fades"), dclip, d_stats.cpu().numpy().astype(np.uint64))
+        verified = verify_step(N, blocks, outputs, pristine, logos_np, not args.no_erase)
+        if not verified["ok"]:
+            print(json.dumps({"verified": verified}), file=sys.stderr, flush=True)
+            raise SystemExit("bench verification FAILED: the timed configuration's outputs differ from the CPU oracle")
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        dist.barrier()
+
+    # free the batch before the attached measurements
+    del dclip, lf, analyzer, eraser, stats, d_analysis, d_stats
+    torch.cuda.empty_cache()
+
+    strong = None
+    if not args.no_strong:
+        try:
+            strong = strong_scan()
+        except SystemExit:
+            raise
+        except Exception as e:                                       # e.g. not enough HBM next to another tenant: never lose the line
+            strong = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+
+    ingest = None
+    if rank == 0 and world == 1 and not args.no_ingest:
+        try:
+            ingest = measure_ingest(ctx, logos, alpha, alphaUV, dev)
+        except Exception as e:
+            ingest = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         fps = N * world * args.steps / elapsed
         # ---- per-kernel figures (HIP events on the launch stream, inside the timed steps) ----
-        mpe_scan = lf_mask_pixel_evals = None
         an_tab = [logos[0].mask_tables(k, MASKRATIO)["count"] for k in (0, 1, 2)]
         scan_tab = [l.mask_tables(0, MASKRATIO)["count"] for l in logos]
-        evals_per_frame = 11 * sum(an_tab) + 2 * sum(scan_tab)      # mask-pixel evaluations per frame (both passes)
-        rect_px_evals = 11 * (LW * LH + 2 * LW * (LH // 2)) + 2 * 3 * LW * LH
-        flops_per_frame = FLOPS_PER_MASK_PIXEL * evals_per_frame + FLOPS_PER_RECT_PIXEL * rect_px_evals
-        kern = {}
-        for name, (calls, ms) in prof.items():
-            kern[name] = {"calls": calls, "avg_ms": ms / max(1, calls), "total_ms": ms}
         frames_timed = N * args.steps
+        flops_an = (FLOPS_PER_MASK_PIXEL * 11 * sum(an_tab) + FLOPS_PER_RECT_PIXEL * 11 * (LW * LH + 2 * LW * (LH // 2))) * frames_timed
+        flops_scan = (FLOPS_PER_MASK_PIXEL * 2 * sum(scan_tab) + FLOPS_PER_RECT_PIXEL * 2 * 3 * LW * LH) * frames_timed
+        kern = {name: {"calls": calls, "avg_ms": ms / max(1, calls), "total_ms": ms} for name, (calls, ms) in prof.items()}
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
+        except Exception:
+            pass
         out_kern = {}
-        EVAL = "logo_eval_fused_kernel"
-        if EVAL in kern:
-            k = kern[EVAL]
-            flops = flops_per_frame * frames_timed
-            algo_bytes = (4 * LW * LH * 1 + 8 * 3 + 132) * frames_timed   # rect rows per logo-pass + results (section 8d)
-            out_kern[EVAL] = {
-                "bound": "fp32-valu", "avg_ms": k["avg_ms"], "launches": k["calls"],
-                "achieved_tflops": flops / (k["total_ms"] * 1e-3) / 1e12,
-                "frac_fp32_peak": flops / (k["total_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                "hbm_gbs_algorithmic": algo_bytes / (k["total_ms"] * 1e-3) / 1e9}
+        for sub, flops, abytes in ((".analysis", flops_an, (LW * LH + 132) * frames_timed), (".scan", flops_scan, (3 * LW * LH + 24) * frames_timed)):
+            if EVAL + sub in kern:
+                k = kern[EVAL + sub]
+                out_kern[EVAL + sub] = {"bound": "fp32-valu", "avg_ms": k["avg_ms"], "launches": k["calls"],
+                                        "achieved_tflops": flops / (k["total_ms"] * 1e-3) / 1e12,
+                                        "frac_fp32_peak": flops / (k["total_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                        "hbm_gbs_algorithmic": abytes / (k["total_ms"] * 1e-3) / 1e9,
+                                        "hbm_bytes_per_launch_pmc": (pmc.get(EVAL + sub, {}).get("hbm_bytes_per_frame") or 0) * N or None}
         if "frame_stats_kernel" in kern:
             k = kern["frame_stats_kernel"]
             b = W * H * frames_timed
             out_kern["frame_stats_kernel"] = {"bound": "hbm", "avg_ms": k["avg_ms"], "launches": k["calls"],
                                               "achieved_gbs": b / (k["total_ms"] * 1e-3) / 1e9,
-                                              "frac": b / (k["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                              "frac": b / (k["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "hbm_bytes_per_launch_pmc": (pmc.get("frame_stats_kernel", {}).get("hbm_bytes_per_frame") or 0) * N or None}
         if "delogo_kernel" in kern:
             k = kern["delogo_kernel"]
             b = 2 * (LW * LH + 2 * (LW // 2) * (LH // 2)) * frames_timed
             out_kern["delogo_kernel"] = {"bound": "hbm", "avg_ms": k["avg_ms"], "launches": k["calls"],
                                          "achieved_gbs": b / (k["total_ms"] * 1e-3) / 1e9,
                                          "frac": b / (k["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        except Exception:
-            pass
-        dom = max(kern, key=lambda n: kern[n]["total_ms"]) if kern else None
-        if dom == EVAL:
-            kk = out_kern[dom]
-            per_launch_flops = flops_per_frame * frames_timed / max(1, kern[dom]["calls"])
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": kk["achieved_tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": kk["frac_fp32_peak"],
-                        "traffic": (pmc.get(EVAL, {}).get("hbm_bytes_per_frame") or 0) * frames_timed / max(1, kern[dom]["calls"]) or None,
-                        "traffic_note": pmc.get("note"), "avg_launch_ms": kk["avg_ms"], "flops_per_launch": per_launch_flops,
-                        "note": "fp32 VALU kernel (no MFMA: per-pixel private 25-tap kernels, no operand reuse); priced against the fp32 "
-                                "vector peak, which equals the dense fp32 MFMA peak; ops are mul/add/sub without FMA contraction "
-                                "(bit-exactness), so 0.5 is the ceiling of this fraction; launches are the scan (3 logos x 2 fades) "
-                                "and the analysis (3 evaluation logos x 11 fades), averaged"}
-        elif dom in out_kern and "achieved_gbs" in out_kern[dom]:
-            kk = out_kern[dom]
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": kk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": kk["frac"], "traffic": None, "avg_launch_ms": kk["avg_ms"]}
-        else:
-            roofline = None
+        # the dominant kernel: logo_eval_fused_kernel (both of its launches per step, as in round 1) unless something else leads
+        ev_total = sum(kern[n]["total_ms"] for n in kern if n.startswith(EVAL))
+        ev_calls = sum(kern[n]["calls"] for n in kern if n.startswith(EVAL))
+        others = {n: kern[n]["total_ms"] for n in kern if not n.startswith(EVAL)}
+        roofline = None
+        if ev_calls and (not others or ev_total >= max(others.values())):
+            fl = flops_an + flops_scan
+            tr_an = pmc.get(EVAL + ".analysis", {}).get("hbm_bytes_per_frame")
+            tr_sc = pmc.get(EVAL + ".scan", {}).get("hbm_bytes_per_frame")
+            roofline = {"kernel": EVAL, "bound": "fp32-valu", "achieved": fl / (ev_total * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": fl / (ev_total * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "traffic": ((tr_an + tr_sc) / 2 * N) if (tr_an and tr_sc) else None,
+                        "traffic_source": (PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench's own launches; "
+                                           "not collected inside the timed run)") if (tr_an and tr_sc) else None,
+                        "avg_launch_ms": ev_total / ev_calls, "flops_per_launch": fl / ev_calls,
+                        "algorithmic_bytes_per_launch": ((LW * LH + 132) + (3 * LW * LH + 24)) / 2 * N,
+                        "note": "fp32 VALU kernel (no MFMA: per-pixel private 25-tap kernels, no operand reuse); priced against the fp32 vector "
+                                "peak with FMA counted as 2; ops are mul/add/sub without FMA contraction (bit-exactness), so 0.5 is the ceiling "
+                                "of this fraction; launches per step: the analysis (3 evaluation logos x 11 fades) and the scan (3 logos x 2 "
+                                "fades), averaged; flops are the reference's own operation count (101 per mask-pixel evaluation + 6 per "
+                                "rectangle pixel per evaluation)"}
+        elif others:
+            dom = max(others, key=others.get)
+            if dom in out_kern and "achieved_gbs" in out_kern[dom]:
+                kk = out_kern[dom]
+                roofline = {"kernel": dom, "bound": "hbm", "achieved": kk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": kk["frac"], "traffic": kk.get("hbm_bytes_per_launch_pmc"), "traffic_source": PMC_TRAFFIC,
+                            "avg_launch_ms": kk["avg_ms"]}
         cpu = None
         if args.cpu_frames > 0 and world == 1:        # the CPU baseline is reported at N=1 only
-            cfps, detail, ctimed = cpu_baseline(args.cpu_frames, logos_np, alpha, alphaUV, args.cpu_seconds)
-            cpu = {"value": cfps, "unit": "frames/sec", "cores": 1, "kind": "port",
-                   "sample": f"{ctimed} frames ({args.cpu_frames} distinct 1440x1080 8-bit frames, pass repeated), same pass (scan 3 logos + "
-                             "analyze + fade/erase + frame metrics), oracle/libamt_oracle.so -O2 -mavx single thread (the reference "
-                             "loop is serial, LogoScan.hpp:1577)",
-                   "host_cpus": os.cpu_count(), "detail_s": detail}
+            cpu = cpu_baseline(args.cpu_frames, logos_np, alpha, alphaUV, args.cpu_seconds)
         line = {
             "metric": "frames/sec 1440x1080i logo+CM+KFM pass",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"single MI355X: {N}-frame 1440x1080i 8-bit YUV420 resident in HBM; LogoFrame scan (3 logos) + "
-                                   "AMTAnalyzeLogo + CalcFade + AMTEraseLogo + CM/KFM frame metrics",
+            "config": {"workload": f"single MI355X: {N}-frame 1440x1080i 8-bit YUV420 resident in HBM; AMTAnalyzeLogo + LogoFrame scan (3 logos) "
+                                   "+ CM/KFM frame metrics + CalcFade + AMTEraseLogo (BASELINE configs[1])",
                        "frames_per_gpu": N, "logo": f"{LW}x{LH}@({IMGX},{IMGY})", "maskratio": MASKRATIO,
-                       "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"frames sharded x{world} (one private batch per rank)" if world > 1 else "single GPU"},
+            "timed_region_s": elapsed,
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": (fps / cpu["value"]) if cpu else None,
+            "gpu_over_cpu_all_cores": (fps / cpu["all_cores"]["value"]) if cpu else None,
+            "verified": verified, "strong_scan": strong, "ingest": ingest,
             "kernels": out_kern,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# frames that are NOT resident: pageable host -> pinned ring -> hipMemcpyAsync on the side stream, overlapped with the
+# analysis of the previous batch.  Never `value`; reported beside it.
+# --------------------------------------------------------------------------------------------------------------------
+def measure_ingest(ctx, logos, alpha, alphaUV, dev, B=256, batches=10):
+    import torch
+    import amt_synth as S
+    from amatsukaze_amd import AMTAnalyzeLogo, FrameStats, LogoFrame
+    g = S.make_clip_torch(B, W, H, 0x5EED0002, alpha, alphaUV, IMGX, IMGY, dev, pitchY=PITCH_Y, pitchUV=PITCH_UV, chroma=False)
+    hY = g["Y"].cpu().numpy().copy()                                  # the "decoder output": pageable host memory
+    del g
+    ybytes = hY.nbytes
+    # rectangle-only variant for the logo passes: the rows [IMGY, IMGY+LH) of the Y plane at full pitch (the kernels address
+    # (imgx, imgy) inside a frame, so the upload keeps the pitch and drops the rows nobody reads): LH*pitch bytes per frame
+    hR = np.ascontiguousarray(hY[:, IMGY:IMGY + LH, :])
+    rbytes = hR.nbytes
+    dbuf = [torch.empty((B, H, PITCH_Y), dtype=torch.uint8, device=dev) for _ in range(2)]
+    lf = LogoFrame(ctx, [logos[0]], MASKRATIO)
+    lf.begin(W, H, 8, B * batches)
+    an = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO)
+    fs = FrameStats(ctx, W, H, 8)
+    d_an = torch.empty((B, 33), dtype=torch.float32, device=dev)
+    d_st = torch.empty((B, 8), dtype=torch.int64, device=dev)
+
+    def upload(k, rect):
+        if rect:   # rows [IMGY, IMGY+LH) of every frame: B pieces of LH*pitch bytes, one frame stride apart on the device
+            ctx.check(ctx.lib.amtgpu_frames_upload_strided(ctx.h, dbuf[k & 1].data_ptr() + IMGY * PITCH_Y, H * PITCH_Y, hR.ctypes.data,
+                                                           LH * PITCH_Y, LH * PITCH_Y, B))
+        else:
+            ctx.check(ctx.lib.amtgpu_frames_upload(ctx.h, dbuf[k & 1].data_ptr(), hY.ctypes.data, ybytes))
+
+    def compute(k, rect):
+        ctx.check(ctx.lib.amtgpu_frames_upload_wait(ctx.h))          # compute stream waits for the copies issued so far
+        lf.scan_batch(dbuf[k & 1], 8, k * B, B)
+        an.analyze_device(dbuf[k & 1], 8, d_an)
+        if not rect:
+            fs.run_device(dbuf[k & 1], d_st)
+
+    def timed(fn, *a):
+        fn(*a)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(*a)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def ingest_only(rect):
+        for k in range(batches):
+            upload(k, rect)
+        ctx.check(ctx.lib.amtgpu_frames_upload_wait(ctx.h))
+
+    def compute_only(rect):
+        for k in range(batches):
+            compute(k, rect)
+
+    def pipelined(rect):
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        upload(0, rect)
+        for k in range(batches):
+            compute(k, rect)
+            done[k & 1].record()
+            if k + 1 < batches:
+                if k >= 1:
+                    done[(k + 1) & 1].synchronize()                   # batch k-1 has released the buffer batch k+1 goes into
+                upload(k + 1, rect)
+
+    n = B * batches
+    ti, tc, tp = timed(ingest_only, False), timed(compute_only, False), timed(pipelined, False)
+    ri, rc, rp = timed(ingest_only, True), timed(compute_only, True), timed(pipelined, True)
+    return {"what": "PCIe-inclusive rates: frames start in pageable host memory (amtgpu_frames_upload: pinned double-buffered ring, "
+                    "hipMemcpyAsync on the side stream) and the previous batch is analysed meanwhile; never `value`",
+            "batch_frames": B, "batches": batches,
+            "y_plane": {"bytes_per_frame": ybytes // B, "ingest_only_fps": n / ti, "ingest_GBs": ybytes * batches / ti / 1e9,
+                        "compute_only_fps": n / tc, "pipelined_fps": n / tp, "passes": "scan 1 logo + analysis + frame metrics"},
+            "logo_rectangle_rows": {"bytes_per_frame": rbytes // B, "ingest_only_fps": n / ri, "ingest_GBs": rbytes * batches / ri / 1e9,
+                                    "compute_only_fps": n / rc, "pipelined_fps": n / rp, "passes": "scan 1 logo + analysis (logo passes only)"}}
 
 
 if __name__ == "__main__":

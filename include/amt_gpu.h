@@ -15,6 +15,8 @@
  *
  * All kernels are launched on the context's HIP stream (amtgpu_context_set_stream); calls that return
  * results to host memory synchronise that stream, calls documented "async" do not.
+ * Calls on one context are serialised by a lock inside it (filters sharing a context may be driven from several
+ * AviSynth threads); use one context per thread for concurrency.
  */
 #ifndef AMT_GPU_H
 #define AMT_GPU_H
@@ -47,7 +49,12 @@ int amtgpu_abi_version(void);
 AmtGpuContext* amtgpu_context_create(int device);       /* NULL if no HIP device / bad index */
 void           amtgpu_context_destroy(AmtGpuContext* ctx);
 const char*    amtgpu_last_error(const AmtGpuContext* ctx);
-/* use an existing hipStream_t (e.g. the caller's compute stream); NULL = the context's own stream */
+/* use an existing hipStream_t (e.g. the caller's compute stream); NULL = the context's own stream, which is created
+ * hipStreamNonBlocking: it is NOT ordered against the legacy default ("null") stream.  A caller whose other GPU work runs
+ * on the null stream (handle 0, e.g. PyTorch without an explicit stream) passes AMTGPU_STREAM_LEGACY_DEFAULT
+ * (== hipStreamLegacy) so that the "async" entry points below are stream-ordered with that work.  On any other stream
+ * pair the caller orders the two with events or amtgpu_context_synchronize before consuming device outputs. */
+#define AMTGPU_STREAM_LEGACY_DEFAULT ((void*)1)
 int            amtgpu_context_set_stream(AmtGpuContext* ctx, void* hip_stream);
 void*          amtgpu_context_get_stream(AmtGpuContext* ctx);
 int            amtgpu_context_synchronize(AmtGpuContext* ctx);
@@ -63,6 +70,11 @@ int            amtgpu_profile_report(AmtGpuContext* ctx, char* out, int cap);
 void* amtgpu_device_alloc(AmtGpuContext* ctx, uint64_t bytes);
 void  amtgpu_device_free(AmtGpuContext* ctx, void* dptr);
 int   amtgpu_frames_upload(AmtGpuContext* ctx, void* ddst, const void* hsrc, uint64_t bytes);   /* async on side stream */
+/* the same for nchunks pieces of chunk_bytes that sit dst_stride apart on the device and src_stride apart on the host -- e.g. only
+ * the logo rectangle's rows of every frame of a batch (h*pitch bytes instead of a whole frame: the logo passes read nothing
+ * else).  async on the side stream */
+int   amtgpu_frames_upload_strided(AmtGpuContext* ctx, void* ddst, int64_t dst_stride, const void* hsrc, int64_t src_stride,
+                                   uint64_t chunk_bytes, int nchunks);
 int   amtgpu_frames_upload_wait(AmtGpuContext* ctx);   /* make the compute stream wait for pending uploads */
 int   amtgpu_download(AmtGpuContext* ctx, void* hdst, const void* dsrc, uint64_t bytes);        /* synchronous */
 
@@ -167,6 +179,34 @@ int  amtgpu_scanlogo(AmtGpuContext* ctx, const void* dY, const void* dU, const v
                      int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int imgw, int imgh,
                      int nframes, int serviceid, const char* dstpath, int imgx, int imgy, int w, int h,
                      int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb);
+
+/* ---- frame-sharded runs (one process per GPU).  The library does no communication itself: the host
+ *      supplies two collectives over HOST memory -- RCCL in a C++ host (include/amt_rccl_collectives.hpp wraps an ncclComm_t),
+ *      torch.distributed in the Python mirror (amatsukaze_amd/sharding.py).  Ranks hold contiguous frame ranges in stream
+ *      order (rank 0 the first frames).  Both callbacks return 1 on success, 0 on failure. ---- */
+typedef struct AmtGpuCollectives {
+    int rank, world;
+    /* every rank contributes `bytes` bytes; recv receives world*bytes in rank order */
+    int (*allgather)(void* user, const void* send, void* recv, int64_t bytes);
+    /* in-place sum over all ranks of `count` int64 */
+    int (*allreduce_sum_i64)(void* user, int64_t* buf, int64_t count);
+    void* user;
+} AmtGpuCollectives;
+
+/* LogoFrame::scanFrames sharded (LogoScan.hpp:1577-1584, frames independent): after this rank has scanned its frames
+ * [first, first+nlocal) with amtgpu_logoframe_scan_batch, exchange the {corr0,corr1} records so that EVERY rank holds the
+ * whole clip's results (8 B per frame per logo) and select_logo / write_result give the single-GPU answer anywhere. */
+int  amtgpu_logoframe_allgather_results(AmtGpuLogoFrame* lf, const AmtGpuCollectives* coll, int first, int nlocal);
+
+/* ScanLogo sharded (LogoAnalyzer, LogoScan.hpp:917-1079): dY/dU/dV hold this rank's `nframes_local` frames.  The three
+ * globally sequential rounds are kept: round 0 accepts the first numMaxFrames valid frames IN STREAM ORDER (:885; an
+ * all-gather of per-rank valid counts gives every rank its share of the quota), each round's exact int64 accumulators are
+ * all-reduced, and every rank solves the same regression -> the .lgd is byte-identical to the single-GPU one at any world
+ * size.  Rank 0 writes dstpath (other ranks may pass NULL).  A cancel from any rank's callback stops all ranks. */
+int  amtgpu_scanlogo_sharded(AmtGpuContext* ctx, const AmtGpuCollectives* coll, const void* dY, const void* dU, const void* dV,
+                             int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int imgw, int imgh,
+                             int nframes_local, int serviceid, const char* dstpath, int imgx, int imgy, int w, int h,
+                             int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb);
 
 /* ---- self-specified whole-frame passes (NO in-tree reference arithmetic: SURVEY.md section 0;
  *      "parity unpinned").  Stand in for what chapter_exe (CMAnalyze.hpp:319-337) and KFMDeint's

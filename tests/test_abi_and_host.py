@@ -197,3 +197,12 @@ def test_kfm_and_cm_output_file_contracts(tmp_path, lib):
         if m:
             got.append(int(m.group(1)))
     assert got == sc.tolist()
+
+
+def test_release_library_reads_no_experiment_knobs():
+    """AMTGPU_DBG / AMTGPU_LDSPAD / AMTGPU_FPI / AMTGPU_G exist only in instrumented builds (-DAMT_EXPERIMENT,
+    amatsukaze_amd/build.py build_variant): a stray environment variable must not be able to change the release
+    library's results, so the strings are not even in it."""
+    blob = open(binding.LIB_PATH, "rb").read()
+    for knob in (b"AMTGPU_DBG", b"AMTGPU_LDSPAD", b"AMTGPU_FPI", b"AMTGPU_G\0", b"AMTGPU_VERBOSE"):
+        assert knob not in blob, knob

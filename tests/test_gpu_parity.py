@@ -331,3 +331,19 @@ def test_score_bin_edge_means(gpu):
         want = np.zeros(cfg["N"] * 33, np.float32)
         orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
         assert got.reshape(-1).tobytes() == want.tobytes(), (scale_a, scale_b)
+
+
+def test_experiment_environment_variables_are_ignored(gpu, monkeypatch):
+    """round-1 builds let AMTGPU_DBG skip kernel phases (wrong results, return code ok); the release library no longer reads it"""
+    from amatsukaze_amd import AMTAnalyzeLogo
+    for k, v in (("AMTGPU_DBG", "7"), ("AMTGPU_LDSPAD", "40000"), ("AMTGPU_FPI", "1"), ("AMTGPU_G", "3")):
+        monkeypatch.setenv(k, v)
+    cs = make_case(gpu, SMALL)
+    orc = cs["orc"]
+    d, t, b = oracle_eval_logos(orc, cs["lo"])
+    Y = cs["clip"]["Y"]
+    n = Y.shape[0]
+    want = np.zeros(n * 33, np.float32)
+    orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, n, _ptr(want))
+    got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"])
+    assert got.tobytes() == want.tobytes()

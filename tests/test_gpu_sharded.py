@@ -1,0 +1,116 @@
+"""The frame-sharded drivers on the HIP path, world_size 2: one process per rank with its own context, the kernels of both
+ranks on real hardware.  With >= 2 GPUs every rank takes its own device and the collectives run over RCCL (backend nccl);
+on a 1-GPU box both ranks share device 0 and the collectives run over gloo -- the sharded code path (quota, all-gather,
+exact all-reduce, identical regression on every rank, halo analysis) is the same.  Expected values are the REAL
+reference's outputs (tests/golden/, no oracle in the loop): the sharded result must be the single-GPU result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, tmpdir, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ndev = torch.cuda.device_count()
+    devidx = rank % ndev
+    torch.cuda.set_device(devidx)
+    backend = "nccl" if ndev >= world else "gloo"
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", devidx))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Context, DeviceClip, Logo, LogoFrame
+        from amatsukaze_amd import sharding as SH
+        dev = torch.device("cuda", devidx)
+        ctx = Context(devidx)
+        coll = SH.TorchCollectives()
+        g = G.load()
+        W, H, LW, LH, X, Y0, N = (g[k] for k in ("W", "H", "LW", "LH", "X", "Y0", "N"))
+        res = {"rank": rank, "backend": backend}
+
+        # ---- ScanLogo, sharded: the .lgd must be the reference's own file ----
+        Y2, U2, V2 = G.frames(g, "scanlogo_crop_y", "scanlogo_crop_u", "scanlogo_crop_v")
+        n2 = Y2.shape[0]
+        a, b = SH.shard_range(n2, rank, world)
+        loc = DeviceClip(torch.from_numpy(Y2[a:b]).to(dev), torch.from_numpy(U2[a:b]).to(dev), torch.from_numpy(V2[a:b]).to(dev), W, H)
+        dst = os.path.join(tmpdir, "sharded.lgd")
+        ok = SH.scan_logo_sharded(ctx, loc, 1041, dst if rank == 0 else None, X, Y0, LW, LH, 12, 25, coll)
+        res["scanlogo_ok"] = bool(ok) and coll.error is None
+        if rank == 0:
+            res["scanlogo_lgd_equal"] = open(dst, "rb").read() == g["scanlogo_lgd"].tobytes()
+        # a quota that ends inside rank 0's shard (rank 1 contributes nothing) and one nobody reaches
+        for cap, tag in ((3, "cap3"), (10000, "capall")):
+            d2 = os.path.join(tmpdir, f"sharded_{tag}.lgd")
+            ok = SH.scan_logo_sharded(ctx, loc, 1041, d2 if rank == 0 else None, X, Y0, LW, LH, 12, cap, coll)
+            if rank == 0:
+                from amatsukaze_amd import ScanLogo
+                full = DeviceClip(torch.from_numpy(Y2).to(dev), torch.from_numpy(U2).to(dev), torch.from_numpy(V2).to(dev), W, H)
+                d1 = os.path.join(tmpdir, f"single_{tag}.lgd")
+                ok1 = ScanLogo(ctx, full, 1041, d1, X, Y0, LW, LH, 12, cap)
+                res[f"scanlogo_{tag}"] = (bool(ok) == bool(ok1)) and (not ok1 or open(d1, "rb").read() == open(d2, "rb").read())
+
+        # ---- LogoFrame all-frames scan, sharded (ragged: 39 frames -> 20 + 19) + all-gather on every rank ----
+        Y, U, V = G.frames(g, pitch_pad=32)
+        NS = N - 1
+        f0, f1 = SH.shard_range(NS, rank, world)
+        logos = [Logo.from_planes(ctx, g[k], LW, LH, W, H, X, Y0) for k in ("logo0", "logo1")]
+        lf = LogoFrame(ctx, logos, 0.35)
+        lf.begin(W, H, 8, NS)
+        lf.scan_batch(torch.from_numpy(Y[f0:f1]).to(dev), 8, f0, f1 - f0)
+        SH.logoframe_allgather(lf, f0, f1 - f0, coll)
+        res["logoframe_equal"] = lf.evalResults.tobytes() == g["logoframe_evals"][:NS].tobytes()
+        lf.selectLogo(2)
+        res["best"] = lf.getBestLogo()
+
+        # ---- analysis + erase of a shard with an 8-frame analysis halo either side (CalcFade2 reads n-8 .. n+8) ----
+        e0, e1 = SH.shard_range(N, rank, world)
+        h0, h1 = SH.halo_range(e0, e1, N)
+        an = np.zeros((N, 33), np.float32)
+        hal = DeviceClip(torch.from_numpy(Y[h0:h1]).to(dev), torch.from_numpy(U[h0:h1]).to(dev), torch.from_numpy(V[h0:h1]).to(dev), W, H)
+        an[h0:h1] = AMTAnalyzeLogo(ctx, logos[0], 0.35).analyze(hal)
+        er = AMTEraseLogo(ctx, logos[0], "", 0, 16)
+        fades = er.calc_fades(an, N, e0, e1 - e0)          # touches only records inside [e0-8, e1+8)
+        res["fades_equal"] = fades.tobytes() == g["erase_nolf_fades"][e0:e1].tobytes()
+        own = DeviceClip(hal.Y[e0 - h0:e1 - h0], hal.U[e0 - h0:e1 - h0], hal.V[e0 - h0:e1 - h0], W, H)
+        er.erase(own, fades)
+        ctx.synchronize()
+        cy, cu, cv = G.crops(g, own.Y.cpu().numpy(), own.U.cpu().numpy(), own.V.cpu().numpy())
+        res["erase_equal"] = bool(np.array_equal(cy, g["erase_nolf_Y"][e0:e1]) and np.array_equal(cu, g["erase_nolf_U"][e0:e1])
+                                  and np.array_equal(cv, g["erase_nolf_V"][e0:e1]))
+        q.put(res)
+    except Exception as e:      # surface the failure in the parent instead of a bare timeout
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_hip_path_world2(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert "error" not in r, r["error"]
+    r0, r1 = res
+    assert r0["scanlogo_ok"] and r1["scanlogo_ok"]
+    assert r0["scanlogo_lgd_equal"], "sharded ScanLogo .lgd differs from the reference's"
+    assert r0["scanlogo_cap3"] and r0["scanlogo_capall"]
+    for r in res:
+        assert r["logoframe_equal"] and r["best"] == int(G.load()["logoframe_best"])
+        assert r["fades_equal"] and r["erase_equal"]
+    assert all(p.exitcode == 0 for p in procs)

@@ -91,3 +91,36 @@ def test_sharded_scan_and_logo_generation_world2():
         assert p.exitcode == 0
     assert all(ok1 and ok2 for _, ok1, ok2, _ in res), res
     assert sum(r[3] for r in res) == 9
+
+
+def _coll_worker(rank, world, port, q):
+    """the host-memory collectives handed to the C ABI's sharded drivers (AmtGpuCollectives), called the way C calls them"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = SH.TorchCollectives()
+        send = np.array([rank * 10 + 1, rank * 10 + 2], np.int64)
+        recv = np.zeros(2 * world, np.int64)
+        ok = c.struct.allgather(None, send.ctypes.data, recv.ctypes.data, 16)
+        buf = np.array([1, 2 ** 40 + rank, -5], np.int64)             # sums that do not fit a double's 24-bit float cousin
+        ok2 = c.struct.allreduce_sum_i64(None, buf.ctypes.data, 3)
+        q.put((rank, ok, recv.tolist(), ok2, buf.tolist(), c.struct.rank, c.struct.world, c.error is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_collectives_callbacks_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_coll_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, recv, ok2, buf, srank, sworld, noerr in res:
+        assert ok == 1 and ok2 == 1 and noerr and srank == rank and sworld == 2
+        assert recv == [1, 2, 11, 12]
+        assert buf == [2, 2 ** 41 + 1, -10]

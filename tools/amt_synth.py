@@ -203,15 +203,16 @@ def make_clip_np(N: int, W: int, H: int, seed: int, alpha=None, alphaUV=None, im
 # ------------------------------------------------------------------------------------------------
 def make_clip_torch(N: int, W: int, H: int, seed: int, alpha, alphaUV, imgx: int, imgy: int, device,
                     bits: int = 8, period: int = 900, fade: int = 12, pitchY: int | None = None,
-                    pitchUV: int | None = None, start: int = 0, chunk: int = 64, cadence: str = "30i"):
+                    pitchUV: int | None = None, start: int = 0, chunk: int = 64, cadence: str = "30i", chroma: bool = True):
+    """chroma=False: Y plane only (the all-frames LogoFrame scan reads nothing else); U/V come back as None."""
     import torch
     dt = torch.uint8 if bits <= 8 else torch.int16
     maxv = (1 << bits) - 1
     pitchY = pitchY or W
     pitchUV = pitchUV or W // 2
     Ys = torch.zeros((N, H, pitchY), dtype=dt, device=device)
-    Us = torch.zeros((N, H // 2, pitchUV), dtype=dt, device=device)
-    Vs = torch.zeros((N, H // 2, pitchUV), dtype=dt, device=device)
+    Us = torch.zeros((N, H // 2, pitchUV), dtype=dt, device=device) if chroma else None
+    Vs = torch.zeros((N, H // 2, pitchUV), dtype=dt, device=device) if chroma else None
     yy = torch.arange(H, device=device, dtype=torch.int64)[:, None]
     xx = torch.arange(W, device=device, dtype=torch.int64)[None, :]
     al = torch.as_tensor(alpha, dtype=torch.float32, device=device) if alpha is not None else None
@@ -240,11 +241,12 @@ def make_clip_torch(N: int, W: int, H: int, seed: int, alpha, alphaUV, imgx: int
         hsh = (hsh ^ (hsh >> 16)) & 0xFFFFFFFF
         noise = (hsh & 0xF) + ((hsh >> 4) & 0xF) + ((hsh >> 8) & 0xF) - 22
         Y = (base + noise).clamp(0, 255).to(torch.float32) * (maxv / 255.0)
-        hc = hsh[:, 0::2, 0::2]
-        cxx = xx[:, 0::2] // 2
-        cyy = yy[0::2] // 2
-        U = (128 + ((cxx + scene * 13) % 41) - 20 + ((hc >> 12) & 7) - 3).to(torch.float32) * (maxv / 255.0)
-        V = (128 + ((cyy + scene * 7) % 37) - 18 + ((hc >> 16) & 7) - 3).to(torch.float32) * (maxv / 255.0)
+        if chroma:
+            hc = hsh[:, 0::2, 0::2]
+            cxx = xx[:, 0::2] // 2
+            cyy = yy[0::2] // 2
+            U = (128 + ((cxx + scene * 13) % 41) - 20 + ((hc >> 12) & 7) - 3).to(torch.float32) * (maxv / 255.0)
+            V = (128 + ((cyy + scene * 7) % 37) - 18 + ((hc >> 16) & 7) - 3).to(torch.float32) * (maxv / 255.0)
         if al is not None:
             h, w = al.shape
             vis = torch.as_tensor(logo_presence(np.arange(start + c0, start + c1), period, fade),
@@ -252,11 +254,13 @@ def make_clip_torch(N: int, W: int, H: int, seed: int, alpha, alphaUV, imgx: int
             a = al[None] * vis
             r = Y[:, imgy:imgy + h, imgx:imgx + w]
             Y[:, imgy:imgy + h, imgx:imgx + w] = (1 - a) * r + a * (235.0 / 255.0) * maxv
-            ac = alc[None] * vis
-            for P in (U, V):
-                r = P[:, imgy // 2:imgy // 2 + h // 2, imgx // 2:imgx // 2 + w // 2]
-                P[:, imgy // 2:imgy // 2 + h // 2, imgx // 2:imgx // 2 + w // 2] = (1 - ac) * r + ac * (128.0 / 255.0) * maxv
+            if chroma:
+                ac = alc[None] * vis
+                for P in (U, V):
+                    r = P[:, imgy // 2:imgy // 2 + h // 2, imgx // 2:imgx // 2 + w // 2]
+                    P[:, imgy // 2:imgy // 2 + h // 2, imgx // 2:imgx // 2 + w // 2] = (1 - ac) * r + ac * (128.0 / 255.0) * maxv
         Ys[c0:c1, :, :W] = Y.round().clamp(0, maxv).to(dt)
-        Us[c0:c1, :, :W // 2] = U.round().clamp(0, maxv).to(dt)
-        Vs[c0:c1, :, :W // 2] = V.round().clamp(0, maxv).to(dt)
+        if chroma:
+            Us[c0:c1, :, :W // 2] = U.round().clamp(0, maxv).to(dt)
+            Vs[c0:c1, :, :W // 2] = V.round().clamp(0, maxv).to(dt)
     return {"Y": Ys, "U": Us, "V": Vs}
