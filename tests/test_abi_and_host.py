@@ -199,7 +199,8 @@ def test_kfm_and_cm_output_file_contracts(tmp_path, lib):
     assert got == sc.tolist()
 
 
-def test_release_library_reads_no_experiment_knobs():
+def test_release_library_reads_no_experiment_knobs(lib):
+    from amatsukaze_amd import binding
     """AMTGPU_DBG / AMTGPU_LDSPAD / AMTGPU_FPI / AMTGPU_G exist only in instrumented builds (-DAMT_EXPERIMENT,
     amatsukaze_amd/build.py build_variant): a stray environment variable must not be able to change the release
     library's results, so the strings are not even in it."""
