@@ -252,7 +252,12 @@ class LogoFrame:
 class AMTAnalyzeLogo:
     """logo::AMTAnalyzeLogo (LogoScan.hpp:1106-1236); GetFrames returns 33 floats per source frame."""
 
-    def __init__(self, ctx: Context, logo, maskratio: float = 0.35):
+    MODES = {"exact": 0, "linear": 1}
+
+    def __init__(self, ctx: Context, logo, maskratio: float = 0.35, mode: str = "exact"):
+        """mode "exact": records bit-identical to the reference's; "linear": all fades from one evaluation of the source and one
+        of the background window per mask pixel (scores within `error_bound` of the reference's, decisions guarded by exact
+        re-evaluation -- include/amt_gpu.h AMTGPU_ANALYZE_LINEAR_GUARDED)."""
         self.ctx = ctx
         if isinstance(logo, Logo):
             self._keep = logo
@@ -260,6 +265,13 @@ class AMTAnalyzeLogo:
         else:
             self.h = ctx.lib.amtgpu_analyze_create(ctx.h, str(logo).encode(), maskratio)
         ctx.check(self.h, "AMTAnalyzeLogo")
+        ctx.check(ctx.lib.amtgpu_analyze_set_mode(self.h, self.MODES[mode]))
+
+    def last_refined(self):
+        return self.ctx.lib.amtgpu_analyze_last_refined(self.h)
+
+    def error_bound(self, group=0, bits=8):
+        return self.ctx.lib.amtgpu_analyze_error_bound(self.h, group, bits)
 
     def analyze_device(self, Y, bits, out):
         es = 1 if bits <= 8 else 2

@@ -19,6 +19,7 @@ SOURCES = [
     "amt_gpu_ingest.hip",
     "eval_engine.hip",
     "eval_fused_kernels.hip",
+    "eval_linear_kernels.hip",
     "erase_scan_kernels.hip",
     "stats_kernels.hip",
     "ingest_kernels.hip",

@@ -456,7 +456,31 @@ struct AmtGpuAnalyze {
     LogoPlanes logo;
     std::unique_ptr<EvalEngine> engine;
     DevBuf<float> dTmp;
+    int mode = AMTGPU_ANALYZE_EXACT;
+    DevBuf<int> dList, dCount;          // decision guard of the linear mode: frames to re-evaluate exactly
 };
+
+// one batch in the selected mode.  Linear mode: all fades from one window evaluation of s and of bg, then the decision guard --
+// frames whose argmin over the fades of p, t or b is not safe against the evaluation's error bound are listed on the device and
+// re-evaluated by the exact kernel in the same stream (no host round trip)
+static void analyze_run(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* dout)
+{
+    if (an->mode == AMTGPU_ANALYZE_EXACT) {
+        an->engine->run(dY, frame_stride, pitch, bits, nframes, dout);
+        return;
+    }
+    if (nframes <= 0) return;
+    an->ctx->bind();
+    if (an->dList.size() < (size_t)nframes) an->dList.alloc(nframes);
+    if (an->dCount.size() < 1) an->dCount.alloc(1);
+    an->engine->run_linear(dY, frame_stride, pitch, bits, nframes, dout);
+    float eps[3];
+    for (int k = 0; k < 3; ++k) eps[k] = 2.0f * an->engine->linear_error_bound(k, bits);
+    const int sp = an->ctx->prof_begin("analysis_mark_kernel");
+    AMT_HIP(launch_analysis_mark(an->ctx->stream, dout, AMTGPU_ANALYZE_FLOATS, nframes, 3, AMTGPU_NUM_FADE, eps, an->dList.get(), an->dCount.get()));
+    an->ctx->prof_end(sp);
+    an->engine->run_listed(dY, frame_stride, pitch, bits, nframes, an->dList.get(), an->dCount.get(), dout);
+}
 
 static AmtGpuAnalyze* analyze_new(AmtGpuContext* c, LogoPlanes logo, float maskratio)
 {
@@ -507,8 +531,38 @@ int amtgpu_analyze_batch(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride
 {
     return guard(an->ctx, [&] {
         if (bits < 8 || bits > 16) throw std::runtime_error("[AMTAnalyzeLogo] Unsupported pixel format");
-        an->engine->run(dY, frame_stride, pitch, bits, nframes, dout);
+        analyze_run(an, dY, frame_stride, pitch, bits, nframes, dout);
     });
+}
+
+int amtgpu_analyze_set_mode(AmtGpuAnalyze* an, int mode)
+{
+    return guard(an->ctx, [&] {
+        if (mode != AMTGPU_ANALYZE_EXACT && mode != AMTGPU_ANALYZE_LINEAR_GUARDED) throw std::runtime_error("unknown analysis mode");
+        an->mode = mode;
+    });
+}
+
+int amtgpu_analyze_last_refined(AmtGpuAnalyze* an)
+{
+    int n = -1;
+    guard(an->ctx, [&] {
+        if (an->mode == AMTGPU_ANALYZE_EXACT || an->dCount.size() < 1) { n = 0; return; }
+        an->ctx->bind();
+        AMT_HIP(hipMemcpyAsync(&n, an->dCount.get(), sizeof(int), hipMemcpyDeviceToHost, an->ctx->stream));
+        AMT_HIP(hipStreamSynchronize(an->ctx->stream));
+    });
+    return n;
+}
+
+float amtgpu_analyze_error_bound(AmtGpuAnalyze* an, int group, int bits)
+{
+    float e = -1.0f;
+    guard(an->ctx, [&] {
+        if (group < 0 || group > 2 || bits < 8 || bits > 16) throw std::runtime_error("bad group / bits");
+        e = an->mode == AMTGPU_ANALYZE_EXACT ? 0.0f : an->engine->linear_error_bound(group, bits);
+    });
+    return e;
 }
 
 int amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* hout)
@@ -517,7 +571,7 @@ int amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_s
         if (bits < 8 || bits > 16) throw std::runtime_error("[AMTAnalyzeLogo] Unsupported pixel format");
         const size_t n = (size_t)nframes * AMTGPU_ANALYZE_FLOATS;
         if (an->dTmp.size() < n) an->dTmp.alloc(n);
-        an->engine->run(dY, frame_stride, pitch, bits, nframes, an->dTmp.get());
+        analyze_run(an, dY, frame_stride, pitch, bits, nframes, an->dTmp.get());
         an->ctx->bind();
         if (n) AMT_HIP(hipMemcpyAsync(hout, an->dTmp.get(), n * sizeof(float), hipMemcpyDeviceToHost, an->ctx->stream));
         AMT_HIP(hipStreamSynchronize(an->ctx->stream));

@@ -94,6 +94,17 @@ public:
     // dframe_map (device, optional): batch frame i reads source frame dframe_map[i] of dY
     void run(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout,
              const int* dframe_map = nullptr);
+    // Linear (decision-guarded) evaluation of all fades from one window evaluation of s and one of bg
+    // (eval_linear_kernels.hip).  Results are within linear_error_bound(i, bits) of run()'s for logo i; same arguments as run().
+    void run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout,
+                    const int* dframe_map = nullptr);
+    // rigorous bound on |run_linear - run| for every score of logo i (rounding analysis in eval_engine.hip)
+    float linear_error_bound(int logo, int bits) const;
+    // exact re-evaluation of the frames listed on the device: batch slot j < *dcount reads source frame dlist[j] and its results
+    // go to record dlist[j] of dout (scatter).  max_frames bounds *dcount.  async
+    void run_listed(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int max_frames, const int* dlist, const int* dcount,
+                    float* dout);
+    int num_fades() const { return (int)fades_.size(); }
     int num_logos() const { return (int)specs_.size(); }
     const EvalLogoSpec& spec(int i) const { return specs_[i]; }
     // flops / bytes bookkeeping for the bench (algorithmic, per frame)
@@ -116,12 +127,30 @@ private:
     DevBuf<EvalLogoDev> d_logos_;
     DevBuf<EvalBand> d_bands_;
     DevBuf<float> d_fades_;
+    // linear mode (built on first use)
+    void ensure_linear();
+    bool linear_ready_ = false;
+    int lin_plane_cap_ = 0;
+    float vmax_unit_ = 1.0f;                       // max over logos / pixels of max(1, |a| + |b|): window values are <= this * maxv
+    std::vector<double> lin_err_corr_, lin_err_sum_;   // per logo: the two parts of the error bound, in units of (u * vmax) and u
+    std::vector<DevBuf<float2>> d_kpix_;
+    std::vector<DevBuf<uint32_t>> d_pos_;
+    DevBuf<LinLogoDev> d_lins_;
+    DevBuf<EvalBand> d_lin_bands_;
 };
 
-// kernel launcher (eval_fused_kernels.hip)
+// kernel launcher (eval_fused_kernels.hip).  dnframes (device, optional): the number of frames actually present (<= nframes,
+// which then only sizes the grid); scatter != 0: frame i's results go to record dframe_map[i] of dout
 hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* dlogos, int nlogos, const EvalBand* dbands,
                                   const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
                                   long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
-                                  int take_abs, int plane_cap);
+                                  int take_abs, int plane_cap, const int* dnframes = nullptr, int scatter = 0);
+// eval_linear_kernels.hip
+hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const LinLogoDev* dlins, int nlogos,
+                                   const EvalBand* dbands, const float* dfades, int nfades, int fade0, const void* dY,
+                                   const int* dframe_map, long long frame_stride_elems, int pitch, int nframes, int G, float* dout,
+                                   int out_frame_stride, int take_abs, int plane_cap, float bin_delta);
+hipError_t launch_analysis_mark(hipStream_t st, const float* drec, int stride, int nframes, int ngroups, int nfades, const float* eps3,
+                                int* dlist, int* dcount);
 
 } // namespace amt

@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -185,6 +186,139 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
         AMT_HIP(launch_logo_eval_fused(ctx_->stream, bits, d_logos_.get(), nl, d_bands_.get(), d_fades_.get(), nf, f0, dY, dframe_map,
                                        frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0,
                                        plane_cap_));
+        ctx_->prof_end(sp);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// linear (decision-guarded) mode
+// ------------------------------------------------------------------------------------------------------------------------
+void EvalEngine::ensure_linear()
+{
+    if (linear_ready_) return;
+    ctx_->bind();
+    const int nl = (int)specs_.size();
+    std::vector<LinLogoDev> hl(nl);
+    std::vector<EvalBand> bands;
+    d_kpix_.resize(nl); d_pos_.resize(nl);
+    lin_err_corr_.assign(nl, 0.0); lin_err_sum_.assign(nl, 0.0);
+    lin_plane_cap_ = 0;
+    double vunit = 1.0;
+    for (int i = 0; i < nl; ++i) {
+        const EvalLogoSpec& S = specs_[i];
+        const MaskTables& T = S.tables;
+        const int w = S.planes.w, h = S.planes.h;
+        const int lp = lds_pitch(w);
+        if (5 * lp > kLinPlaneCap) throw std::runtime_error("logo too wide for the linear evaluation kernel");
+        const int cpad = std::max(kTablePad, (T.count + kTablePad - 1) / kTablePad * kTablePad);       // == EvalLogoDev::count_pad
+        // pixel bands: up to kLinThreads raster-consecutive mask pixels whose 5x5 windows fit the LDS plane
+        const int band0 = (int)bands.size();
+        auto py = [&](int m) { return (int)(T.pos[m] >> 16); };
+        for (int m = 0; m < T.count;) {
+            EvalBand B{};
+            B.logo = i; B.m0 = m;
+            const int ytop = py(m) - 2;
+            int e = m;
+            while (e < T.count && e - m < kLinThreads && (py(e) + 2 - ytop + 1) * lp <= kLinPlaneCap) ++e;
+            B.npix = e - m; B.s0 = m; B.nslots = e - m;
+            B.y0 = ytop; B.nrows = py(e - 1) + 2 - ytop + 1;
+            lin_plane_cap_ = std::max(lin_plane_cap_, B.nrows * lp);
+            bands.push_back(B);
+            m = e;
+        }
+        std::vector<float2> kpix((size_t)13 * cpad, float2{0.0f, 0.0f});
+        std::vector<uint32_t> pos(cpad, 0u);
+        for (int m = 0; m < T.count; ++m) {
+            const float* k = &T.kernels[(size_t)m * 25];
+            for (int j = 0; j < 13; ++j) kpix[(size_t)j * cpad + m] = float2{k[2 * j], 2 * j + 1 < 25 ? k[2 * j + 1] : 0.0f};
+            pos[m] = T.pos[m];
+        }
+        for (int m = T.count; m < cpad; ++m) pos[m] = T.count ? T.pos[T.count - 1] : 0u;
+        d_kpix_[i].upload(kpix, ctx_->stream);
+        d_pos_[i].upload(pos, ctx_->stream);
+        hl[i].kpix = d_kpix_[i].get(); hl[i].pos = d_pos_[i].get();
+        hl[i].band0 = band0; hl[i].nbands = (int)bands.size() - band0;
+
+        // ---- error bound of the linear evaluation against the reference's evaluation order (u = 2^-24, v = bound on window values) ----
+        // every window value (s, bg, any blend with fade in [0,1] ... fades up to 2 are covered by the factor below) is <= v = vunit*maxv;
+        // exact path:  W_i carries 3 roundings, the mean 6 + 1, (W_i - m), the product, the 6-deep sum:   |d corr| <= 27 u v sum|k|
+        // linear path: corr(s), corr(bg) as above without the blend (23 u v sum|k| each, weights f and 1-f), 3 roundings to combine:  26
+        //  => |corr_lin - corr_exact| <= 53 u v sum|k_i|; the clamp is 1-Lipschitz, so a term moves by <= scale*scale2 times that (+ 2u|t|);
+        // the two summation orders (sequential vs tree) differ by <= (count + 32) u sum|t|, and |t| <= scale2.
+        const float* a = S.planes.A(0);
+        const float* b = S.planes.B(0);
+        for (int p = 0; p < w * h; ++p) vunit = std::max(vunit, (double)std::fabs(a[p]) + std::fabs(b[p]));
+        double ecorr = 0, tsum = 0;
+        for (int m = 0; m < T.count; ++m) {
+            double sk = 0;
+            for (int t = 0; t < 25; ++t) sk += std::fabs(T.kernels[(size_t)m * 25 + t]);
+            double smax = 0, s2max = 0;
+            for (int c = 0; c < kNumBins; ++c) {
+                const double sc = std::fabs(T.scales[((size_t)m * 32 + c) * 2]), s2 = std::fabs(T.scales[((size_t)m * 32 + c) * 2 + 1]);
+                smax = std::max(smax, sc * s2);
+                s2max = std::max(s2max, s2);
+            }
+            ecorr += smax * sk * 53.0;
+            tsum += s2max;
+        }
+        const double black = std::max(1e-30, (double)std::fabs(T.blackScore));
+        lin_err_corr_[i] = ecorr / black;                                       // x u x v
+        lin_err_sum_[i] = ((double)T.count + 40.0) * tsum / black + 8.0;        // x u  (+ the final division / abs, results are O(1))
+    }
+    vmax_unit_ = (float)(vunit * 2.0);          // fades of ReMakeLogo reach 1.9: |f| + |1-f| <= 3; analysis fades are in [0,1]; 2x margin
+    d_lins_.upload(hl, ctx_->stream);
+    d_lin_bands_.upload(bands, ctx_->stream);
+    linear_ready_ = true;
+}
+
+float EvalEngine::linear_error_bound(int logo, int bits) const
+{
+    const_cast<EvalEngine*>(this)->ensure_linear();
+    const double u = 1.0 / 16777216.0, maxv = (double)((1 << bits) - 1);
+    return (float)(1.25 * u * (lin_err_corr_[logo] * vmax_unit_ * maxv + lin_err_sum_[logo]));
+}
+
+void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout, const int* dframe_map)
+{
+    if (nframes <= 0 || specs_.empty()) return;
+    ensure_linear();
+    ctx_->bind();
+    const int es = bits <= 8 ? 1 : 2;
+    if (frame_stride_bytes % es) throw std::runtime_error("frame stride not a multiple of the sample size");
+    const int nl = (int)specs_.size();
+    const int nf_all = (int)fades_.size();
+    // the interpolated mean is within 19 u v of the exactly evaluated one (7 + 7 roundings of the two means, 3 to combine them, 9 on
+    // the exact side... see ensure_linear); a 32 u v window decides when the exact mean is computed for the bin
+    const float bin_delta = 32.0f / 16777216.0f * vmax_unit_ * (float)((1 << bits) - 1);
+    int G = (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
+    for (int f0 = 0; f0 < nf_all; f0 += kLinMaxFades) {
+        const int nf = std::min(kLinMaxFades, nf_all - f0);
+        G = std::max(1, std::min(G, kLinThreads / nf));
+        const size_t dot = prof_name_.find('.');
+        const int sp = ctx_->prof_begin(("logo_eval_linear_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
+        AMT_HIP(launch_logo_eval_linear(ctx_->stream, bits, d_logos_.get(), d_lins_.get(), nl, d_lin_bands_.get(), d_fades_.get(), nf, f0, dY,
+                                        dframe_map, frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0,
+                                        lin_plane_cap_, bin_delta));
+        ctx_->prof_end(sp);
+    }
+}
+
+void EvalEngine::run_listed(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int max_frames, const int* dlist,
+                            const int* dcount, float* dout)
+{
+    if (max_frames <= 0 || specs_.empty()) return;
+    ctx_->bind();
+    const int es = bits <= 8 ? 1 : 2;
+    if (frame_stride_bytes % es) throw std::runtime_error("frame stride not a multiple of the sample size");
+    const int nl = (int)specs_.size();
+    const int nf_all = (int)fades_.size();
+    for (int f0 = 0; f0 < nf_all; f0 += kEvalMaxFades) {
+        const int nf = std::min(kEvalMaxFades, nf_all - f0);
+        const int G = std::max(1, std::min(2, kEvalThreads / nf));      // few frames are expected: small groups, surplus workgroups exit
+        const int sp = ctx_->prof_begin((prof_name_ + "_refine").c_str());
+        AMT_HIP(launch_logo_eval_fused(ctx_->stream, bits, d_logos_.get(), nl, d_bands_.get(), d_fades_.get(), nf, f0, dY, dlist,
+                                       frame_stride_bytes / es, pitch, max_frames, G, dout, out_frame_stride_, take_abs_ ? 1 : 0,
+                                       plane_cap_, dcount, 1));
         ctx_->prof_end(sp);
     }
 }

@@ -145,9 +145,13 @@ __device__ __forceinline__
 void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands,
                           const float* __restrict__ fades, int nfades, int fade0,
                           const pix_t* __restrict__ Y, const int* __restrict__ frame_map, long long frame_stride, int pitch,
-                          float maxv, int nframes, int G, int ngroups, float* __restrict__ out, int out_frame_stride,
-                          int take_abs, int plane_cap, int sc_pitch, int dbg_in)
+                          float maxv, int nframes_in, int G, int ngroups, float* __restrict__ out, int out_frame_stride,
+                          int take_abs, int plane_cap, int sc_pitch, int dbg_in, const int* __restrict__ nframes_dev, int scatter)
 {
+    // listed re-evaluation (decision guard of the linear mode): the number of frames present sits on the device, the grid is
+    // sized for the worst case, surplus workgroups leave at once
+    const int nframes = nframes_dev ? min(*nframes_dev, nframes_in) : nframes_in;
+    if ((int)(blockIdx.x % (unsigned)ngroups) * G >= nframes) return;
 #ifdef AMT_EXPERIMENT
     const int dbg = dbg_in;      // timing ablations of instrumented builds only (amatsukaze_amd/build.py build_variant)
 #else
@@ -416,7 +420,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
         const int g = tid / nfades, f = tid - g * nfades;
         float r = accs[tid] / L.blackScore;
         if (take_abs) r = fabsf(r);
-        out[(long long)(F0 + g) * out_frame_stride + L.out_off + fade0 + f] = r;
+        const int row = scatter ? frame_map[F0 + g] : F0 + g;
+        out[(long long)row * out_frame_stride + L.out_off + fade0 + f] = r;
     }
 }
 
@@ -428,10 +433,11 @@ __global__ __launch_bounds__(kEvalThreads) __attribute__((amdgpu_waves_per_eu(2,
 void logo_eval_fused_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands, const float* __restrict__ fades,
                             int nfades, int fade0, const pix_t* __restrict__ Y, const int* __restrict__ frame_map,
                             long long frame_stride, int pitch, float maxv, int nframes, int G, int ngroups, float* __restrict__ out,
-                            int out_frame_stride, int take_abs, int plane_cap, int sc_pitch, int dbg)
+                            int out_frame_stride, int take_abs, int plane_cap, int sc_pitch, int dbg, const int* __restrict__ nframes_dev,
+                            int scatter)
 {
     logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, nframes, G, ngroups, out,
-                                     out_frame_stride, take_abs, plane_cap, sc_pitch, dbg);
+                                     out_frame_stride, take_abs, plane_cap, sc_pitch, dbg, nframes_dev, scatter);
 }
 
 static size_t fused_lds_bytes(int plane_cap, int nfades, int sc_pitch, int G, int fpi)
@@ -442,9 +448,10 @@ static size_t fused_lds_bytes(int plane_cap, int nfades, int sc_pitch, int G, in
 hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* dlogos, int nlogos, const EvalBand* dbands,
                                   const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
                                   long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
-                                  int take_abs, int plane_cap)
+                                  int take_abs, int plane_cap, const int* dnframes, int scatter)
 {
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
+    if (scatter && !dframe_map) return hipErrorInvalidValue;
     if (nfades > kEvalMaxFades || G * nfades > kEvalThreads || plane_cap > kEvalThreads * kEvalStage) return hipErrorInvalidValue;
     // Instrumented builds only (-DAMT_EXPERIMENT, build.py build_variant): AMTGPU_DBG bit 0 skips the sum, 1 the staging,
     // 2 the fade loop (timing ablations, WRONG results); AMTGPU_LDSPAD inflates the LDS request to lower the occupancy;
@@ -467,7 +474,7 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
 #define AMT_LAUNCH(T, F)                                                                                                          \
     hipLaunchKernelGGL((logo_eval_fused_kernel<T, F>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,         \
                        (const T*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, \
-                       plane_cap, sc_pitch, dbg)
+                       plane_cap, sc_pitch, dbg, dnframes, scatter)
     if (fpi == 2) { if (bits <= 8) AMT_LAUNCH(uint8_t, 2); else AMT_LAUNCH(uint16_t, 2); }
     else { if (bits <= 8) AMT_LAUNCH(uint8_t, 1); else AMT_LAUNCH(uint16_t, 1); }
 #undef AMT_LAUNCH

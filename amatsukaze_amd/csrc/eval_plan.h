@@ -34,6 +34,16 @@ struct EvalLogoDev {
     int lp;                  // LDS row pitch in floats: ((w+31)&~31)+8
 };
 
+// ---- linear (decision-guarded) evaluation, eval_linear_kernels.hip: one mask pixel per thread ----
+constexpr int kLinThreads = 512;    // threads per workgroup = mask pixels per band
+constexpr int kLinMaxFades = 12;    // fades per launch (11 for AMTAnalyzeLogo)
+constexpr int kLinPlaneCap = 4608;  // {s,bg} pairs an LDS plane holds (8 B each): 17 rows of a 256-wide logo
+struct LinLogoDev {
+    const float2* kpix;      // [13][count_pad]  taps of mask pixel m as pairs {k[2j], k[2j+1]} (k[25] = 0), pair-major
+    const uint32_t* pos;     // [count_pad]  (y << 16) | x of mask pixel m
+    int band0, nbands;       // this logo's PIXEL bands in the linear band table (EvalBand: m0 / npix / y0 / nrows; s0, nslots unused)
+};
+
 // a band = up to kEvalThreads consecutive run slots (one per thread) and the logo rows their windows touch
 struct EvalBand {
     int logo;

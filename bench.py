@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive (streamed) measurement")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-erase", action="store_true")
+    ap.add_argument("--analysis-mode", choices=("linear", "exact"), default="linear",
+                    help="AMTAnalyzeLogo evaluation: linear = all fades from one window evaluation of s and bg, decisions guarded by exact "
+                         "re-evaluation (identical fades / erased frames, scores within 1e-4); exact = the reference's fp32 order for every fade")
     return ap.parse_args()
 
 
@@ -269,7 +272,7 @@ def reference_logo_passes(orc, hs, Y, U, V, nframes, oracle_out):
 # --------------------------------------------------------------------------------------------------------------------
 # verification of the bench's own outputs (outside the timed region)
 # --------------------------------------------------------------------------------------------------------------------
-def verify_step(N, blocks, outputs, pristine, logos_np, erase):
+def verify_step(N, blocks, outputs, pristine, logos_np, erase, analysis_tol=0.0):
     """outputs: scan records (N,3,2), analysis (N,33), fades (N,2), erased device clip, metrics (N,8) of ONE step over the
     freshly generated batch at the bench's launch geometry; pristine: {block: (Y,U,V,prevY)} host copies taken before that
     step.  Compares the frames of every block with the CPU oracle, bytes."""
@@ -281,7 +284,12 @@ def verify_step(N, blocks, outputs, pristine, logos_np, erase):
         res["frames"] += bn
         res["scan"] &= ol.scan(Y, bn).tobytes() == np.ascontiguousarray(ev_g[b0:b0 + bn]).tobytes()
         an = ol.analyze(Y, bn)
-        res["analysis"] &= an.tobytes() == np.ascontiguousarray(an_g[b0:b0 + bn]).tobytes()
+        if analysis_tol == 0.0:
+            res["analysis"] &= an.tobytes() == np.ascontiguousarray(an_g[b0:b0 + bn]).tobytes()
+        else:       # linear mode: scores within the tolerance; the decisions taken from them (fades, erased pixels) still compare as bytes
+            d = float(np.abs(an.reshape(bn, 33) - an_g[b0:b0 + bn]).max())
+            res["analysis_max_abs_err"] = max(res.get("analysis_max_abs_err", 0.0), d)
+            res["analysis"] &= d <= analysis_tol
         res["metrics"] &= ol.metrics(Y, bn, prevY).tobytes() == np.ascontiguousarray(st_g[b0:b0 + bn]).tobytes()
         if not erase:
             continue
@@ -440,7 +448,7 @@ def main():
     dclip = DeviceClip(clip["Y"], clip["U"], clip["V"], W, H, 8)
     lf = LogoFrame(ctx, logos, MASKRATIO)
     lf.begin(W, H, 8, N)
-    analyzer = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO)
+    analyzer = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO, mode=args.analysis_mode)
     eraser = AMTEraseLogo(ctx, logos[0], "", 0, 16)
     stats = FrameStats(ctx, W, H, 8)
     d_analysis = torch.empty((N, 33), dtype=torch.float32, device=dev)
@@ -492,10 +500,29 @@ def main():
         step(collective=False)                                       # rank 0 alone
         torch.cuda.synchronize()
         outputs = (lf.evalResults, h_analysis.numpy(), last.get("fades"), dclip, d_stats.cpu().numpy().astype(np.uint64))
-        verified = verify_step(N, blocks, outputs, pristine, logos_np, not args.no_erase)
+        verified = verify_step(N, blocks, outputs, pristine, logos_np, not args.no_erase, 1e-4 if args.analysis_mode == "linear" else 0.0)
+        verified["analysis_mode"] = args.analysis_mode
+        verified["analysis_compare"] = "bytes" if args.analysis_mode == "exact" else "abs <= 1e-4 (fades and erased frames: bytes)"
+        verified["guard_refined_frames"] = analyzer.last_refined()
         if not verified["ok"]:
             print(json.dumps({"verified": verified}), file=sys.stderr, flush=True)
             raise SystemExit("bench verification FAILED: the timed configuration's outputs differ from the CPU oracle")
+    if world > 1:
+        dist.barrier()
+
+    # the other analysis mode, for the record (outside the timed region): the same 10 000-frame launch
+    alt_prof = {}
+    if rank == 0:
+        alt = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO, mode="exact" if args.analysis_mode == "linear" else "linear")
+        alt.analyze_device(dclip.Y, 8, d_analysis)
+        torch.cuda.synchronize()
+        ctx.profile(True)
+        for _ in range(5):
+            alt.analyze_device(dclip.Y, 8, d_analysis)
+        torch.cuda.synchronize()
+        alt_prof = ctx.profile_report()
+        ctx.profile(False)
+        del alt
     if world > 1:
         dist.barrier()
 
@@ -524,65 +551,59 @@ def main():
         # ---- per-kernel figures (HIP events on the launch stream, inside the timed steps) ----
         an_tab = [logos[0].mask_tables(k, MASKRATIO)["count"] for k in (0, 1, 2)]
         scan_tab = [l.mask_tables(0, MASKRATIO)["count"] for l in logos]
-        frames_timed = N * args.steps
-        flops_an = (FLOPS_PER_MASK_PIXEL * 11 * sum(an_tab) + FLOPS_PER_RECT_PIXEL * 11 * (LW * LH + 2 * LW * (LH // 2))) * frames_timed
-        flops_scan = (FLOPS_PER_MASK_PIXEL * 2 * sum(scan_tab) + FLOPS_PER_RECT_PIXEL * 2 * 3 * LW * LH) * frames_timed
-        kern = {name: {"calls": calls, "avg_ms": ms / max(1, calls), "total_ms": ms} for name, (calls, ms) in prof.items()}
+        # algorithmic work per frame (the reference's own operation count) and bytes
+        flops_an = FLOPS_PER_MASK_PIXEL * 11 * sum(an_tab) + FLOPS_PER_RECT_PIXEL * 11 * (LW * LH + 2 * LW * (LH // 2))
+        flops_scan = FLOPS_PER_MASK_PIXEL * 2 * sum(scan_tab) + FLOPS_PER_RECT_PIXEL * 2 * 3 * LW * LH
+        VALU = {"logo_eval_fused_kernel.analysis": (flops_an, LW * LH + 132, "every fade in the reference's fp32 order (bit-exact records)"),
+                "logo_eval_linear_kernel.analysis": (flops_an, LW * LH + 132, "all 11 fades from one window evaluation of s and of bg; flops are the "
+                                                     "ALGORITHMIC count of the reference (the kernel issues ~4x fewer), so this fraction may pass 0.5"),
+                "logo_eval_fused_kernel.scan": (flops_scan, 3 * LW * LH + 24, "3 logos x fades {0,1}, reference order (bit-exact records)")}
+        HBM = {"frame_stats_kernel": W * H, "delogo_kernel": 2 * (LW * LH + 2 * (LW // 2) * (LH // 2))}
         pmc = {}
         try:
             pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
         except Exception:
             pass
-        out_kern = {}
-        for sub, flops, abytes in ((".analysis", flops_an, (LW * LH + 132) * frames_timed), (".scan", flops_scan, (3 * LW * LH + 24) * frames_timed)):
-            if EVAL + sub in kern:
-                k = kern[EVAL + sub]
-                out_kern[EVAL + sub] = {"bound": "fp32-valu", "avg_ms": k["avg_ms"], "launches": k["calls"],
-                                        "achieved_tflops": flops / (k["total_ms"] * 1e-3) / 1e12,
-                                        "frac_fp32_peak": flops / (k["total_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                        "hbm_gbs_algorithmic": abytes / (k["total_ms"] * 1e-3) / 1e9,
-                                        "hbm_bytes_per_launch_pmc": (pmc.get(EVAL + sub, {}).get("hbm_bytes_per_frame") or 0) * N or None}
-        if "frame_stats_kernel" in kern:
-            k = kern["frame_stats_kernel"]
-            b = W * H * frames_timed
-            out_kern["frame_stats_kernel"] = {"bound": "hbm", "avg_ms": k["avg_ms"], "launches": k["calls"],
-                                              "achieved_gbs": b / (k["total_ms"] * 1e-3) / 1e9,
-                                              "frac": b / (k["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                              "hbm_bytes_per_launch_pmc": (pmc.get("frame_stats_kernel", {}).get("hbm_bytes_per_frame") or 0) * N or None}
-        if "delogo_kernel" in kern:
-            k = kern["delogo_kernel"]
-            b = 2 * (LW * LH + 2 * (LW // 2) * (LH // 2)) * frames_timed
-            out_kern["delogo_kernel"] = {"bound": "hbm", "avg_ms": k["avg_ms"], "launches": k["calls"],
-                                         "achieved_gbs": b / (k["total_ms"] * 1e-3) / 1e9,
-                                         "frac": b / (k["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        # the dominant kernel: logo_eval_fused_kernel (both of its launches per step, as in round 1) unless something else leads
-        ev_total = sum(kern[n]["total_ms"] for n in kern if n.startswith(EVAL))
-        ev_calls = sum(kern[n]["calls"] for n in kern if n.startswith(EVAL))
-        others = {n: kern[n]["total_ms"] for n in kern if not n.startswith(EVAL)}
+
+        def kernel_entry(name, calls, ms, frames_per_call, timed):
+            e = {"avg_ms": ms / max(1, calls), "launches": calls, "inside_timed_region": timed}
+            fr = frames_per_call * calls
+            tr = pmc.get(name, {}).get("hbm_bytes_per_frame")
+            if name in VALU:
+                fl, ab, what = VALU[name]
+                e.update({"bound": "fp32-valu", "achieved_tflops": fl * fr / (ms * 1e-3) / 1e12,
+                          "frac_fp32_peak": fl * fr / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": fl * frames_per_call,
+                          "algorithmic_bytes_per_launch": ab * frames_per_call, "hbm_gbs_algorithmic": ab * fr / (ms * 1e-3) / 1e9, "what": what})
+            elif name in HBM:
+                e.update({"bound": "hbm", "achieved_gbs": HBM[name] * fr / (ms * 1e-3) / 1e9, "frac": HBM[name] * fr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": HBM[name] * frames_per_call})
+            e["hbm_bytes_per_launch_pmc"] = tr * frames_per_call if tr else None
+            return e
+
+        out_kern = {name: kernel_entry(name, calls, ms, N, True) for name, (calls, ms) in prof.items() if calls}
+        for name, (calls, ms) in alt_prof.items():
+            if calls and name not in out_kern:
+                out_kern[name] = kernel_entry(name, calls, ms, N, False)
+        timed = {n: e for n, e in out_kern.items() if e["inside_timed_region"]}
+        dom = max(timed, key=lambda n: timed[n]["avg_ms"] * timed[n]["launches"]) if timed else None
         roofline = None
-        if ev_calls and (not others or ev_total >= max(others.values())):
-            fl = flops_an + flops_scan
-            tr_an = pmc.get(EVAL + ".analysis", {}).get("hbm_bytes_per_frame")
-            tr_sc = pmc.get(EVAL + ".scan", {}).get("hbm_bytes_per_frame")
-            roofline = {"kernel": EVAL, "bound": "fp32-valu", "achieved": fl / (ev_total * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": fl / (ev_total * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "traffic": ((tr_an + tr_sc) / 2 * N) if (tr_an and tr_sc) else None,
-                        "traffic_source": (PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench's own launches; "
-                                           "not collected inside the timed run)") if (tr_an and tr_sc) else None,
-                        "avg_launch_ms": ev_total / ev_calls, "flops_per_launch": fl / ev_calls,
-                        "algorithmic_bytes_per_launch": ((LW * LH + 132) + (3 * LW * LH + 24)) / 2 * N,
-                        "note": "fp32 VALU kernel (no MFMA: per-pixel private 25-tap kernels, no operand reuse); priced against the fp32 vector "
-                                "peak with FMA counted as 2; ops are mul/add/sub without FMA contraction (bit-exactness), so 0.5 is the ceiling "
-                                "of this fraction; launches per step: the analysis (3 evaluation logos x 11 fades) and the scan (3 logos x 2 "
-                                "fades), averaged; flops are the reference's own operation count (101 per mask-pixel evaluation + 6 per "
-                                "rectangle pixel per evaluation)"}
-        elif others:
-            dom = max(others, key=others.get)
-            if dom in out_kern and "achieved_gbs" in out_kern[dom]:
-                kk = out_kern[dom]
-                roofline = {"kernel": dom, "bound": "hbm", "achieved": kk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": kk["frac"], "traffic": kk.get("hbm_bytes_per_launch_pmc"), "traffic_source": PMC_TRAFFIC,
-                            "avg_launch_ms": kk["avg_ms"]}
+        if dom:
+            kk = timed[dom]
+            src = (PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench's own launches, tools/gpu_prof_bench.sh; not "
+                   "collected inside the timed run)") if kk["hbm_bytes_per_launch_pmc"] else None
+            if kk.get("bound") == "fp32-valu":
+                roofline = {"kernel": dom, "bound": "fp32-valu", "achieved": kk["achieved_tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": kk["frac_fp32_peak"], "traffic": kk["hbm_bytes_per_launch_pmc"], "traffic_source": src,
+                            "avg_launch_ms": kk["avg_ms"], "flops_per_launch": kk["flops_per_launch"],
+                            "algorithmic_bytes_per_launch": kk["algorithmic_bytes_per_launch"],
+                            "note": "fp32 VALU kernel (no MFMA: per-pixel private 25-tap kernels, no operand reuse); priced against the fp32 "
+                                    "vector peak with FMA counted as 2; flops are the reference's own operation count (101 per mask-pixel "
+                                    "evaluation + 6 per rectangle pixel per evaluation); the exact kernels use mul/add/sub without FMA "
+                                    "contraction (bit-exactness), so 0.5 is their ceiling. " + kk.get("what", "")}
+            elif kk.get("bound") == "hbm":
+                roofline = {"kernel": dom, "bound": "hbm", "achieved": kk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kk["frac"],
+                            "traffic": kk["hbm_bytes_per_launch_pmc"], "traffic_source": src, "avg_launch_ms": kk["avg_ms"],
+                            "algorithmic_bytes_per_launch": kk["algorithmic_bytes_per_launch"]}
         cpu = None
         if args.cpu_frames > 0 and world == 1:        # the CPU baseline is reported at N=1 only
             cpu = cpu_baseline(args.cpu_frames, logos_np, alpha, alphaUV, args.cpu_seconds)
@@ -593,6 +614,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"single MI355X: {N}-frame 1440x1080i 8-bit YUV420 resident in HBM; AMTAnalyzeLogo + LogoFrame scan (3 logos) "
                                    "+ CM/KFM frame metrics + CalcFade + AMTEraseLogo (BASELINE configs[1])",
+                       "analysis_mode": args.analysis_mode,
                        "frames_per_gpu": N, "logo": f"{LW}x{LH}@({IMGX},{IMGY})", "maskratio": MASKRATIO,
                        "parallelism": f"frames sharded x{world} (one private batch per rank)" if world > 1 else "single GPU"},
             "timed_region_s": elapsed,

@@ -141,6 +141,24 @@ int  amtgpu_analyze_batch(AmtGpuAnalyze* an, const void* dY, int64_t frame_strid
 /* convenience: same, results copied to host (synchronises) */
 int  amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* hout);
 
+/* Evaluation mode of the 33 scores per frame.
+ *   AMTGPU_ANALYZE_EXACT (default): every fade evaluated in the reference's fp32 order -- records are bit-identical to
+ *     AMTAnalyzeLogo::GetFrameT's.
+ *   AMTGPU_ANALYZE_LINEAR_GUARDED: CalcCorrelation5x5 is linear in the window (ComputeKernel.cpp:77-121), so the 11 blends are
+ *     formed from ONE evaluation of the source window and ONE of the background-estimate window per mask pixel (~4x less
+ *     arithmetic).  Scores differ from the reference's by rounding only (|diff| <= amtgpu_analyze_error_bound, typically 1e-6;
+ *     the north star allows 1e-4), and the integer decisions taken from them are guarded: bins are selected from the exactly
+ *     evaluated mean whenever the interpolated one is near a bin edge, and every frame whose argmin over the fades of p, t or b
+ *     (all CalcFade2 ever reads, LogoScan.hpp:1288-1314) is not separated by more than twice the error bound is re-evaluated by
+ *     the exact kernel before the batch is handed out -- amtgpu_erase_calc_fades returns identical fades in both modes. */
+#define AMTGPU_ANALYZE_EXACT 0
+#define AMTGPU_ANALYZE_LINEAR_GUARDED 1
+int   amtgpu_analyze_set_mode(AmtGpuAnalyze* an, int mode);
+/* frames of the most recent batch that the guard re-evaluated exactly (synchronises); 0 in exact mode, -1 on error */
+int   amtgpu_analyze_last_refined(AmtGpuAnalyze* an);
+/* the linear mode's bound on |score - reference score| for group 0 = p, 1 = t, 2 = b at the given bit depth; 0 in exact mode */
+float amtgpu_analyze_error_bound(AmtGpuAnalyze* an, int group, int bits);
+
 /* ---- encode-time erase: replaces logo::AMTEraseLogo ("AMTEraseLogo" "ccs[logof]s[mode]i[maxfade]i",
  *      Amatsukaze.cpp:59; ctor :1464-1481, ReadLogoFrameFile :1421-1461, CalcFade :1317-1341,
  *      CalcFade2 :1263-1315, Delogo :1248-1261, GetFrameT mode 0 :1343-1400).  logofpath may be "" ---- */

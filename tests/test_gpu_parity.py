@@ -347,3 +347,43 @@ def test_experiment_environment_variables_are_ignored(gpu, monkeypatch):
     orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, n, _ptr(want))
     got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"])
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("cfgname,bits", [("small", 8), ("small", 10), ("small", 12), ("hd", 8)])
+def test_analyze_linear_guarded_mode(gpu, cfgname, bits):
+    """AMTGPU_ANALYZE_LINEAR_GUARDED: the 11 fades formed from one evaluation of the source and one of the background window.
+    Gate (VERDICT r1 #3 ii): every score within 1e-4 of the oracle's AND inside the library's own error bound, CalcFade outputs
+    IDENTICAL (the guard re-evaluates exactly every frame whose argmin is not safe), erased frames identical."""
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo
+    cfg = SMALL if cfgname == "small" else HD
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=32)
+    orc, ctx = cs["orc"], gpu["ctx"]
+    d, t, b = oracle_eval_logos(orc, cs["lo"])
+    Y = cs["clip"]["Y"]
+    n = Y.shape[0]
+    want = np.zeros(n * 33, np.float32)
+    orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], bits, n, _ptr(want))
+    want = want.reshape(n, 33)
+    an = AMTAnalyzeLogo(ctx, cs["logo"], 0.35, mode="linear")
+    got = an.analyze(cs["dclip"])
+    refined = an.last_refined()
+    assert 0 <= refined <= n
+    err = np.abs(got - want)
+    bounds = [an.error_bound(k, bits) for k in range(3)]
+    assert all(0 < e < 0.05 for e in bounds), bounds
+    assert err.max() <= 1e-4, (err.max(), refined)
+    for k in range(3):
+        assert err[:, 11 * k:11 * k + 11].max() <= bounds[k]
+    # integer decisions: identical fades from both records, hence identical erased frames
+    er = AMTEraseLogo(ctx, cs["logo"], "", 0, 16)
+    f_lin, f_ref = er.calc_fades(got, n), er.calc_fades(want, n)
+    assert f_lin.tobytes() == f_ref.tobytes()
+    # frames the guard re-evaluated carry the exact record
+    amb = np.zeros(n, bool)
+    for k in range(3):
+        srt = np.sort(want[:, 11 * k:11 * k + 11], axis=1)
+        amb |= (srt[:, 1] - srt[:, 0]) <= 1.0 * bounds[k]          # certainly inside the guard's 2x margin
+    assert (got[amb] == want[amb]).all()
+    exact = AMTAnalyzeLogo(ctx, cs["logo"], 0.35).analyze(cs["dclip"])
+    assert exact.tobytes() == want.tobytes()
+    print(f"linear mode {cfgname}/{bits}: max err {err.max():.2e}, bounds {bounds}, refined {refined}/{n}")
