@@ -210,8 +210,9 @@ void EvalEngine::ensure_linear()
         const int w = S.planes.w, h = S.planes.h;
         const int lp = lds_pitch(w);
         if (5 * lp > kLinPlaneCap) throw std::runtime_error("logo too wide for the linear evaluation kernel");
+        if ((size_t)T.count + kTablePad >= (1u << 21)) throw std::runtime_error("logo too large for the linear evaluation kernel");   // 24-bit byte offsets
         const int cpad = std::max(kTablePad, (T.count + kTablePad - 1) / kTablePad * kTablePad);       // == EvalLogoDev::count_pad
-        // pixel bands: up to kLinThreads raster-consecutive mask pixels whose 5x5 windows fit the LDS plane
+        // pixel bands: up to kLinBandPix raster-consecutive mask pixels whose 5x5 windows fit the LDS plane
         const int band0 = (int)bands.size();
         auto py = [&](int m) { return (int)(T.pos[m] >> 16); };
         for (int m = 0; m < T.count;) {
@@ -219,7 +220,7 @@ void EvalEngine::ensure_linear()
             B.logo = i; B.m0 = m;
             const int ytop = py(m) - 2;
             int e = m;
-            while (e < T.count && e - m < kLinThreads && (py(e) + 2 - ytop + 1) * lp <= kLinPlaneCap) ++e;
+            while (e < T.count && e - m < kLinBandPix && (py(e) + 2 - ytop + 1) * lp <= kLinPlaneCap) ++e;
             B.npix = e - m; B.s0 = m; B.nslots = e - m;
             B.y0 = ytop; B.nrows = py(e - 1) + 2 - ytop + 1;
             lin_plane_cap_ = std::max(lin_plane_cap_, B.nrows * lp);
@@ -230,7 +231,9 @@ void EvalEngine::ensure_linear()
         std::vector<uint32_t> pos(cpad, 0u);
         for (int m = 0; m < T.count; ++m) {
             const float* k = &T.kernels[(size_t)m * 25];
-            for (int j = 0; j < 13; ++j) kpix[(size_t)j * cpad + m] = float2{k[2 * j], 2 * j + 1 < 25 ? k[2 * j + 1] : 0.0f};
+            float ksum = 0.0f;
+            for (int t = 0; t < 25; ++t) ksum += k[t];
+            for (int j = 0; j < 13; ++j) kpix[(size_t)j * cpad + m] = float2{k[2 * j], 2 * j + 1 < 25 ? k[2 * j + 1] : ksum};   // [12].y = sum of the taps
             pos[m] = T.pos[m];
         }
         for (int m = T.count; m < cpad; ++m) pos[m] = T.count ? T.pos[T.count - 1] : 0u;
@@ -242,8 +245,10 @@ void EvalEngine::ensure_linear()
         // ---- error bound of the linear evaluation against the reference's evaluation order (u = 2^-24, v = bound on window values) ----
         // every window value (s, bg, any blend with fade in [0,1] ... fades up to 2 are covered by the factor below) is <= v = vunit*maxv;
         // exact path:  W_i carries 3 roundings, the mean 6 + 1, (W_i - m), the product, the 6-deep sum:   |d corr| <= 27 u v sum|k|
-        // linear path: corr(s), corr(bg) as above without the blend (23 u v sum|k| each, weights f and 1-f), 3 roundings to combine:  26
-        //  => |corr_lin - corr_exact| <= 53 u v sum|k_i|; the clamp is 1-Lipschitz, so a term moves by <= scale*scale2 times that (+ 2u|t|);
+        // linear path: corr = sum k_i w_i - mean * sum k_i as two 13-deep FMA chains (<= 14 u sum|k_i w_i| + 2u for the add and the
+        //              mean term, whose own error 7 u v is multiplied by |sum k_i| <= sum|k_i|): 23 u v sum|k|, for s and for bg with
+        //              weights 1-f and f; 3 roundings to combine:  26
+        //  => |corr_lin - corr_exact| <= 53 u v sum|k_i| (58 below); the clamp is 1-Lipschitz, so a term moves by <= scale*scale2 times that (+ 2u|t|);
         // the two summation orders (sequential vs tree) differ by <= (count + 32) u sum|t|, and |t| <= scale2.
         const float* a = S.planes.A(0);
         const float* b = S.planes.B(0);
@@ -258,7 +263,7 @@ void EvalEngine::ensure_linear()
                 smax = std::max(smax, sc * s2);
                 s2max = std::max(s2max, s2);
             }
-            ecorr += smax * sk * 53.0;
+            ecorr += smax * sk * 58.0;
             tsum += s2max;
         }
         const double black = std::max(1e-30, (double)std::fabs(T.blackScore));

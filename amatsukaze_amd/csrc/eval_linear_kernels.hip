@@ -60,6 +60,7 @@ template <> struct Raw4<uint8_t> {
         typedef unsigned __attribute__((aligned(1))) ua_t;
         v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
     }
+    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
     __device__ __forceinline__ int get(int k) const { return (int)((v >> (8 * k)) & 0xFFu); }
 };
 template <> struct Raw4<uint16_t> {
@@ -69,12 +70,14 @@ template <> struct Raw4<uint16_t> {
         typedef u2 __attribute__((aligned(2))) ua_t;
         v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
     }
+    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
     __device__ __forceinline__ int get(int k) const { return (int)((v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu); }
 };
 
 constexpr int kWaves = kLinThreads / 64;
 constexpr int kStageRows = 2;                  // rows a wave stages per trip
 constexpr int kPartPitch = kLinThreads + 4;    // one LDS row of per-pixel terms per fade
+constexpr int kGatherChunk = 6;                // fades whose scale gathers are in flight together
 
 // the 5x5 window of one pixel, element (r, c) at W[r*5+c] = {s, bg}
 __device__ __forceinline__ void load_window(const f2* plane, int woff, int lp, f2 (&W)[25])
@@ -92,22 +95,19 @@ __device__ __forceinline__ f2 window_means(const f2 (&W)[25])
     for (int i = 0; i < 5; ++i) c[i] = ((W[i] + W[5 + i]) + (W[10 + i] + W[15 + i])) + W[20 + i];
     return div25_pk(((c[0] + c[4]) + c[2]) + (c[1] + c[3]));
 }
-// {corr(k, s), corr(k, bg)} (CalcCorrelation5x5_AVX order); taps as pairs Kp[j] = {k[2j], k[2j+1]}, broadcast per use
+// {corr(k, s), corr(k, bg)} = sum_i k_i (w_i - mean) = sum_i k_i w_i - mean * sum_i k_i: 25 packed FMAs + one (this path is not
+// the reference's evaluation order; its rounding is covered by EvalEngine::linear_error_bound).  Taps as pairs
+// Kp[j] = {k[2j], k[2j+1]} with Kp[12].y = sum_i k_i, broadcast per use.
 __device__ __forceinline__ f2 window_corr(const f2 (&Kp)[13], const f2 (&W)[25], f2 M)
 {
-    f2 p[5];
+    f2 acc0 = {0.0f, 0.0f}, acc1 = acc0;         // two chains: the FMAs of one depend on each other
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        f2 t[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int e = r * 5 + i;
-            const f2 kk = (e & 1) ? bc_hi(Kp[e >> 1]) : bc_lo(Kp[e >> 1]);
-            t[r] = kk * (W[e] - M);
-        }
-        p[i] = ((t[0] + t[1]) + (t[2] + t[3])) + t[4];
+    for (int e = 0; e < 25; ++e) {
+        const f2 kk = (e & 1) ? bc_hi(Kp[e >> 1]) : bc_lo(Kp[e >> 1]);
+        if (e & 1) acc1 = __builtin_elementwise_fma(kk, W[e], acc1);
+        else acc0 = __builtin_elementwise_fma(kk, W[e], acc0);
     }
-    return ((p[0] + p[4]) + p[2]) + (p[1] + p[3]);
+    return __builtin_elementwise_fma(-bc_hi(Kp[12]), M, acc0 + acc1);
 }
 // is v within delta of a bin edge that matters: multiples of 8 in [8, 248] ((int)avg clamped to 0..255, >> 3)
 __device__ __forceinline__ bool near_bin_edge(float v, float delta)
@@ -137,17 +137,32 @@ __device__ __forceinline__ float exact_blend_mean(const f2* plane, int woff, int
 
 using namespace lin;
 
-template <typename pix_t>
+// a*s + b*maxv for the four pixels a lane stages, given s; LDS layout {s0,bg0,s1,bg1} {s2,bg2,s3,bg3}
+__device__ __forceinline__ void store_pairs(f2* dst, const f4& sv, const f4& av, const f4& bv, float maxv)
+{
+    f4 lo, hi;
+    lo[0] = sv[0]; lo[1] = unblend_bg(av[0], bv[0], maxv, sv[0]);
+    lo[2] = sv[1]; lo[3] = unblend_bg(av[1], bv[1], maxv, sv[1]);
+    hi[0] = sv[2]; hi[1] = unblend_bg(av[2], bv[2], maxv, sv[2]);
+    hi[2] = sv[3]; hi[3] = unblend_bg(av[3], bv[3], maxv, sv[3]);
+    reinterpret_cast<f4*>(dst)[0] = lo;
+    reinterpret_cast<f4*>(dst)[1] = hi;
+}
+
+// NF > 0: exactly NF fades (11 for AMTAnalyzeLogo: no per-fade branches); NF == 0: nfades <= kLinMaxFades at run time
+template <typename pix_t, int NF>
 __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoDev* __restrict__ lins, const EvalBand* __restrict__ bands,
-                             const float* __restrict__ fades, int nfades, int fade0, const pix_t* __restrict__ Y,
+                             const float* __restrict__ fades, int nfades_rt, int fade0, const pix_t* __restrict__ Y,
                              const int* __restrict__ frame_map, long long frame_stride, int pitch, float maxv, int nframes, int G,
                              int ngroups, float* __restrict__ out, int out_frame_stride, int take_abs, int plane_cap, float bin_delta)
 {
+    constexpr int NFMAX = NF > 0 ? NF : kLinMaxFades;
+    const int nfades = NF > 0 ? NF : nfades_rt;
     extern __shared__ float lds[];
     f2* const plane = reinterpret_cast<f2*>(lds);         // [plane_cap] {s, bg = a*s + b*maxv} of the band's rows, current frame
-    float* const part = lds + 2 * plane_cap;              // [kLinMaxFades][kPartPitch] per-pixel terms of the current (band, frame)
-    float* const accs = part + kLinMaxFades * kPartPitch; // [G][nfades] running sums
+    float* const part = lds + 2 * plane_cap;              // [NFMAX][kPartPitch] per-pixel terms of the current (band, frame)
+    float* const accs = part + NFMAX * kPartPitch;        // [G][nfades] running sums
 
     const int logo = blockIdx.x / ngroups;
     const int grp = blockIdx.x - logo * ngroups;
@@ -157,19 +172,28 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     const LinLogoDev X = lins[logo];
     const gptr_t gA = (gptr_t)L.a, gB = (gptr_t)L.b, gScales = (gptr_t)L.scales, gK = (gptr_t)X.kpix, gPos = (gptr_t)X.pos;
     const unsigned cpad = (unsigned)L.count_pad;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the staging rows' address math stays scalar
     const int w = L.w, lp = L.lp;
     constexpr unsigned ES = sizeof(pix_t);
+    // bin edges in 1/4096 fixed point: a mean within dq of a multiple of 8 takes the exact path
+    const int dq = (int)(bin_delta * 4096.0f) + 2;
 
     if (tid < G * nfades) accs[tid] = 0.0f;
     const int fade_bits = __builtin_bit_cast(int, fades[fade0 + min(lane, nfades - 1)]);     // lane f holds fade f
+    // buffer descriptors: loads below are (descriptor, per-lane column offset, wave-uniform row offset) -- no per-load address math
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.a), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.b), 0, 0x7FFFFFFF, 0x00020000);
 
     // tree sum of the previous iteration's per-pixel terms: wave w owns fades w, w+8; fixed order -> deterministic
     auto reduce_part = [&](int g) {
         for (int f = wave; f < nfades; f += kWaves) {
-            const float4 v0 = *reinterpret_cast<const float4*>(part + f * kPartPitch + 4 * lane);
-            const float4 v1 = *reinterpret_cast<const float4*>(part + f * kPartPitch + 256 + 4 * lane);
-            float s = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kLinThreads / 256; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(part + f * kPartPitch + 256 * q + 4 * lane);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (lane == 0) accs[g * nfades + f] += s;
@@ -183,64 +207,69 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
         const unsigned m = (unsigned)(B.m0 + (act ? tid : 0));
         const unsigned pos = gld<unsigned>(gPos, m * 4u);
         const int woff = ((int)(pos >> 16) - 2 - B.y0) * lp + (int)(pos & 0xFFFFu) - 2;   // plane offset of the window's top-left element
+        const unsigned m8 = m * 8u, cpad8 = cpad * 8u;                                     // byte offsets into the bin-major scale table
         f2 Kp[13];
 #pragma unroll
-        for (int j = 0; j < 13; ++j) Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
+        for (int j = 0; j < 13; ++j) {
+            Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
+            if (!act) Kp[j] = f2{0.0f, 0.0f};          // a surplus thread evaluates to exactly 0 (no branches in the fade code below)
+        }
 
         for (int g = 0; g < gcount; ++g, ++it) {
             const int frame = F0 + g;
             const int srcFrame = frame_map ? frame_map[frame] : frame;
             const gptr_t src = (gptr_t)(Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx);
             // ---- 1. {s, bg} of the band's rows -> LDS: a wave stages 2 consecutive rows x 256 columns per trip, a lane four
-            //      adjacent columns; the [1 2 1] vertical blend of DeintY (LogoScan.hpp:763-780) re-uses the 4 raw rows it loads ----
-            for (int rg = wave * kStageRows; rg < B.nrows; rg += kStageRows * kWaves) {
+            //      adjacent columns.  Row addresses are wave-uniform (scalar base + one per-lane column offset).  Samples are
+            //      converted byte-wise (v_cvt_f32_ubyte*) and the [1 2 1] vertical blend of DeintY (LogoScan.hpp:763-780) is done
+            //      on the floats: every intermediate is an integer below 2^24, so (r0 + 2 r1 + r2 + 2) * 0.25 equals the
+            //      reference's (float)(int sum) / 4.0f bit for bit; bg = a*s + (b*maxv), b*maxv rounded first as in :247 ----
+            const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)src), 0, 0x7FFFFFFF, 0x00020000);
+            for (int rg0 = wave * kStageRows; rg0 < B.nrows; rg0 += kStageRows * kWaves) {
+                const int rg = __builtin_amdgcn_readfirstlane(rg0);      // provably wave-uniform: row offsets go to the scalar operand
                 const int y = B.y0 + rg;
+                // source rows of the trip (uniform): deint reads y-1 .. y+2 clamped to the rectangle, a field logo its own rows
+                int so[kStageRows + 2];
+#pragma unroll
+                for (int j = 0; j < kStageRows + 2; ++j)
+                    so[j] = (L.deint ? min(max(y - 1 + j, 0), L.h - 1) : min(y + max(j - 1, 0), L.h - 1) * L.row_step) * pitch * (int)ES;
                 for (int xg = 0; xg < w; xg += 256) {
                     const int x = xg + 4 * lane;
-                    const int nv = min(4, w - x);
-                    const int xl = nv >= 4 ? x : 0;
-                    Raw4<pix_t> raw[kStageRows + 2];
-                    f4 av[kStageRows], bv[kStageRows];
-                    if (L.deint) {
+                    if (x + 4 <= w) {
+                        Raw4<pix_t> raw[kStageRows + 2];
+                        f4 av[kStageRows], bv[kStageRows];
+#pragma unroll
+                        for (int j = 0; j < kStageRows + 2; ++j) raw[j].load_buf(rS, (unsigned)x * ES, so[j]);
+#pragma unroll
+                        for (int j = 0; j < kStageRows; ++j) {
+                            const int ro = min(y + j, L.h - 1) * w * 4;
+                            av[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)x * 4u, ro, 0));
+                            bv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)x * 4u, ro, 0));
+                        }
+                        f4 fr[kStageRows + 2];
 #pragma unroll
                         for (int j = 0; j < kStageRows + 2; ++j)
-                            raw[j].load(src, (unsigned)(min(max(y - 1 + j, 0), L.h - 1) * pitch + xl) * ES);
-                    } else {
 #pragma unroll
-                        for (int j = 0; j < kStageRows; ++j)
-                            raw[j + 1].load(src, (unsigned)(min(y + j, L.h - 1) * L.row_step * pitch + xl) * ES);
-                        raw[0] = raw[1]; raw[kStageRows + 1] = raw[kStageRows];
-                    }
-#pragma unroll
-                    for (int j = 0; j < kStageRows; ++j) {
-                        const unsigned o = (unsigned)(min(y + j, L.h - 1) * w + xl) * 4u;
-                        av[j] = gld<f4u>(gA, o);
-                        bv[j] = gld<f4u>(gB, o);
-                    }
-                    if (nv >= 4) {
+                            for (int k = 0; k < 4; ++k) fr[j][k] = (float)raw[j].get(k);
 #pragma unroll
                         for (int j = 0; j < kStageRows; ++j) {
                             const int yy = y + j;
                             if (rg + j < B.nrows) {
-                                const bool blend = L.deint && yy != 0 && yy != L.h - 1;
-                                f4 lo, hi;           // {s0,bg0,s1,bg1} {s2,bg2,s3,bg3}
+                                f4 sv;
+                                if (L.deint && yy != 0 && yy != L.h - 1) {       // uniform per row
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    const float s1 = blend ? (float)(raw[j].get(k) + 2 * raw[j + 1].get(k) + raw[j + 2].get(k) + 2) / 4.0f
-                                                           : (float)raw[j + 1].get(k);
-                                    const float g1 = unblend_bg(av[j][k], bv[j][k], maxv, s1);
-                                    if (k < 2) { lo[2 * k] = s1; lo[2 * k + 1] = g1; } else { hi[2 * k - 4] = s1; hi[2 * k - 3] = g1; }
+                                    for (int k = 0; k < 4; ++k) sv[k] = ((fr[j][k] + 2.0f * fr[j + 1][k]) + (fr[j + 2][k] + 2.0f)) * 0.25f;
+                                } else {
+                                    sv = fr[j + 1];
                                 }
-                                f4* dst = reinterpret_cast<f4*>(plane + (rg + j) * lp + x);
-                                dst[0] = lo;
-                                dst[1] = hi;
+                                store_pairs(plane + (rg + j) * lp + x, sv, av[j], bv[j], maxv);
                             }
                         }
-                    } else if (nv > 0) {
+                    } else if (x < w) {            // ragged right edge of a logo whose width is not a multiple of 4: sample by sample
                         for (int j = 0; j < kStageRows && rg + j < B.nrows; ++j) {
                             const int yy = y + j;
                             const bool blend = L.deint && yy != 0 && yy != L.h - 1;
-                            for (int k = 0; k < nv; ++k) {
+                            for (int k = 0; k < w - x; ++k) {
                                 int q0, q1, q2;
                                 if (L.deint) {
                                     q0 = gld<pix_t>(src, (unsigned)(max(yy - 1, 0) * pitch + x + k) * ES);
@@ -263,45 +292,60 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             __syncthreads();                         // B1: plane complete, part rows free again
 
             // ---- 3. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
-            f2 R = {0.0f, 0.0f}, M = R;
-            if (act) {
+            // The taps are loop-invariant, so LICM would hoist their {k,k} broadcasts out of the frame loop and keep 50 registers of
+            // copies; an empty asm makes them opaque per iteration and the broadcast folds into the multiply's op_sel instead.
+#pragma unroll
+            for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
+            f2 R, M;
+            {
                 f2 W[25];
-                load_window(plane, woff, lp, W);
+                load_window(plane, woff, lp, W);     // surplus threads read pixel B.m0's window: finite values, zero taps
                 M = window_means(W);
                 R = window_corr(Kp, W, M);
             }
-            // ---- 4. all fades from the two pairs.  First every fade's bin (a rolled loop: the exact-mean path exists once in
-            //      the code); it passes through the thread's own cell of the still unused part row so that the gathers below
-            //      can sit in statically indexed registers ----
-            if (act) {
-                for (int f = 0; f < nfades; ++f) {
-                    const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
-                    const float omf = 1 - fade;
-                    float mf = fade * M.y + omf * M.x;
-                    if (near_bin_edge(mf, bin_delta)) mf = exact_blend_mean(plane, woff, lp, fade, omf);   // the reference's own value decides
-                    reinterpret_cast<int*>(part)[f * kPartPitch + tid] = score_bin_dev(mf);
-                }
-            }
-            // ---- the scale gathers, all in flight together ----
-            f2 sc[kLinMaxFades];
+            // ---- 4. all fades from the two pairs, kGatherChunk at a time: interpolated mean -> bin -> scale gather (in flight
+            //      together), then correlation and per-pixel term (LogoScan.hpp:305-308).  The bin select is discontinuous: a mean
+            //      within dq of a bin edge is flagged, and the flagged (pixel, fade) pairs -- about 1e-4 of all -- are redone below
+            //      with the mean evaluated exactly as the reference does ----
+            const float m0q = M.x * 4096.0f, dMq = (M.y - M.x) * 4096.0f, dR = R.y - R.x;     // mean in 1/4096 units: m0q + fade * dMq
+            unsigned emin = 0x7FFFu;                                                          // smallest distance (+dq) to a bin edge
 #pragma unroll
-            for (int f = 0; f < kLinMaxFades; ++f) {
-                if (f < nfades && act) {
-                    const int bin = reinterpret_cast<const int*>(part)[f * kPartPitch + tid];
-                    sc[f] = gld<f2>(gScales, (__umul24((unsigned)bin, cpad) + m) * 8u);
-                }
-            }
-            // ---- the correlations and the per-pixel terms (LogoScan.hpp:305-308) ----
+            for (int f0 = 0; f0 < NFMAX; f0 += kGatherChunk) {
+                f2 sc[kGatherChunk];
 #pragma unroll
-            for (int f = 0; f < kLinMaxFades; ++f) {
-                if (f < nfades) {
-                    float t = 0.0f;
-                    if (act) {
+                for (int j = 0; j < kGatherChunk; ++j) {
+                    const int f = f0 + j;
+                    if (f < NFMAX && (NF > 0 || f < nfades)) {
                         const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
-                        const float omf = 1 - fade;
-                        t = score_term(fade * R.y + omf * R.x, sc[f].x, sc[f].y);
+                        const int q = (int)__builtin_fmaf(fade, dMq, m0q);
+                        emin = min(emin, (unsigned)(q + dq) & 0x7FFFu);
+                        sc[j] = gld<f2>(gScales, __umul24((unsigned)min(max(q >> 15, 0), 31), cpad8) + m8);
                     }
-                    part[f * kPartPitch + tid] = t;
+                }
+#pragma unroll
+                for (int j = 0; j < kGatherChunk; ++j) {
+                    const int f = f0 + j;
+                    if (f < NFMAX && (NF > 0 || f < nfades)) {
+                        const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
+                        const float c = __builtin_fmaf(fade, dR, R.x);
+                        part[f * kPartPitch + tid] = __builtin_amdgcn_fmed3f(c * sc[j].x, -1.0f, 1.0f) * sc[j].y;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- a mean near an edge (about 1e-4 of all pixel-fades): exact mean -> the reference's bin; when it differs from the
+            //      interpolated mean's, replace the term ----
+            if (act && emin <= (unsigned)(2 * dq)) {
+                for (int f = 0; f < nfades; ++f) {
+                    const float fade = fades[fade0 + f];
+                    const int q = (int)__builtin_fmaf(fade, dMq, m0q);
+                    if (((unsigned)(q + dq) & 0x7FFFu) > (unsigned)(2 * dq)) continue;
+                    const int bin_lin = min(max(q >> 15, 0), 31);
+                    const int bin_ref = score_bin_dev(exact_blend_mean(plane, woff, lp, fade, 1 - fade));
+                    if (bin_ref != bin_lin) {
+                        const f2 s2 = gld<f2>(gScales, __umul24((unsigned)bin_ref, cpad8) + m8);
+                        part[f * kPartPitch + tid] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fade, dR, R.x) * s2.x, -1.0f, 1.0f) * s2.y;
+                    }
                 }
             }
             prev_g = g;
@@ -327,16 +371,16 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     if (nfades > kLinMaxFades || G * nfades > kLinThreads || plane_cap > kLinPlaneCap) return hipErrorInvalidValue;
     const int ngroups = (nframes + G - 1) / G;
     const float maxv = (float)((1 << bits) - 1);
-    const size_t lds = ((size_t)2 * plane_cap + (size_t)kLinMaxFades * kPartPitch + (size_t)G * nfades) * sizeof(float);
+    const int nfmax = nfades == 11 ? 11 : kLinMaxFades;
+    const size_t lds = ((size_t)2 * plane_cap + (size_t)nfmax * kPartPitch + (size_t)G * nfades) * sizeof(float);
     dim3 grid((unsigned)((long long)ngroups * nlogos));
-    if (bits <= 8)
-        hipLaunchKernelGGL(logo_eval_linear_kernel<uint8_t>, grid, dim3(kLinThreads), lds, st, dlogos, dlins, dbands, dfades, nfades, fade0,
-                           (const uint8_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride,
-                           take_abs, plane_cap, bin_delta);
-    else
-        hipLaunchKernelGGL(logo_eval_linear_kernel<uint16_t>, grid, dim3(kLinThreads), lds, st, dlogos, dlins, dbands, dfades, nfades, fade0,
-                           (const uint16_t*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride,
-                           take_abs, plane_cap, bin_delta);
+#define AMT_LAUNCH(T, N)                                                                                                              \
+    hipLaunchKernelGGL((logo_eval_linear_kernel<T, N>), grid, dim3(kLinThreads), lds, st, dlogos, dlins, dbands, dfades, nfades, fade0,   \
+                       (const T*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, \
+                       plane_cap, bin_delta)
+    if (nfades == 11) { if (bits <= 8) AMT_LAUNCH(uint8_t, 11); else AMT_LAUNCH(uint16_t, 11); }
+    else { if (bits <= 8) AMT_LAUNCH(uint8_t, 0); else AMT_LAUNCH(uint16_t, 0); }
+#undef AMT_LAUNCH
     return hipGetLastError();
 }
 

@@ -36,8 +36,9 @@ struct EvalLogoDev {
 
 // ---- linear (decision-guarded) evaluation, eval_linear_kernels.hip: one mask pixel per thread ----
 constexpr int kLinThreads = 512;    // threads per workgroup = mask pixels per band
+constexpr int kLinBandPix = kLinThreads;
 constexpr int kLinMaxFades = 12;    // fades per launch (11 for AMTAnalyzeLogo)
-constexpr int kLinPlaneCap = 4608;  // {s,bg} pairs an LDS plane holds (8 B each): 17 rows of a 256-wide logo
+constexpr int kLinPlaneCap = 3328;  // {s,bg} pairs an LDS plane holds (8 B each): 12 rows of a 256-wide logo
 struct LinLogoDev {
     const float2* kpix;      // [13][count_pad]  taps of mask pixel m as pairs {k[2j], k[2j+1]} (k[25] = 0), pair-major
     const uint32_t* pos;     // [count_pad]  (y << 16) | x of mask pixel m

@@ -20,6 +20,7 @@ ap.add_argument("--what", default="analyze")
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--logos", type=int, default=1, help="candidate logos of the LogoFrame scan (bench.py: 3)")
+ap.add_argument("--mode", default="exact", help="analysis mode: exact | linear")
 a = ap.parse_args()
 W, H, LW, LH, X, Y0 = 1440, 1080, 256, 128, 1120, 64
 dev = torch.device("cuda:0")
@@ -30,7 +31,7 @@ ctx = Context(0)
 logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
 out = torch.empty((a.frames, 33), dtype=torch.float32, device=dev)
 st = torch.empty((a.frames, 8), dtype=torch.int64, device=dev)
-an = AMTAnalyzeLogo(ctx, logo, 0.35)
+an = AMTAnalyzeLogo(ctx, logo, 0.35, mode=a.mode)
 cands = [logo] + [Logo.from_planes(ctx, S.make_logo(LW, LH, seed=0x10600002 + k, strength=0.5 + 0.1 * k)[0], LW, LH, W, H, X, Y0)
                   for k in range(a.logos - 1)]
 lf = LogoFrame(ctx, cands, 0.35)
