@@ -539,6 +539,7 @@ int amtgpu_analyze_set_mode(AmtGpuAnalyze* an, int mode)
 {
     return guard(an->ctx, [&] {
         if (mode != AMTGPU_ANALYZE_EXACT && mode != AMTGPU_ANALYZE_LINEAR_GUARDED) throw std::runtime_error("unknown analysis mode");
+        if (mode == AMTGPU_ANALYZE_LINEAR_GUARDED) (void)an->engine->linear_error_bound(0, 8);   // builds the tables; throws for logos the kernel does not take (wider than 256)
         an->mode = mode;
     });
 }

@@ -209,7 +209,7 @@ void EvalEngine::ensure_linear()
         const MaskTables& T = S.tables;
         const int w = S.planes.w, h = S.planes.h;
         const int lp = lds_pitch(w);
-        if (5 * lp > kLinPlaneCap) throw std::runtime_error("logo too wide for the linear evaluation kernel");
+        if (5 * lp > kLinPlaneCap || w > 256 || w < 4) throw std::runtime_error("logo too wide for the linear evaluation kernel");
         if ((size_t)T.count + kTablePad >= (1u << 21)) throw std::runtime_error("logo too large for the linear evaluation kernel");   // 24-bit byte offsets
         const int cpad = std::max(kTablePad, (T.count + kTablePad - 1) / kTablePad * kTablePad);       // == EvalLogoDev::count_pad
         // pixel bands: up to kLinBandPix raster-consecutive mask pixels whose 5x5 windows fit the LDS plane
@@ -220,7 +220,7 @@ void EvalEngine::ensure_linear()
             B.logo = i; B.m0 = m;
             const int ytop = py(m) - 2;
             int e = m;
-            while (e < T.count && e - m < kLinBandPix && (py(e) + 2 - ytop + 1) * lp <= kLinPlaneCap) ++e;
+            while (e < T.count && e - m < kLinBandPix && (py(e) + 2 - ytop + 1) * lp <= kLinPlaneCap && py(e) + 2 - ytop + 1 <= kLinBandRows) ++e;
             B.npix = e - m; B.s0 = m; B.nslots = e - m;
             B.y0 = ytop; B.nrows = py(e - 1) + 2 - ytop + 1;
             lin_plane_cap_ = std::max(lin_plane_cap_, B.nrows * lp);

@@ -149,7 +149,24 @@ __device__ __forceinline__ void store_pairs(f2* dst, const f4& sv, const f4& av,
     reinterpret_cast<f4*>(dst)[1] = hi;
 }
 
-// NF > 0: exactly NF fades (11 for AMTAnalyzeLogo: no per-fade branches); NF == 0: nfades <= kLinMaxFades at run time
+// sum over the 64 lanes of a wave in a fixed order (DPP: every step is one v_add_f32); the total lands in lane 63
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));   // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));   // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));   // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));   // row_shr:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));   // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, true));   // row_bcast:31
+    return v;
+}
+
+// NF > 0: exactly NF fades (11 for AMTAnalyzeLogo: no per-fade branches); NF == 0: nfades <= kLinMaxFades at run time.
+//
+// Software pipeline over the (band, frame) iterations of a workgroup, ONE barrier per iteration: the raw rows of the NEXT
+// iteration are requested before the current window evaluation (4 registers in flight), its logo coefficients after it, and
+// both are converted into the other half of a double-buffered LDS plane after the fade code -- the global-memory latency of
+// staging sits behind the arithmetic instead of in front of a barrier.
 template <typename pix_t, int NF>
 __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoDev* __restrict__ lins, const EvalBand* __restrict__ bands,
@@ -160,9 +177,9 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     constexpr int NFMAX = NF > 0 ? NF : kLinMaxFades;
     const int nfades = NF > 0 ? NF : nfades_rt;
     extern __shared__ float lds[];
-    f2* const plane = reinterpret_cast<f2*>(lds);         // [plane_cap] {s, bg = a*s + b*maxv} of the band's rows, current frame
-    float* const part = lds + 2 * plane_cap;              // [NFMAX][kPartPitch] per-pixel terms of the current (band, frame)
-    float* const accs = part + NFMAX * kPartPitch;        // [G][nfades] running sums
+    f2* const planes = reinterpret_cast<f2*>(lds);                 // [2][plane_cap] {s, bg = a*s + b*maxv} of a band's rows, one frame each
+    float* const wpart = lds + 4 * plane_cap;                      // [2][kWaves][NFMAX] per-wave sums of the terms of an iteration
+    float* const accs = wpart + 2 * kWaves * NFMAX;                // [G][nfades] running sums
 
     const int logo = blockIdx.x / ngroups;
     const int grp = blockIdx.x - logo * ngroups;
@@ -170,7 +187,7 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     const int gcount = min(G, nframes - F0);
     const EvalLogoDev L = logos[logo];
     const LinLogoDev X = lins[logo];
-    const gptr_t gA = (gptr_t)L.a, gB = (gptr_t)L.b, gScales = (gptr_t)L.scales, gK = (gptr_t)X.kpix, gPos = (gptr_t)X.pos;
+    const gptr_t gScales = (gptr_t)L.scales, gK = (gptr_t)X.kpix, gPos = (gptr_t)X.pos;
     const unsigned cpad = (unsigned)L.count_pad;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the staging rows' address math stays scalar
@@ -185,180 +202,217 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.a), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.b), 0, 0x7FFFFFFF, 0x00020000);
 
-    // tree sum of the previous iteration's per-pixel terms: wave w owns fades w, w+8; fixed order -> deterministic
-    auto reduce_part = [&](int g) {
-        for (int f = wave; f < nfades; f += kWaves) {
-            float s = 0.0f;
+    // ---- staging of one (band, frame): a wave owns rows rg = 2*wave, 2*wave+1 of the band (bands have <= 2*kWaves rows, host),
+    //      a lane four adjacent columns (w <= 256, host); a ragged right edge (w % 4 == 2) is covered by shifting the last lane
+    //      group left, its two duplicated columns are written twice with the same values ----
+    const bool slane = 4 * lane < w;
+    const int sx = min(4 * lane, w - 4);
+    struct RowSet { int y, nrows; };
+    auto frame_rsrc = [&](int g) {
+        const int frame = F0 + g;
+        const int srcFrame = frame_map ? frame_map[frame] : frame;
+        const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
+    };
+    auto load_raw = [&](const __amdgpu_buffer_rsrc_t rS, int y0, Raw4<pix_t> (&raw)[kStageRows + 2]) {
+        const int y = y0 + kStageRows * wave;
 #pragma unroll
-            for (int q = 0; q < kLinThreads / 256; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(part + f * kPartPitch + 256 * q + 4 * lane);
-                s += (v.x + v.y) + (v.z + v.w);
+        for (int j = 0; j < kStageRows + 2; ++j) {
+            const int row = L.deint ? min(max(y - 1 + j, 0), L.h - 1) : min(y + max(j - 1, 0), L.h - 1) * L.row_step;
+            raw[j].load_buf(rS, (unsigned)sx * ES, row * pitch * (int)ES);
+        }
+    };
+    auto load_ab = [&](int y0, f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
+        const int y = y0 + kStageRows * wave;
+#pragma unroll
+        for (int j = 0; j < kStageRows; ++j) {
+            const int ro = min(y + j, L.h - 1) * w * 4;
+            av[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)sx * 4u, ro, 0));
+            bv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)sx * 4u, ro, 0));
+        }
+    };
+    // Samples are converted byte-wise and the [1 2 1] vertical blend of DeintY (LogoScan.hpp:763-780) is done on the floats: every
+    // intermediate is an integer below 2^24, so (r0 + 2 r1 + r2 + 2) * 0.25 equals the reference's (float)(int sum) / 4.0f bit for bit
+    auto convert_store = [&](f2* plane, int y0, int nrows, const Raw4<pix_t> (&raw)[kStageRows + 2], const f4 (&av)[kStageRows],
+                             const f4 (&bv)[kStageRows]) {
+        const int rg = kStageRows * wave;
+        if (!slane) return;
+        f4 fr[kStageRows + 2];
+#pragma unroll
+        for (int j = 0; j < kStageRows + 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fr[j][k] = (float)raw[j].get(k);
+#pragma unroll
+        for (int j = 0; j < kStageRows; ++j) {
+            const int yy = y0 + rg + j;
+            if (rg + j < nrows) {
+                f4 sv;
+                if (L.deint && yy != 0 && yy != L.h - 1) {       // uniform per row
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sv[k] = ((fr[j][k] + 2.0f * fr[j + 1][k]) + (fr[j + 2][k] + 2.0f)) * 0.25f;
+                } else {
+                    sv = fr[j + 1];
+                }
+                store_pairs(plane + (rg + j) * lp + sx, sv, av[j], bv[j], maxv);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) accs[g * nfades + f] += s;
         }
     };
 
-    int it = 0, prev_g = 0;
-    for (int bi = 0; bi < X.nbands; ++bi) {
-        const EvalBand B = bands[X.band0 + bi];
-        const bool act = tid < B.npix;
-        const unsigned m = (unsigned)(B.m0 + (act ? tid : 0));
-        const unsigned pos = gld<unsigned>(gPos, m * 4u);
-        const int woff = ((int)(pos >> 16) - 2 - B.y0) * lp + (int)(pos & 0xFFFFu) - 2;   // plane offset of the window's top-left element
-        const unsigned m8 = m * 8u, cpad8 = cpad * 8u;                                     // byte offsets into the bin-major scale table
-        f2 Kp[13];
-#pragma unroll
-        for (int j = 0; j < 13; ++j) {
-            Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
-            if (!act) Kp[j] = f2{0.0f, 0.0f};          // a surplus thread evaluates to exactly 0 (no branches in the fade code below)
-        }
-
-        for (int g = 0; g < gcount; ++g, ++it) {
-            const int frame = F0 + g;
-            const int srcFrame = frame_map ? frame_map[frame] : frame;
-            const gptr_t src = (gptr_t)(Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx);
-            // ---- 1. {s, bg} of the band's rows -> LDS: a wave stages 2 consecutive rows x 256 columns per trip, a lane four
-            //      adjacent columns.  Row addresses are wave-uniform (scalar base + one per-lane column offset).  Samples are
-            //      converted byte-wise (v_cvt_f32_ubyte*) and the [1 2 1] vertical blend of DeintY (LogoScan.hpp:763-780) is done
-            //      on the floats: every intermediate is an integer below 2^24, so (r0 + 2 r1 + r2 + 2) * 0.25 equals the
-            //      reference's (float)(int sum) / 4.0f bit for bit; bg = a*s + (b*maxv), b*maxv rounded first as in :247 ----
-            const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)src), 0, 0x7FFFFFFF, 0x00020000);
-            for (int rg0 = wave * kStageRows; rg0 < B.nrows; rg0 += kStageRows * kWaves) {
-                const int rg = __builtin_amdgcn_readfirstlane(rg0);      // provably wave-uniform: row offsets go to the scalar operand
-                const int y = B.y0 + rg;
-                // source rows of the trip (uniform): deint reads y-1 .. y+2 clamped to the rectangle, a field logo its own rows
-                int so[kStageRows + 2];
-#pragma unroll
-                for (int j = 0; j < kStageRows + 2; ++j)
-                    so[j] = (L.deint ? min(max(y - 1 + j, 0), L.h - 1) : min(y + max(j - 1, 0), L.h - 1) * L.row_step) * pitch * (int)ES;
-                for (int xg = 0; xg < w; xg += 256) {
-                    const int x = xg + 4 * lane;
-                    if (x + 4 <= w) {
-                        Raw4<pix_t> raw[kStageRows + 2];
-                        f4 av[kStageRows], bv[kStageRows];
-#pragma unroll
-                        for (int j = 0; j < kStageRows + 2; ++j) raw[j].load_buf(rS, (unsigned)x * ES, so[j]);
-#pragma unroll
-                        for (int j = 0; j < kStageRows; ++j) {
-                            const int ro = min(y + j, L.h - 1) * w * 4;
-                            av[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)x * 4u, ro, 0));
-                            bv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)x * 4u, ro, 0));
-                        }
-                        f4 fr[kStageRows + 2];
-#pragma unroll
-                        for (int j = 0; j < kStageRows + 2; ++j)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) fr[j][k] = (float)raw[j].get(k);
-#pragma unroll
-                        for (int j = 0; j < kStageRows; ++j) {
-                            const int yy = y + j;
-                            if (rg + j < B.nrows) {
-                                f4 sv;
-                                if (L.deint && yy != 0 && yy != L.h - 1) {       // uniform per row
-#pragma unroll
-                                    for (int k = 0; k < 4; ++k) sv[k] = ((fr[j][k] + 2.0f * fr[j + 1][k]) + (fr[j + 2][k] + 2.0f)) * 0.25f;
-                                } else {
-                                    sv = fr[j + 1];
-                                }
-                                store_pairs(plane + (rg + j) * lp + x, sv, av[j], bv[j], maxv);
-                            }
-                        }
-                    } else if (x < w) {            // ragged right edge of a logo whose width is not a multiple of 4: sample by sample
-                        for (int j = 0; j < kStageRows && rg + j < B.nrows; ++j) {
-                            const int yy = y + j;
-                            const bool blend = L.deint && yy != 0 && yy != L.h - 1;
-                            for (int k = 0; k < w - x; ++k) {
-                                int q0, q1, q2;
-                                if (L.deint) {
-                                    q0 = gld<pix_t>(src, (unsigned)(max(yy - 1, 0) * pitch + x + k) * ES);
-                                    q1 = gld<pix_t>(src, (unsigned)(yy * pitch + x + k) * ES);
-                                    q2 = gld<pix_t>(src, (unsigned)(min(yy + 1, L.h - 1) * pitch + x + k) * ES);
-                                } else {
-                                    q0 = q2 = 0;
-                                    q1 = gld<pix_t>(src, (unsigned)(yy * L.row_step * pitch + x + k) * ES);
-                                }
-                                const float s1 = blend ? (float)(q0 + 2 * q1 + q2 + 2) / 4.0f : (float)q1;
-                                plane[(rg + j) * lp + x + k] = f2{s1, unblend_bg(gld<float>(gA, (unsigned)(yy * w + x + k) * 4u),
-                                                                                 gld<float>(gB, (unsigned)(yy * w + x + k) * 4u), maxv, s1)};
-                            }
-                        }
-                    }
-                }
-            }
-            // ---- 2. fold the previous iteration's terms into the running sums (its rows are complete since barrier B0) ----
-            if (it > 0) reduce_part(prev_g);
-            __syncthreads();                         // B1: plane complete, part rows free again
-
-            // ---- 3. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
-            // The taps are loop-invariant, so LICM would hoist their {k,k} broadcasts out of the frame loop and keep 50 registers of
-            // copies; an empty asm makes them opaque per iteration and the broadcast folds into the multiply's op_sel instead.
-#pragma unroll
-            for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
-            f2 R, M;
-            {
-                f2 W[25];
-                load_window(plane, woff, lp, W);     // surplus threads read pixel B.m0's window: finite values, zero taps
-                M = window_means(W);
-                R = window_corr(Kp, W, M);
-            }
-            // ---- 4. all fades from the two pairs, kGatherChunk at a time: interpolated mean -> bin -> scale gather (in flight
-            //      together), then correlation and per-pixel term (LogoScan.hpp:305-308).  The bin select is discontinuous: a mean
-            //      within dq of a bin edge is flagged, and the flagged (pixel, fade) pairs -- about 1e-4 of all -- are redone below
-            //      with the mean evaluated exactly as the reference does ----
-            const float m0q = M.x * 4096.0f, dMq = (M.y - M.x) * 4096.0f, dR = R.y - R.x;     // mean in 1/4096 units: m0q + fade * dMq
-            unsigned emin = 0x7FFFu;                                                          // smallest distance (+dq) to a bin edge
-#pragma unroll
-            for (int f0 = 0; f0 < NFMAX; f0 += kGatherChunk) {
-                f2 sc[kGatherChunk];
-#pragma unroll
-                for (int j = 0; j < kGatherChunk; ++j) {
-                    const int f = f0 + j;
-                    if (f < NFMAX && (NF > 0 || f < nfades)) {
-                        const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
-                        const int q = (int)__builtin_fmaf(fade, dMq, m0q);
-                        emin = min(emin, (unsigned)(q + dq) & 0x7FFFu);
-                        sc[j] = gld<f2>(gScales, __umul24((unsigned)min(max(q >> 15, 0), 31), cpad8) + m8);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kGatherChunk; ++j) {
-                    const int f = f0 + j;
-                    if (f < NFMAX && (NF > 0 || f < nfades)) {
-                        const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
-                        const float c = __builtin_fmaf(fade, dR, R.x);
-                        part[f * kPartPitch + tid] = __builtin_amdgcn_fmed3f(c * sc[j].x, -1.0f, 1.0f) * sc[j].y;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- a mean near an edge (about 1e-4 of all pixel-fades): exact mean -> the reference's bin; when it differs from the
-            //      interpolated mean's, replace the term ----
-            if (act && emin <= (unsigned)(2 * dq)) {
-                for (int f = 0; f < nfades; ++f) {
-                    const float fade = fades[fade0 + f];
-                    const int q = (int)__builtin_fmaf(fade, dMq, m0q);
-                    if (((unsigned)(q + dq) & 0x7FFFu) > (unsigned)(2 * dq)) continue;
-                    const int bin_lin = min(max(q >> 15, 0), 31);
-                    const int bin_ref = score_bin_dev(exact_blend_mean(plane, woff, lp, fade, 1 - fade));
-                    if (bin_ref != bin_lin) {
-                        const f2 s2 = gld<f2>(gScales, __umul24((unsigned)bin_ref, cpad8) + m8);
-                        part[f * kPartPitch + tid] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fade, dR, R.x) * s2.x, -1.0f, 1.0f) * s2.y;
-                    }
-                }
-            }
-            prev_g = g;
-            __syncthreads();                         // B0: part rows complete, plane consumed
-        }
+    const int niter = X.nbands * gcount;
+    EvalBand B = bands[X.band0];
+    // prologue: the first iteration's rows
+    {
+        Raw4<pix_t> raw[kStageRows + 2];
+        f4 av[kStageRows], bv[kStageRows];
+        load_raw(frame_rsrc(0), B.y0, raw);
+        load_ab(B.y0, av, bv);
+        convert_store(planes, B.y0, B.nrows, raw, av, bv);
     }
-    if (it > 0) reduce_part(prev_g);
+    bool act = false;
+    unsigned m = 0, m8 = 0;
+    int woff = 0;
+    const unsigned cpad8 = cpad * 8u;
+    f2 Kp[13];
+    __syncthreads();
+
+    int bi = 0, g = 0;
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        f2* const plane = planes + cur * plane_cap;
+        if (g == 0) {
+            // ---- a new band: this thread's mask pixel, its window offset and its taps ----
+            act = tid < B.npix;
+            m = (unsigned)(B.m0 + (act ? tid : 0));
+            const unsigned pos = gld<unsigned>(gPos, m * 4u);
+            woff = ((int)(pos >> 16) - 2 - B.y0) * lp + (int)(pos & 0xFFFFu) - 2;          // plane offset of the window's top-left element
+            m8 = m * 8u;
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
+                if (!act) Kp[j] = f2{0.0f, 0.0f};      // a surplus thread evaluates to exactly 0 (no branches in the fade code below)
+            }
+        }
+        // the next iteration: same band / next frame, or the next band / first frame
+        const bool has_next = it + 1 < niter;
+        const bool next_band = g + 1 == gcount;
+        const int ng = next_band ? 0 : g + 1;
+        EvalBand Bn = B;
+        if (has_next && next_band) Bn = bands[X.band0 + bi + 1];
+        // ---- 1. request the next iteration's raw rows ----
+        Raw4<pix_t> raw[kStageRows + 2];
+        if (has_next) load_raw(frame_rsrc(ng), Bn.y0, raw);
+        // ---- 2. fold the previous iteration's per-wave sums into the running sums (fixed order: deterministic) ----
+        if (it > 0 && tid < nfades) {
+            const float* wp = wpart + (cur ^ 1) * kWaves * NFMAX + tid;
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kWaves; ++q) s += wp[q * NFMAX];
+            const int pg = g == 0 ? gcount - 1 : g - 1;        // the previous iteration's frame
+            accs[pg * nfades + tid] += s;
+        }
+        // ---- 3. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
+        // The taps are loop-invariant, so LICM would hoist their {k,k} broadcasts out of the loop and keep 50 registers of
+        // copies; an empty asm makes them opaque per iteration and the broadcast folds into the multiply's op_sel instead.
+#pragma unroll
+        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
+        f2 R, M;
+#ifdef AMT_LIN_NO_EVAL
+        M = plane[woff]; R = Kp[0] * M;
+#else
+        {
+            f2 W[25];
+            load_window(plane, woff, lp, W);     // surplus threads read pixel B.m0's window: finite values, zero taps
+            M = window_means(W);
+            R = window_corr(Kp, W, M);
+        }
+#endif
+        // ---- 4. request the next iteration's logo coefficients (the window registers are free again) ----
+        f4 av[kStageRows], bv[kStageRows];
+        if (has_next) load_ab(Bn.y0, av, bv);
+        // ---- 5. all fades from the two pairs: interpolated mean -> bin -> scale gather, all in flight together; while they travel
+        //      the next iteration's rows are converted into the other plane (loads return in order: raw rows and coefficients
+        //      were requested earlier); then correlation and per-pixel term (LogoScan.hpp:305-308), summed over the wave.
+        //      The bin select is discontinuous: a mean within dq of a bin edge is noted, and those (pixel, fade) pairs -- about
+        //      1e-4 of all -- are redone below with the mean evaluated exactly as the reference does ----
+        const float m0q = M.x * 4096.0f, dMq = (M.y - M.x) * 4096.0f, dR = R.y - R.x;     // mean in 1/4096 units: m0q + fade * dMq
+        unsigned emin = 0x7FFFu;                                                          // smallest distance (+dq) to a bin edge
+        float term[NFMAX];
+#ifdef AMT_LIN_NO_FADES
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f) term[f] = R.x + dR * (float)f + m0q + dMq;
+#else
+        // every fade's scale gather is in flight before the first term is formed: one exposed round trip to L2 per iteration
+        constexpr int NA = (NFMAX + 1) / 2;
+        auto issue = [&](int f, f2& dst) {
+            const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
+            const int q = (int)__builtin_fmaf(fade, dMq, m0q);
+            emin = min(emin, (unsigned)(q + dq) & 0x7FFFu);
+            dst = gld<f2>(gScales, __umul24((unsigned)min(max(q >> 15, 0), 31), cpad8) + m8);
+        };
+        auto finish = [&](int f, const f2& sc) {
+            const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
+            term[f] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fade, dR, R.x) * sc.x, -1.0f, 1.0f) * sc.y;
+        };
+        f2 scA[NA], scB[NFMAX - NA];
+#pragma unroll
+        for (int f = 0; f < NA; ++f) if (NF > 0 || f < nfades) issue(f, scA[f]);
+#pragma unroll
+        for (int f = NA; f < NFMAX; ++f) if (NF > 0 || f < nfades) issue(f, scB[f - NA]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NA; ++f) if (NF > 0 || f < nfades) finish(f, scA[f]);
+#pragma unroll
+        for (int f = NA; f < NFMAX; ++f) if (NF > 0 || f < nfades) finish(f, scB[f - NA]);
+        // a mean near an edge: exact mean -> the reference's bin; when it differs from the interpolated mean's, replace the term
+        if (act && emin <= (unsigned)(2 * dq)) {
+#pragma unroll
+            for (int f = 0; f < NFMAX; ++f) {
+                if (NF > 0 || f < nfades) {
+                    const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
+                    const int q = (int)__builtin_fmaf(fade, dMq, m0q);
+                    if (((unsigned)(q + dq) & 0x7FFFu) <= (unsigned)(2 * dq)) {
+                        const int bin_ref = score_bin_dev(exact_blend_mean(plane, woff, lp, fade, 1 - fade));
+                        if (bin_ref != min(max(q >> 15, 0), 31)) {
+                            const f2 s2 = gld<f2>(gScales, __umul24((unsigned)bin_ref, cpad8) + m8);
+                            term[f] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fade, dR, R.x) * s2.x, -1.0f, 1.0f) * s2.y;
+                        }
+                    }
+                }
+            }
+        }
+#endif
+#ifdef AMT_LIN_NO_REDUCE
+        if (lane == 63) wpart[(cur * kWaves + wave) * NFMAX] = term[0] + term[NFMAX - 1];
+#else
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f) {
+            if (NF > 0 || f < nfades) {
+                const float s = wave_sum_dpp(term[f]);
+                if (lane == 63) wpart[(cur * kWaves + wave) * NFMAX + f] = s;
+            }
+        }
+#endif
+#ifndef AMT_LIN_NO_STAGE
+        if (has_next) convert_store(planes + (cur ^ 1) * plane_cap, Bn.y0, Bn.nrows, raw, av, bv);
+#endif
+        __syncthreads();                         // next plane and this iteration's wave sums complete; current plane consumed
+        if (next_band) { B = Bn; ++bi; }
+        g = ng;
+    }
+    // the last iteration's wave sums
+    if (niter > 0 && tid < nfades) {
+        const float* wp = wpart + ((niter - 1) & 1) * kWaves * NFMAX + tid;
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kWaves; ++q) s += wp[q * NFMAX];
+        accs[(gcount - 1) * nfades + tid] += s;
+    }
     __syncthreads();
     if (tid < gcount * nfades) {
-        const int g = tid / nfades, f = tid - g * nfades;
+        const int gg = tid / nfades, f = tid - gg * nfades;
         float r = accs[tid] / L.blackScore;
         if (take_abs) r = fabsf(r);
-        out[(long long)(F0 + g) * out_frame_stride + L.out_off + fade0 + f] = r;
+        out[(long long)(F0 + gg) * out_frame_stride + L.out_off + fade0 + f] = r;
     }
 }
 
@@ -372,7 +426,7 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     const int ngroups = (nframes + G - 1) / G;
     const float maxv = (float)((1 << bits) - 1);
     const int nfmax = nfades == 11 ? 11 : kLinMaxFades;
-    const size_t lds = ((size_t)2 * plane_cap + (size_t)nfmax * kPartPitch + (size_t)G * nfades) * sizeof(float);
+    const size_t lds = ((size_t)4 * plane_cap + (size_t)2 * (kLinThreads / 64) * nfmax + (size_t)G * nfades) * sizeof(float);
     dim3 grid((unsigned)((long long)ngroups * nlogos));
 #define AMT_LAUNCH(T, N)                                                                                                              \
     hipLaunchKernelGGL((logo_eval_linear_kernel<T, N>), grid, dim3(kLinThreads), lds, st, dlogos, dlins, dbands, dfades, nfades, fade0,   \

@@ -37,6 +37,7 @@ struct EvalLogoDev {
 // ---- linear (decision-guarded) evaluation, eval_linear_kernels.hip: one mask pixel per thread ----
 constexpr int kLinThreads = 512;    // threads per workgroup = mask pixels per band
 constexpr int kLinBandPix = kLinThreads;
+constexpr int kLinBandRows = 2 * (kLinThreads / 64);   // rows a band may touch: each wave stages two rows per iteration
 constexpr int kLinMaxFades = 12;    // fades per launch (11 for AMTAnalyzeLogo)
 constexpr int kLinPlaneCap = 3328;  // {s,bg} pairs an LDS plane holds (8 B each): 12 rows of a 256-wide logo
 struct LinLogoDev {
