@@ -21,6 +21,7 @@
 
 namespace amtavs {
 
+class AVSValue;
 enum { PLANAR_Y = 1 << 0, PLANAR_U = 1 << 1, PLANAR_V = 1 << 2 };
 enum { CACHE_GET_MTMODE = 509, MT_NICE_FILTER = 1 };
 
@@ -90,6 +91,9 @@ public:
         if (pf->use_count() > 1) *pf = std::make_shared<VideoFrame>(**pf);
         return true;
     }
+    /* plugin registration (avisynth.h:1389): stored by a real host, recorded by test hosts */
+    typedef class AVSValue (*ApplyFunc)(class AVSValue args, void* user_data, IScriptEnvironment* env);
+    virtual void AddFunction(const char* /*name*/, const char* /*params*/, ApplyFunc /*apply*/, void* /*user_data*/) {}
     [[noreturn]] virtual void ThrowError(const char* fmt, ...)
     {
         char buf[1024];
@@ -110,6 +114,48 @@ public:
     virtual int SetCacheHints(int, int) { return 0; }
 };
 typedef std::shared_ptr<IClip> PClip;
+
+/* ---- script values and plugin registration: what AvisynthPluginInit3 and the filters' Create factories touch
+ *      (include/avisynth.h:1166-1260 AVSValue, :1389 AddFunction, Amatsukaze.cpp:43-65) ---- */
+struct AVS_Linkage;     /* the real header's function-pointer table; opaque here (the stand-in links directly) */
+
+class AVSValue {
+    enum Kind { UNDEF, CLIP, BOOL, INT, FLOAT, STRING, ARRAY } kind_ = UNDEF;
+    PClip clip_;
+    long long i_ = 0;
+    double f_ = 0;
+    std::string s_;
+    std::vector<AVSValue> arr_;
+public:
+    AVSValue() {}
+    AVSValue(IClip* c) : kind_(CLIP), clip_(c) {}            /* takes ownership, like AviSynth's ref-counted PClip(IClip*) */
+    AVSValue(const PClip& c) : kind_(CLIP), clip_(c) {}
+    AVSValue(bool b) : kind_(BOOL), i_(b) {}
+    AVSValue(int i) : kind_(INT), i_(i) {}
+    AVSValue(float f) : kind_(FLOAT), f_(f) {}
+    AVSValue(double f) : kind_(FLOAT), f_(f) {}
+    AVSValue(const char* s) : kind_(STRING), s_(s) {}
+    AVSValue(const std::vector<AVSValue>& a) : kind_(ARRAY), arr_(a) {}
+    bool Defined() const { return kind_ != UNDEF; }
+    bool IsClip() const { return kind_ == CLIP; }
+    bool IsInt() const { return kind_ == INT; }
+    bool IsFloat() const { return kind_ == FLOAT || kind_ == INT; }
+    bool IsString() const { return kind_ == STRING; }
+    bool IsArray() const { return kind_ == ARRAY; }
+    PClip AsClip() const { if (kind_ != CLIP) throw AvisynthError("Invalid arguments: clip expected"); return clip_; }
+    int AsInt() const { if (kind_ != INT) throw AvisynthError("Invalid arguments: int expected"); return (int)i_; }
+    int AsInt(int def) const { return Defined() ? AsInt() : def; }
+    double AsFloat() const { if (!IsFloat()) throw AvisynthError("Invalid arguments: float expected"); return kind_ == INT ? (double)i_ : f_; }
+    double AsFloat(float def) const { return Defined() ? AsFloat() : (double)def; }
+    const char* AsString() const { if (kind_ != STRING) throw AvisynthError("Invalid arguments: string expected"); return s_.c_str(); }
+    const char* AsString(const char* def) const { return Defined() ? AsString() : def; }
+    int ArraySize() const { return kind_ == ARRAY ? (int)arr_.size() : 1; }
+    const AVSValue& operator[](int i) const
+    {
+        if (kind_ != ARRAY) { if (i == 0) return *this; throw AvisynthError("Invalid arguments: index out of range"); }
+        return arr_.at((size_t)i);
+    }
+};
 
 class GenericVideoFilter : public IClip {
 protected:

@@ -39,6 +39,7 @@
 
 namespace amtgpu {
 
+using AMT_AVS_NS AVSValue;
 using AMT_AVS_NS GenericVideoFilter;
 using AMT_AVS_NS IScriptEnvironment;
 using AMT_AVS_NS PClip;

@@ -4,6 +4,8 @@
 // Everything the filters return is dumped to files; tests/test_gpu_filters_cpp.py compares them with the CPU oracle.
 //   filters_host_test <clip.raw> <logo.lgd> <logo2.lgd> <logof-in or -> <outdir> <device>
 // clip.raw: int32 {W,H,bits,N,pitchY,pitchUV} then Y[N][H][pitchY], U[N][H/2][pitchUV], V[...] (elements of 1 or 2 bytes)
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -12,6 +14,29 @@
 #include "amt_filters.hpp"
 
 using namespace amtavs;
+
+// a host that records what a plugin registers (name, argument specification, factory), the way AviSynth's function table does
+struct Registered { std::string name, params; IScriptEnvironment::ApplyFunc apply; void* user; };
+class RecordingEnv : public IScriptEnvironment {
+public:
+    std::vector<Registered> funcs;
+    void AddFunction(const char* name, const char* params, ApplyFunc apply, void* user) override { funcs.push_back({name, params, apply, user}); }
+    const Registered& find(const std::string& n) const
+    {
+        for (const auto& f : funcs) if (f.name == n) return f;
+        throw std::runtime_error("plugin did not register " + n);
+    }
+};
+typedef const char* (*PluginInit3)(IScriptEnvironment*, const AVS_Linkage*);
+
+static const char* load_plugin(const std::string& path, RecordingEnv& env)
+{
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) throw std::runtime_error(std::string("dlopen: ") + dlerror());
+    PluginInit3 init = reinterpret_cast<PluginInit3>(dlsym(h, "AvisynthPluginInit3"));
+    if (!init) throw std::runtime_error("plugin exports no AvisynthPluginInit3");
+    return init(&env, nullptr);
+}
 
 class RawClip : public IClip {
     VideoInfo vi_;
@@ -62,6 +87,16 @@ static void dump(const std::string& path, const void* p, size_t n)
 
 int main(int argc, char** argv)
 {
+    if (argc == 3 && std::string(argv[1]) == "--registration") {
+        // what the plugin registers, one "name<TAB>params" line each, then its description string (no GPU needed)
+        try {
+            RecordingEnv renv;
+            const char* desc = load_plugin(argv[2], renv);
+            for (const auto& f : renv.funcs) std::printf("%s\t%s\n", f.name.c_str(), f.params.c_str());
+            std::printf("%s\n", desc);
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc < 7) { std::fprintf(stderr, "usage: %s clip.raw logo.lgd logo2.lgd logof|- outdir device\n", argv[0]); return 2; }
     const std::string clipPath = argv[1], logo = argv[2], logo2 = argv[3], logofIn = argv[4], out = argv[5];
     IScriptEnvironment env;
@@ -109,6 +144,36 @@ int main(int argc, char** argv)
                     for (int y = 0; y < fr->GetHeight(plane); ++y)
                         f.write(reinterpret_cast<const char*>(fr->GetReadPtr(plane)) + (size_t)y * fr->GetPitch(plane), fr->GetRowSize(plane));
             }
+        }
+
+        // 3b. the same graph built the way AviSynth builds it: through the factories the plugin registered with the
+        //     reference's names / argument specifications (Amatsukaze.cpp:58-59), defaults left undefined
+        if (argc >= 8) {
+            RecordingEnv renv;
+            load_plugin(argv[7], renv);
+            const Registered& fa = renv.find("AMTAnalyzeLogo");
+            const Registered& fe = renv.find("AMTEraseLogo");
+            if (fa.params != "cs[maskratio]i" || fe.params != "ccs[logof]s[mode]i[maxfade]i") throw std::runtime_error("argument specification differs");
+            AVSValue an2 = fa.apply(AVSValue(std::vector<AVSValue>{AVSValue(src), AVSValue(logo.c_str()), AVSValue()}), fa.user, &renv);
+            AVSValue an3 = fa.apply(AVSValue(std::vector<AVSValue>{AVSValue(src), AVSValue(logo.c_str()), AVSValue(35)}), fa.user, &renv);
+            for (int n = 0; n < avi.num_frames; ++n) {
+                PVideoFrame a = an2.AsClip()->GetFrame(n, &renv), b = an3.AsClip()->GetFrame(n, &renv);
+                if (std::memcmp(a->GetReadPtr(), &records[(size_t)n * 1056], 1056) || std::memcmp(b->GetReadPtr(), &records[(size_t)n * 1056], 1056))
+                    throw std::runtime_error("plugin-built AMTAnalyzeLogo differs from the directly constructed one");
+            }
+            AVSValue er2 = fe.apply(AVSValue(std::vector<AVSValue>{AVSValue(src), an2, AVSValue(logo.c_str()), AVSValue(), AVSValue(), AVSValue()}),
+                                    fe.user, &renv);
+            std::ofstream f(out + "/erased_plugin.raw", std::ios::binary);
+            for (int n = 0; n < vi.num_frames; ++n) {
+                PVideoFrame fr = er2.AsClip()->GetFrame(n, &renv);
+                for (int plane : {PLANAR_Y, PLANAR_U, PLANAR_V})
+                    for (int y = 0; y < fr->GetHeight(plane); ++y)
+                        f.write(reinterpret_cast<const char*>(fr->GetReadPtr(plane)) + (size_t)y * fr->GetPitch(plane), fr->GetRowSize(plane));
+            }
+            // a mode the GPU path does not provide must surface as a script error, as ThrowError does in the reference
+            std::ofstream pf(out + "/plugin_errors.txt");
+            try { fe.apply(AVSValue(std::vector<AVSValue>{AVSValue(src), an2, AVSValue(logo.c_str()), AVSValue(), AVSValue(1), AVSValue()}), fe.user, &renv); pf << "no error\n"; }
+            catch (const AvisynthError& e) { pf << e.msg << "\n"; }
         }
 
         // 4. error texts of the constructors

@@ -207,3 +207,19 @@ def test_release_library_reads_no_experiment_knobs(lib):
     blob = open(binding.LIB_PATH, "rb").read()
     for knob in (b"AMTGPU_DBG", b"AMTGPU_LDSPAD", b"AMTGPU_FPI", b"AMTGPU_G\0", b"AMTGPU_VERBOSE"):
         assert knob not in blob, knob
+
+
+def test_avisynth_plugin_registration(lib):
+    """plugin/amt_plugin.cpp exports AvisynthPluginInit3 and registers the logo filters under the reference's names and
+    argument specifications (Amatsukaze.cpp:58-59); registration itself needs no GPU."""
+    import subprocess
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp, "all"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(cpp, "filters_host_test"), "--registration", os.path.join(cpp, "libamt_avs_plugin.so")],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[:2] == ["AMTAnalyzeLogo\tcs[maskratio]i", "AMTEraseLogo\tccs[logof]s[mode]i[maxfade]i"]
+    assert len(lines) == 3 and lines[2]                       # the description string AviSynth shows
+    sym = subprocess.run(["nm", "-D", "--defined-only", os.path.join(cpp, "libamt_avs_plugin.so")], capture_output=True, text=True).stdout
+    assert " T AvisynthPluginInit3" in sym

@@ -14,11 +14,12 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "filters_host_test")
+PLUGIN = os.path.join(ROOT, "tests", "cpp", "libamt_avs_plugin.so")
 CFG = dict(W=352, H=240, LW=96, LH=48, IMGX=224, IMGY=18, N=43, period=16, fade=6, flat=3)
 
 
 def build_exe():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "all"], stdout=subprocess.DEVNULL)
     return EXE
 
 
@@ -47,7 +48,7 @@ def test_cpp_filters_match_oracle(tmp_path, bits):
     logof_in = tmp_path / "logof_in.txt"                       # a logoframe file with two logo sections (LogoScan.hpp:1818-1819 format)
     logof_in.write_text("    14 S 0 ALL     12     17\n    20 E 0 ALL     18     23\n    30 S 0 ALL     29     33\n"
                         "    39 E 0 ALL     38     39\n")
-    r = subprocess.run([exe, str(raw), logo1, logo2, str(logof_in), str(out), "0"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, str(raw), logo1, logo2, str(logof_in), str(out), "0", PLUGIN], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr + r.stdout
 
     Y, U, V = clip["Y"], clip["U"], clip["V"]
@@ -85,7 +86,9 @@ def test_cpp_filters_match_oracle(tmp_path, bits):
     # ---- AMTEraseLogo: without and with a logoframe file ----
     text = logof_in.read_bytes()
     dt = Y.dtype
-    for variant, name in ((0, "erased.raw"), (1, "erased_logof.raw")):
+    # erased_plugin.raw: the graph AMTEraseLogo(src, AMTAnalyzeLogo(src, logo), logo) built through the factories that
+    # plugin/amt_plugin.cpp registered in AvisynthPluginInit3 (names / argument specs of Amatsukaze.cpp:58-59, defaults undefined)
+    for variant, name in ((0, "erased.raw"), (1, "erased_logof.raw"), (0, "erased_plugin.raw")):
         fr = np.zeros(N, np.int32)
         if variant:
             assert orc.lib.orc_read_logoframe(text, N, _ptr(fr)) == 0
@@ -106,3 +109,4 @@ def test_cpp_filters_match_oracle(tmp_path, bits):
     errs = (out / "errors.txt").read_text().splitlines()
     assert errs[0].startswith("Failed to read logo file (") and "missing.lgd" in errs[0]
     assert "mode 1" in errs[1]
+    assert "mode 1" in (out / "plugin_errors.txt").read_text()
