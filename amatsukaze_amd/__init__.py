@@ -3,8 +3,8 @@
 Product code only: HIP kernels + C ABI (csrc/, libamt_gpu.so) and the Python mirror of the reference's
 filter interface (api.py).  Nothing here imports the CPU oracle.
 """
-from .api import (AMTAnalyzeLogo, AMTEraseLogo, AmtError, Context, DeviceClip, FrameStats, Logo, LogoFrame,
+from .api import (AMTAnalyzeLogo, AMTEraseLogo, AmtError, AmtsFile, Context, DeviceClip, FrameStats, Logo, LogoFrame,
                   LogoScan, ScanLogo, weave_fields)
 
-__all__ = ["AMTAnalyzeLogo", "AMTEraseLogo", "AmtError", "Context", "DeviceClip", "FrameStats", "Logo", "LogoFrame",
+__all__ = ["AMTAnalyzeLogo", "AMTEraseLogo", "AmtError", "AmtsFile", "Context", "DeviceClip", "FrameStats", "Logo", "LogoFrame",
            "LogoScan", "ScanLogo", "weave_fields"]

@@ -134,6 +134,52 @@ def weave_fields(ctx: "Context", srcY, srcU, srcV, dst: DeviceClip, top_index=No
         _p(dst.Y), _p(dst.U), _p(dst.V), dst.strideY, dst.strideUV, dst.pitchY, dst.pitchUV, n))
 
 
+class AmtsFile:
+    """The stream-index file AMTSource is built from (amts%d.dat; SaveAMTSource / LoadAMTSource, AMTSource.hpp:835-871)."""
+
+    INFO = ("format", "width", "height", "displayWidth", "displayHeight", "sarWidth", "sarHeight", "frameRateNum", "frameRateDenom",
+            "colorPrimaries", "transferCharacteristics", "colorSpace", "progressive", "fixedFrameRate", "audioChannels", "sampleRate",
+            "decoderMpeg2", "decoderH264", "decoderHevc")
+
+    def __init__(self, path, ctx: "Context" = None):
+        self.lib = ctx.lib if ctx else binding.load()
+        self.h = self.lib.amtgpu_amts_load(ctx.h if ctx else None, str(path).encode())
+        if not self.h:
+            raise AmtError(f"cannot read {path}" + (": " + self.lib.amtgpu_last_error(ctx.h).decode(errors="replace") if ctx else ""))
+        info = np.zeros(19, np.int32)
+        nf, na = C.c_int(), C.c_int()
+        self.lib.amtgpu_amts_get_info(self.h, _p(info), C.byref(nf), C.byref(na))
+        self.info = dict(zip(self.INFO, map(int, info)))
+        self.num_frames, self.num_audio_frames = nf.value, na.value
+        b1, b2 = C.create_string_buffer(4096), C.create_string_buffer(4096)
+        self.lib.amtgpu_amts_get_paths(self.h, b1, 4096, b2, 4096)
+        self.srcpath, self.audiopath = b1.value.decode("utf-8"), b2.value.decode("utf-8")
+
+    def frames(self):
+        n = self.num_frames
+        out = dict(framePTS=np.zeros(n, np.int64), fileOffset=np.zeros(n, np.int64), keyFrame=np.zeros(n, np.int32),
+                   halfDelay=np.zeros(n, np.uint8), cmType=np.zeros(n, np.int32))
+        self.lib.amtgpu_amts_get_frames(self.h, _p(out["framePTS"]), _p(out["fileOffset"]), _p(out["keyFrame"]), _p(out["halfDelay"]),
+                                        _p(out["cmType"]))
+        return out
+
+    def weave_plan(self, picture_pts):
+        """(top_index, bottom_index) per frame for decoded pictures with these PTS in output order (AMTSource::OnFrameOutput);
+        -1 where the sequence cannot make the frame"""
+        pts = np.ascontiguousarray(picture_pts, np.int64)
+        top, bot = np.zeros(self.num_frames, np.int32), np.zeros(self.num_frames, np.int32)
+        if not self.lib.amtgpu_amts_weave_plan(self.h, _p(pts), len(pts), _p(top), _p(bot)):
+            raise AmtError("amtgpu_amts_weave_plan failed")
+        return top, bot
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.amtgpu_amts_destroy(self.h)
+        except Exception:
+            pass
+
+
 class Logo:
     """logo::LogoData + LogoHeader (AMTLogo.hpp:19-280)."""
 

@@ -41,6 +41,12 @@ SIGNATURES = {
     "amtgpu_download": (c_i, [c_p, c_p, c_p, c_u64]),
     "amtgpu_weave_fields_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
                                         c_i64, c_i64, c_i, c_i, c_i]),
+    "amtgpu_amts_load": (c_p, [c_p, c_s]),
+    "amtgpu_amts_destroy": (None, [c_p]),
+    "amtgpu_amts_get_info": (c_i, [c_p, c_p, c_p, c_p]),
+    "amtgpu_amts_get_paths": (c_i, [c_p, c_p, c_i, c_p, c_i]),
+    "amtgpu_amts_get_frames": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    "amtgpu_amts_weave_plan": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "amtgpu_logo_load": (c_p, [c_p, c_s]),
     "amtgpu_logo_from_planes": (c_p, [c_p] + [c_i] * 8 + [c_p]),
     "amtgpu_logo_save": (c_i, [c_p, c_p, c_s, c_s, c_i]),

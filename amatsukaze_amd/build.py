@@ -27,6 +27,7 @@ SOURCES = [
     "logo_fit.cpp",
     "decisions.cpp",
     "stats_decisions.cpp",
+    "amts_file.cpp",
 ]
 
 # -ffp-contract=off: the reference is built without FMA contraction (MSVC /fp:precise) and its scores

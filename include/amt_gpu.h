@@ -92,6 +92,25 @@ int   amtgpu_weave_fields_batch(AmtGpuContext* ctx, const void* dsrcY, const voi
                                 void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY, int pitchUV,
                                 int nframes);
 
+/* ---- the stream-index file AMTSource is built from: replaces LoadAMTSource's reader (AMTSource.hpp:854-871; writer :835-852,
+ *      File::writeArray framing CoreUtils.hpp:275-284, FilterSourceFrame StreamReform.hpp:145-154) and the frame-assembly rule of
+ *      AMTSource::OnFrameOutput (:482-566).  MSVC x64 POD layouts with 2-byte wchar_t, parsed with fixed offsets. ---- */
+typedef struct AmtGpuAmtsFile AmtGpuAmtsFile;
+AmtGpuAmtsFile* amtgpu_amts_load(AmtGpuContext* ctx, const char* path);      /* ctx may be NULL (no message kept then) */
+void amtgpu_amts_destroy(AmtGpuAmtsFile* a);
+/* out19 = VideoFormat {format, width, height, displayWidth, displayHeight, sarWidth, sarHeight, frameRateNum, frameRateDenom,
+ * colorPrimaries, transferCharacteristics, colorSpace, progressive, fixedFrameRate}, AudioFormat {channels, sampleRate},
+ * DecoderSetting {mpeg2, h264, hevc} */
+int  amtgpu_amts_get_info(const AmtGpuAmtsFile* a, int* out19, int* num_frames, int* num_audio_frames);
+/* source TS path and audio wave path, UTF-16 converted to UTF-8; 0 if a buffer is too small */
+int  amtgpu_amts_get_paths(const AmtGpuAmtsFile* a, char* srcpath, int cap_src, char* audiopath, int cap_audio);
+/* per-frame columns of the FilterSourceFrame list (num_frames entries each; any pointer may be NULL) */
+int  amtgpu_amts_get_frames(const AmtGpuAmtsFile* a, int64_t* framePTS, int64_t* fileOffset, int* keyFrame, uint8_t* halfDelay, int* cmType);
+/* Which decoded pictures make which frame: picture_pts = PTS of the decoded pictures in output order.  For frame i the top field
+ * comes from picture top_index[i] and the bottom field from bottom_index[i] (both -1: the frame cannot be made from this sequence,
+ * e.g. a half-delayed frame right after a discontinuity) -- the arrays amtgpu_weave_fields_batch takes. */
+int  amtgpu_amts_weave_plan(const AmtGpuAmtsFile* a, const int64_t* picture_pts, int npictures, int* top_index, int* bottom_index);
+
 /* ---- logo model: replaces LogoData::Load / Save (AMTLogo.hpp:239-279), LogoFile_* getters
  *      (LogoGUISupport.hpp:254-275) ---- */
 AmtGpuLogo* amtgpu_logo_load(AmtGpuContext* ctx, const char* path);

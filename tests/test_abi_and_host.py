@@ -223,3 +223,61 @@ def test_avisynth_plugin_registration(lib):
     assert len(lines) == 3 and lines[2]                       # the description string AviSynth shows
     sym = subprocess.run(["nm", "-D", "--defined-only", os.path.join(cpp, "libamt_avs_plugin.so")], capture_output=True, text=True).stdout
     assert " T AvisynthPluginInit3" in sym
+
+
+def test_amts_stream_index_reader_and_weave_plan(lib, tmp_path):
+    """amtgpu_amts_load parses a file laid out like SaveAMTSource's (AMTSource.hpp:835-852) and amtgpu_amts_weave_plan reproduces
+    AMTSource::OnFrameOutput's picture -> frame matching (:482-566): half-delayed frames take the previous picture's top field."""
+    import amts_util as A
+    step = 3003                                                       # 90 kHz ticks of a 29.97 fps frame
+    base = (1 << 33) - 4 * step                                       # the stream wraps its 33-bit PTS after four frames
+    fpts, half = [], []
+    for i in range(12):
+        fpts.append(base + i * step); half.append(False)
+    # a 3:2 pulldown stretch (:524-552): picture k yields a half-delayed frame AND a plain one with the same PTS
+    for j in range(4):
+        p = base + (12 + j) * step
+        fpts += [p, p]; half += [True, False]
+    for i in range(16, 22):
+        fpts.append(base + i * step); half.append(i % 5 == 0)
+    frames = [dict(halfDelay=h, frameIndex=i, pts=float(p), frameDuration=float(step), framePTS=p, fileOffset=188 * 1000 * i,
+                   keyFrame=(i // 15) * 15, cmType=i % 3) for i, (p, h) in enumerate(zip(fpts, half))]
+    path = tmp_path / "amts0.dat"
+    vf = (1, 1440, 1080, 1440, 1080, 4, 3, 30000, 1001, 1, 1, 1, False, True)
+    A.write_amts(path, "D:\\\\録画\\\\番組.ts", "D:\\\\tmp\\\\audio0.wav", vf, (2, 48000), frames, [(0, 0, 4096), (1, 4096, 4100)], (0, 2, 1))
+    h = lib.amtgpu_amts_load(None, str(path).encode())
+    assert h
+    info = np.zeros(19, np.int32)
+    nf, na = C.c_int(), C.c_int()
+    assert lib.amtgpu_amts_get_info(h, _ptr(info), C.byref(nf), C.byref(na))
+    assert info.tolist() == [1, 1440, 1080, 1440, 1080, 4, 3, 30000, 1001, 1, 1, 1, 0, 1, 2, 48000, 0, 2, 1]
+    assert nf.value == len(frames) and na.value == 2
+    b1, b2 = C.create_string_buffer(256), C.create_string_buffer(256)
+    assert lib.amtgpu_amts_get_paths(h, b1, 256, b2, 256)
+    assert b1.value.decode("utf-8") == "D:\\\\録画\\\\番組.ts" and b2.value.decode() == "D:\\\\tmp\\\\audio0.wav"
+    assert not lib.amtgpu_amts_get_paths(h, b1, 4, b2, 256)            # buffer too small
+    gp, go = np.zeros(nf.value, np.int64), np.zeros(nf.value, np.int64)
+    gk, gc, gh = np.zeros(nf.value, np.int32), np.zeros(nf.value, np.int32), np.zeros(nf.value, np.uint8)
+    assert lib.amtgpu_amts_get_frames(h, _ptr(gp), _ptr(go), _ptr(gk), _ptr(gh), _ptr(gc))
+    assert gp.tolist() == fpts and gh.tolist() == [int(x) for x in half]
+    assert go.tolist() == [f["fileOffset"] for f in frames] and gk.tolist() == [f["keyFrame"] for f in frames]
+    assert gc.tolist() == [f["cmType"] for f in frames]
+    # decoded pictures in output order: PTS truncated to 33 bits, one picture dropped (discontinuity), one unknown PTS
+    pics = [base + i * step for i in range(22)]
+    del pics[9]
+    pics.insert(5, base + 5 * step - 7)
+    pics = [p & ((1 << 33) - 1) for p in pics]
+    top, bot = np.zeros(nf.value, np.int32), np.zeros(nf.value, np.int32)
+    assert lib.amtgpu_amts_weave_plan(h, _ptr(np.array(pics, np.int64)), len(pics), _ptr(top), _ptr(bot))
+    wt, wb = A.reference_plan(fpts, half, pics)
+    assert top.tolist() == wt and bot.tolist() == wb
+    assert (top < 0).sum() >= 1 and any(t != b for t, b in zip(wt, wb) if t >= 0)     # a lost frame and real two-picture weaves
+    lib.amtgpu_amts_destroy(h)
+    # truncated / corrupt files fail loudly, not with garbage
+    data = path.read_bytes()
+    for cut in (3, 40, len(data) - 5):
+        bad = tmp_path / f"cut{cut}.dat"
+        bad.write_bytes(data[:cut])
+        assert not lib.amtgpu_amts_load(None, str(bad).encode())
+    (tmp_path / "neg.dat").write_bytes(b"\\xff" * 8 + data[8:])
+    assert not lib.amtgpu_amts_load(None, str(tmp_path / "neg.dat").encode())

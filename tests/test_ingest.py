@@ -92,3 +92,48 @@ def test_gpu_weave_matches_oracle(W, H, bits, pad, nv12):
     assert np.array_equal(out2.Y[3].cpu().numpy().view(dt)[:, :W], eY)
     assert np.array_equal(out2.U[3].cpu().numpy().view(dt)[:, :W // 2], eU)
     assert np.array_equal(out2.V[3].cpu().numpy().view(dt)[:, :W // 2], eV)
+
+
+@pytest.mark.gpu
+def test_gpu_frames_assembled_from_an_amts_index(tmp_path):
+    """decoded pictures + an amts%d.dat stream index -> frames: amtgpu_amts_weave_plan feeds amtgpu_weave_fields_batch's index
+    arrays (AMTSource::OnFrameOutput + MakeFrame, AMTSource.hpp:482-566, 357-366); half-delayed frames take their top field
+    from the previous picture."""
+    import torch
+    import amts_util as A
+    from amatsukaze_amd import AmtsFile, Context, DeviceClip, weave_fields
+    W, H, bits, P = 352, 240, 8, 9
+    rng = np.random.default_rng(99)
+    Y, U, V = make_pictures(rng, P, W, H, bits, W, W // 2, False)
+    step, base = 3003, 900000
+    fpts, half = [], []
+    for i in range(P):
+        if i in (3, 6):                                   # picture i yields a half-delayed frame and a plain one (same PTS)
+            fpts += [base + i * step] * 2; half += [True, False]
+        else:
+            fpts.append(base + i * step); half.append(i == 0)          # frame 0 half-delayed with nothing before it: cannot be made
+    frames = [dict(halfDelay=h, frameIndex=i, pts=float(p), frameDuration=float(step), framePTS=p, fileOffset=188 * i, keyFrame=0, cmType=0)
+              for i, (p, h) in enumerate(zip(fpts, half))]
+    path = tmp_path / "amts0.dat"
+    A.write_amts(path, "in.ts", "in.wav", (1, W, H, W, H, 1, 1, 30000, 1001, 1, 1, 1, False, True), (2, 48000), frames, [])
+    af = AmtsFile(path)
+    assert af.num_frames == len(frames) and af.info["width"] == W and af.srcpath == "in.ts"
+    top, bot = af.weave_plan([base + i * step for i in range(P)])
+    wt, wb = A.reference_plan(fpts, half, [base + i * step for i in range(P)])
+    assert top.tolist() == wt and bot.tolist() == wb and top[0] == -1 and (top[1:] >= 0).all()
+    made = np.nonzero(top >= 0)[0]
+    dev = torch.device("cuda:0")
+    out = DeviceClip(torch.zeros((len(made), H, W), dtype=torch.uint8, device=dev), torch.zeros((len(made), H // 2, W // 2), dtype=torch.uint8, device=dev),
+                     torch.zeros((len(made), H // 2, W // 2), dtype=torch.uint8, device=dev), W, H, bits)
+    ctx = Context(0)
+    weave_fields(ctx, torch.from_numpy(Y).to(dev), torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev), out, top[made], bot[made], False)
+    torch.cuda.synchronize()
+    orc = Oracle()
+    for j, i in enumerate(made):
+        oY = np.zeros((H, W), np.uint8); oU = np.zeros((H // 2, W // 2), np.uint8); oV = np.zeros((H // 2, W // 2), np.uint8)
+        t, b = int(top[i]), int(bot[i])
+        orc.lib.orc_merge_field(_ptr(Y[t]), _ptr(U[t]), _ptr(V[t]), _ptr(Y[b]), _ptr(U[b]), _ptr(V[b]), W, W // 2, 0, bits, W, H,
+                                _ptr(oY), _ptr(oU), _ptr(oV), W, W // 2)
+        assert out.Y[j].cpu().numpy().tobytes() == oY.tobytes() and out.U[j].cpu().numpy().tobytes() == oU.tobytes()
+        assert out.V[j].cpu().numpy().tobytes() == oV.tobytes()
+    assert any(top[i] != bot[i] for i in made)
