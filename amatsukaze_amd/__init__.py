@@ -4,7 +4,7 @@ Product code only: HIP kernels + C ABI (csrc/, libamt_gpu.so) and the Python mir
 filter interface (api.py).  Nothing here imports the CPU oracle.
 """
 from .api import (AMTAnalyzeLogo, AMTEraseLogo, AmtError, AmtsFile, Context, DeviceClip, FrameStats, Logo, LogoFrame,
-                  LogoScan, ScanLogo, weave_fields)
+                  LogoScan, ScanLogo, ScanLogoFile, weave_fields)
 
 __all__ = ["AMTAnalyzeLogo", "AMTEraseLogo", "AmtError", "AmtsFile", "Context", "DeviceClip", "FrameStats", "Logo", "LogoFrame",
-           "LogoScan", "ScanLogo", "weave_fields"]
+           "LogoScan", "ScanLogo", "ScanLogoFile", "weave_fields"]

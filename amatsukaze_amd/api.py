@@ -423,6 +423,13 @@ def ScanLogo(ctx: Context, clip: DeviceClip, serviceid, dstpath, imgx, imgy, w, 
     return bool(ok)
 
 
+def ScanLogoFile(ctx: Context, srcpath, serviceid, workfile, dstpath, imgx, imgy, w, h, thy, numMaxFrames, cb=None):
+    """ScanLogo with the reference's own argument list (LogoScan.hpp:1083-1098) over a raw 'AMTR' clip file; True/False like it."""
+    cbf = binding.CB(cb) if cb else binding.CB(lambda p, a, b, c: 1)
+    return bool(ctx.lib.amtgpu_scanlogo_file(ctx.h, str(srcpath).encode(), serviceid, str(workfile).encode(), str(dstpath).encode(), imgx, imgy,
+                                             w, h, thy, numMaxFrames, cbf))
+
+
 class FrameStats:
     """Self-specified whole-frame field-difference / combing metrics."""
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "amtgpu_logoscan_set_sums": (c_i, [c_p, c_p, c_p, c_i]),
     "amtgpu_logoscan_get_logo": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i, c_i]),
     "amtgpu_scanlogo": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
+    "amtgpu_scanlogo_file": (c_i, [c_p, c_s, c_i, c_s, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
     "amtgpu_logoframe_allgather_results": (c_i, [c_p, c_p, c_i, c_i]),
     "amtgpu_scanlogo_sharded": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
     "amtgpu_framestats_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),

@@ -309,6 +309,58 @@ void reduce_scan(AmtGpuLogoScan* s, const AmtGpuCollectives* coll, int64_t& canc
     if (!amtgpu_logoscan_set_sums(s, buf.data(), buf.data() + npx, (int)buf[npx + 6])) throw std::runtime_error(s->ctx->err);
 }
 
+// ReMakeLogo twice (LogoScan.hpp:923-1036, 1065-1071) over a device-resident clip: `kept` lists the frames round 0 accepted (indices into
+// the clip), whose rectangle sits at (cx, cy); the finished logo's header gets (himgw, himgh, himgx, himgy).
+template <typename Progress>
+std::unique_ptr<AmtGpuLogo> remake_rounds(AmtGpuContext* c, const AmtGpuCollectives* coll, AmtGpuLogoScan* scan0, const void* dY, const void* dU,
+                                          const void* dV, int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int cx, int cy, int w, int h,
+                                          int thy, const std::vector<int>& kept, const std::vector<int4>& keptVerdict, int himgw, int himgh,
+                                          int himgx, int himgy, Progress&& progress, int64_t& cancel)
+{
+    const int bits = 8;
+    const int numFrames = (int)kept.size();
+    std::unique_ptr<AmtGpuLogo> logo(amtgpu_logoscan_get_logo(scan0, 255, 0, himgw, himgh, himgx, himgy));
+    if (!logo) throw std::runtime_error(c->err);
+    DevBuf<int> dMap;
+    if (numFrames) dMap.upload(kept, c->stream);
+    std::vector<float> fades(20);
+    for (int fi = 0; fi < 20; ++fi) fades[fi] = 0.1f * fi;
+    DevBuf<float> dEval((size_t)std::max(1, numFrames) * 20);
+    std::vector<float> hEval((size_t)numFrames * 20);
+    for (int round = 0; round < 2; ++round) {
+        EvalLogoSpec S;
+        S.planes = deinterlaced_logo(logo->planes);
+        S.tables = build_mask_tables(S.planes, 0.1f);
+        S.imgx = cx; S.imgy = cy; S.row0 = 0; S.row_step = 1; S.deint = 1; S.out_off = 0;
+        std::vector<EvalLogoSpec> specs;
+        specs.push_back(std::move(S));
+        EvalEngine eng(c, std::move(specs), fades, true, 20, "logo_eval_fused_kernel.remake");
+        std::vector<uint8_t> use(numFrames, 0);
+        if (numFrames) {
+            eng.run(dY, strideY, pitchY, bits, numFrames, dEval.get(), dMap.get());
+            AMT_HIP(hipMemcpyAsync(hEval.data(), dEval.get(), hEval.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            AMT_HIP(hipStreamSynchronize(c->stream));
+        }
+        for (int i = 0; i < numFrames; ++i) {
+            float best = FLT_MAX;
+            int bestIdx = 0;
+            for (int fi = 0; fi < 20; ++fi)
+                if (hEval[(size_t)i * 20 + fi] < best) { best = hEval[(size_t)i * 20 + fi]; bestIdx = fi; }
+            use[i] = bestIdx > 8;                       // logo clearly present in this frame
+        }
+        progress(50.0f + 25.0f * round + 12.5f, numFrames, numFrames, numFrames);
+        std::unique_ptr<AmtGpuLogoScan> rescan(logoscan_new(c, w, h, 1, 1, thy));
+        if (numFrames)
+            logoscan_add(rescan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, cx, cy, numFrames, numFrames, use.data(), nullptr,
+                         kept.data(), keptVerdict.data());
+        reduce_scan(rescan.get(), coll, cancel);
+        if (cancel) throw std::runtime_error("Cancel requested");
+        logo.reset(amtgpu_logoscan_get_logo(rescan.get(), 255, 1, himgw, himgh, himgx, himgy));
+        if (!logo) throw std::runtime_error(c->err);
+    }
+    return logo;
+}
+
 int scanlogo_impl(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* dY, const void* dU, const void* dV, int64_t strideY,
                   int64_t strideUV, int pitchY, int pitchUV, int imgw, int imgh, int nframes, int serviceid, const char* dstpath,
                   int imgx, int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb)
@@ -369,46 +421,8 @@ int scanlogo_impl(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* d
             if (cancel) throw std::runtime_error("Cancel requested");
         }
         const int numFrames = (int)kept.size();
-        std::unique_ptr<AmtGpuLogo> logo(amtgpu_logoscan_get_logo(scan.get(), 255, 0, imgw, imgh, imgx, imgy));
-        if (!logo) throw std::runtime_error(c->err);
-
-        DevBuf<int> dMap;
-        if (numFrames) dMap.upload(kept, c->stream);
-        std::vector<float> fades(20);
-        for (int fi = 0; fi < 20; ++fi) fades[fi] = 0.1f * fi;
-        DevBuf<float> dEval((size_t)std::max(1, numFrames) * 20);
-        std::vector<float> hEval((size_t)numFrames * 20);
-        for (int round = 0; round < 2; ++round) {
-            EvalLogoSpec S;
-            S.planes = deinterlaced_logo(logo->planes);
-            S.tables = build_mask_tables(S.planes, 0.1f);
-            S.imgx = imgx; S.imgy = imgy; S.row0 = 0; S.row_step = 1; S.deint = 1; S.out_off = 0;
-            std::vector<EvalLogoSpec> specs;
-            specs.push_back(std::move(S));
-            EvalEngine eng(c, std::move(specs), fades, true, 20, "logo_eval_fused_kernel.remake");
-            std::vector<uint8_t> use(numFrames, 0);
-            if (numFrames) {
-                eng.run(dY, strideY, pitchY, bits, numFrames, dEval.get(), dMap.get());
-                AMT_HIP(hipMemcpyAsync(hEval.data(), dEval.get(), hEval.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-                AMT_HIP(hipStreamSynchronize(c->stream));
-            }
-            for (int i = 0; i < numFrames; ++i) {
-                float best = FLT_MAX;
-                int bestIdx = 0;
-                for (int fi = 0; fi < 20; ++fi)
-                    if (hEval[(size_t)i * 20 + fi] < best) { best = hEval[(size_t)i * 20 + fi]; bestIdx = fi; }
-                use[i] = bestIdx > 8;                       // logo clearly present in this frame
-            }
-            progress(50.0f + 25.0f * round + 12.5f, numFrames, numFrames, numFrames);
-            std::unique_ptr<AmtGpuLogoScan> rescan(logoscan_new(c, w, h, 1, 1, thy));
-            if (numFrames)
-                logoscan_add(rescan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, numFrames, numFrames,
-                             use.data(), nullptr, kept.data(), keptVerdict.data());
-            reduce_scan(rescan.get(), coll, cancel);
-            if (cancel) throw std::runtime_error("Cancel requested");
-            logo.reset(amtgpu_logoscan_get_logo(rescan.get(), 255, 1, imgw, imgh, imgx, imgy));
-            if (!logo) throw std::runtime_error(c->err);
-        }
+        std::unique_ptr<AmtGpuLogo> logo = remake_rounds(c, coll, scan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, w, h,
+                                                         thy, kept, keptVerdict, imgw, imgh, imgx, imgy, progress, cancel);
         progress(1, numFrames, numFrames, numFrames);
         if (dstpath && (!sharded || coll->rank == 0)) save_lgd(logo->planes, dstpath, "No Name", serviceid);
     });
@@ -424,6 +438,80 @@ int amtgpu_scanlogo(AmtGpuContext* c, const void* dY, const void* dU, const void
 {
     return scanlogo_impl(c, nullptr, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, imgw, imgh, nframes, serviceid, dstpath, imgx, imgy,
                          w, h, thy, numMaxFrames, cb);
+}
+
+// The reference's exported ScanLogo, argument for argument (LogoScan.hpp:1083-1098; C# P/Invoke AmatsukazeNatives.cs:391-393), over a
+// raw 8-bit 4:2:0 clip file instead of a transport stream (decode is out of scope): int32 {'AMTR', width, height, nframes} followed by
+// tight Y, U, V planes per frame.  Frames are streamed through the pinned ring in chunks; only the rectangles of accepted frames
+// stay in HBM for the two ReMakeLogo rounds (the reference keeps them in `workfile` through a lossless codec, :840-912 -- here the
+// argument is accepted and the file left untouched).
+int amtgpu_scanlogo_file(AmtGpuContext* c, const char* srcpath, int serviceid, const char* workfile, const char* dstpath, int imgx, int imgy,
+                         int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb)
+{
+    (void)workfile;
+    return guard(c, [&] {
+        auto progress = [&](float p, int nread, int total, int ngather) {
+            if (cb && !cb(p, nread, total, ngather)) throw std::runtime_error("Cancel requested");
+        };
+        std::ifstream f(srcpath, std::ios::binary);
+        if (!f) throw std::runtime_error(std::string("failed to open file ") + srcpath);
+        int32_t hdr[4];
+        f.read(reinterpret_cast<char*>(hdr), sizeof hdr);
+        if (!f || hdr[0] != 0x52544D41 || hdr[1] <= 0 || hdr[2] <= 0 || hdr[3] < 0 || (hdr[1] & 1) || (hdr[2] & 1))
+            throw std::runtime_error("not a raw AMTR clip (int32 'AMTR', width, height, frames; 8-bit 4:2:0 planes)");
+        const int W = hdr[1], H = hdr[2], N = hdr[3];
+        if (imgx < 0 || imgy < 0 || imgx + w > W || imgy + h > H) throw std::runtime_error("scan rectangle outside the frame");
+        if (numMaxFrames < 0) numMaxFrames = 0;
+        const size_t ysz = (size_t)W * H, csz = (size_t)(W / 2) * (H / 2), fsz = ysz + 2 * csz;
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>(1024, (256u << 20) / fsz));
+        const int wUV = w / 2, hUV = h / 2;
+        c->bind();
+        std::unique_ptr<AmtGpuLogoScan> scan(logoscan_new(c, w, h, 1, 1, thy));
+        DevBuf<uint8_t> dChunk(fsz * chunk);
+        // rectangles of the accepted frames, tight: Y [n][h][w], U / V [n][h/2][w/2]
+        const int cap = std::min(numMaxFrames, N);
+        DevBuf<uint8_t> cropY((size_t)std::max(1, cap) * w * h), cropU((size_t)std::max(1, cap) * wUV * hUV), cropV((size_t)std::max(1, cap) * wUV * hUV);
+        std::vector<uint8_t> host(fsz * chunk), planar(fsz * chunk);
+        std::vector<int4> keptVerdict;
+        int nkept = 0;
+        for (int f0 = 0; f0 < N && nkept < numMaxFrames; f0 += chunk) {
+            const int n = std::min(chunk, N - f0);
+            f.read(reinterpret_cast<char*>(host.data()), (std::streamsize)(fsz * n));
+            if (!f) throw std::runtime_error("raw clip truncated");
+            // file order is frame-interleaved (Y,U,V per frame); the device batch is plane-major: Y[n], U[n], V[n]
+            for (int i = 0; i < n; ++i) {
+                std::memcpy(planar.data() + ysz * i, host.data() + fsz * i, ysz);
+                std::memcpy(planar.data() + ysz * n + csz * i, host.data() + fsz * i + ysz, csz);
+                std::memcpy(planar.data() + ysz * n + csz * n + csz * i, host.data() + fsz * i + ysz + csz, csz);
+            }
+            if (!amtgpu_frames_upload(c, dChunk.get(), planar.data(), fsz * n) || !amtgpu_frames_upload_wait(c)) throw std::runtime_error(c->err);
+            const uint8_t *dY = dChunk.get(), *dU = dY + ysz * n, *dV = dU + csz * n;
+            std::vector<uint8_t> valid(n);
+            logoscan_add(scan.get(), dY, dU, dV, (int64_t)ysz, (int64_t)csz, W, W / 2, 8, imgx, imgy, n, numMaxFrames - nkept, nullptr, valid.data(),
+                         nullptr, nullptr);
+            for (int i = 0; i < n; ++i) {
+                if (!valid[i]) continue;
+                AMT_HIP(hipMemcpy2DAsync(cropY.get() + (size_t)nkept * w * h, w, dY + ysz * i + (size_t)imgy * W + imgx, W, w, h,
+                                         hipMemcpyDeviceToDevice, c->stream));
+                AMT_HIP(hipMemcpy2DAsync(cropU.get() + (size_t)nkept * wUV * hUV, wUV, dU + csz * i + (size_t)(imgy / 2) * (W / 2) + imgx / 2, W / 2,
+                                         wUV, hUV, hipMemcpyDeviceToDevice, c->stream));
+                AMT_HIP(hipMemcpy2DAsync(cropV.get() + (size_t)nkept * wUV * hUV, wUV, dV + csz * i + (size_t)(imgy / 2) * (W / 2) + imgx / 2, W / 2,
+                                         wUV, hUV, hipMemcpyDeviceToDevice, c->stream));
+                keptVerdict.push_back(scan->lastVerdicts[i]);
+                ++nkept;
+            }
+            AMT_HIP(hipStreamSynchronize(c->stream));          // the chunk buffer is refilled by the next upload
+            progress(50.0f * (f0 + n) / std::max(1, N), f0 + n, 0, nkept);
+        }
+        std::vector<int> kept(nkept);
+        for (int i = 0; i < nkept; ++i) kept[i] = i;
+        int64_t cancel = 0;
+        std::unique_ptr<AmtGpuLogo> logo = remake_rounds(c, nullptr, scan.get(), cropY.get(), cropU.get(), cropV.get(), (int64_t)w * h,
+                                                         (int64_t)wUV * hUV, w, wUV, 0, 0, w, h, thy, kept, keptVerdict, W, H, imgx, imgy, progress,
+                                                         cancel);
+        progress(1, nkept, nkept, nkept);
+        save_lgd(logo->planes, dstpath, "No Name", serviceid);
+    });
 }
 
 int amtgpu_scanlogo_sharded(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* dY, const void* dU, const void* dV,

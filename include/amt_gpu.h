@@ -217,6 +217,13 @@ int  amtgpu_scanlogo(AmtGpuContext* ctx, const void* dY, const void* dU, const v
                      int nframes, int serviceid, const char* dstpath, int imgx, int imgy, int w, int h,
                      int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb);
 
+/* The reference's exported ScanLogo with its own argument list (LogoScan.hpp:1083-1098; AmatsukazeNatives.cs:391-393):
+ * (ctx, srcpath, serviceid, workfile, dstpath, imgx, imgy, w, h, thy, numMaxFrames, cb) -> 1 ok / 0 fail + amtgpu_last_error.
+ * srcpath is a raw 8-bit 4:2:0 clip (int32 'AMTR', width, height, frames, then tight Y,U,V per frame) instead of a transport stream
+ * (demux / decode are out of scope); frames stream through the pinned ring, accepted rectangles stay in HBM; workfile is unused. */
+int  amtgpu_scanlogo_file(AmtGpuContext* ctx, const char* srcpath, int serviceid, const char* workfile, const char* dstpath,
+                          int imgx, int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb);
+
 /* ---- frame-sharded runs (one process per GPU).  The library does no communication itself: the host
  *      supplies two collectives over HOST memory -- RCCL in a C++ host (include/amt_rccl_collectives.hpp wraps an ncclComm_t),
  *      torch.distributed in the Python mirror (amatsukaze_amd/sharding.py).  Ranks hold contiguous frame ranges in stream

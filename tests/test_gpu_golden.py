@@ -96,3 +96,28 @@ def test_gpu_reproduces_reference_golden_hibit_hd(name):
         lf.begin(W, H, bits, N)
         ctx.check(ctx.lib.amtgpu_logoframe_scan_batch(lf.h, Yq.data_ptr(), int(Yq.stride(0)) * 2, 2 * int(Yq.stride(1)), 0, N))
         assert lf.evalResults.tobytes() == c["logoframe_evals_bytepitch"].tobytes()
+
+
+def test_gpu_scanlogo_file_export_reproduces_reference_lgd(tmp_path):
+    """amtgpu_scanlogo_file has the reference's ScanLogo argument list (LogoScan.hpp:1083-1098: srcpath, serviceid, workfile,
+    dstpath, imgx, imgy, w, h, thy, numMaxFrames, cb); on the raw clip the reference's shim decoder read when the golden file was
+    made it must write the very same .lgd.  Frames stream from the file in chunks; the callback can cancel."""
+    from amatsukaze_amd import Context, ScanLogoFile
+    from amtlib import write_raw_clip
+    g = G.load()
+    W, H, LW, LH, X, Y0 = (g[k] for k in ("W", "H", "LW", "LH", "X", "Y0"))
+    Y2, U2, V2 = G.frames(g, "scanlogo_crop_y", "scanlogo_crop_u", "scanlogo_crop_v")
+    raw = tmp_path / "clip.raw"
+    write_raw_clip(raw, Y2, U2, V2, W, H)
+    ctx = Context(0)
+    calls = []
+    dst = tmp_path / "out.lgd"
+    assert ScanLogoFile(ctx, raw, 1041, tmp_path / "work.dat", dst, X, Y0, LW, LH, 12, 25, lambda p, nread, total, ngather: calls.append((p, nread, ngather)) or 1)
+    assert dst.read_bytes() == g["scanlogo_lgd"].tobytes()
+    assert calls and calls[-1][0] == 1.0 and max(c[2] for c in calls) == 25 and not (tmp_path / "work.dat").exists()
+    # cancel from the callback -> 0 and the reference's message
+    assert not ScanLogoFile(ctx, raw, 1041, tmp_path / "work.dat", tmp_path / "x.lgd", X, Y0, LW, LH, 12, 25, lambda *a: 0)
+    assert b"Cancel requested" in ctx.lib.amtgpu_last_error(ctx.h)
+    # too few flat-bordered frames -> "Insufficient logo frames" like GetLogo (:380-395 through :1061-1064)
+    assert not ScanLogoFile(ctx, raw, 1041, "", tmp_path / "y.lgd", X, Y0, LW, LH, 12, 1)
+    assert not ScanLogoFile(ctx, tmp_path / "missing.raw", 1, "", tmp_path / "z.lgd", X, Y0, LW, LH, 12, 25)
