@@ -61,6 +61,13 @@ template <> struct Raw4<uint8_t> {
         v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
     }
     __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+    // buffer_load ... lds: the four samples go straight to LDS (lane l to dst[l]), no register is held while they travel
+    static __device__ __forceinline__ void request_lds(__amdgpu_buffer_rsrc_t r, unsigned* dst, unsigned voff, int soff, int)
+    {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 4, voff, soff, 0, 0);
+    }
+    __device__ __forceinline__ void from_lds(const unsigned* src, int lane, int) { v = src[lane]; }
+    static constexpr int kDwordsPerLane = 1;
     __device__ __forceinline__ int get(int k) const { return (int)((v >> (8 * k)) & 0xFFu); }
 };
 template <> struct Raw4<uint16_t> {
@@ -71,6 +78,13 @@ template <> struct Raw4<uint16_t> {
         v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
     }
     __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+    static __device__ __forceinline__ void request_lds(__amdgpu_buffer_rsrc_t r, unsigned* dst, unsigned voff, int soff, int nl)
+    {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 4, voff, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + nl), 4, voff + 4u, soff, 0, 0);
+    }
+    __device__ __forceinline__ void from_lds(const unsigned* src, int lane, int nl) { v = u2{src[lane], src[nl + lane]}; }
+    static constexpr int kDwordsPerLane = 2;
     __device__ __forceinline__ int get(int k) const { return (int)((v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu); }
 };
 
@@ -178,7 +192,8 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     const int nfades = NF > 0 ? NF : nfades_rt;
     extern __shared__ float lds[];
     f2* const planes = reinterpret_cast<f2*>(lds);                 // [2][plane_cap] {s, bg = a*s + b*maxv} of a band's rows, one frame each
-    float* const wpart = lds + 4 * plane_cap;                      // [2][kWaves][NFMAX] per-wave sums of the terms of an iteration
+    f2* const abp = planes + 2 * plane_cap;                        // [plane_cap] {a, b} of the current band's rows (frame-independent)
+    float* const wpart = lds + 6 * plane_cap;                      // [2][kWaves][NFMAX] per-wave sums of the terms of an iteration
     float* const accs = wpart + 2 * kWaves * NFMAX;                // [G][nfades] running sums
 
     const int logo = blockIdx.x / ngroups;
@@ -222,6 +237,30 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             raw[j].load_buf(rS, (unsigned)sx * ES, row * pitch * (int)ES);
         }
     };
+    // The same request without registers: the raw rows travel straight into LDS, into the first of the wave's OWN rows of the plane
+    // they will be converted into.  Only the lanes that stage columns take part (nl = ceil(w/4) of them), so the four raw rows occupy
+    // 4 * nl * sizeof(sample) * 4 <= 8 * (w + 8) bytes: one plane row always holds them.  pickup_raw collects them after the fade
+    // code; issued at the top of an iteration, the whole iteration covers the trip to HBM.
+    const int nl = (w + 3) >> 2;
+    auto request_raw = [&](const __amdgpu_buffer_rsrc_t rS, int y0, int nrows, f2* plane) {
+        const int rg = kStageRows * wave;
+        if (rg >= nrows || !slane) return;
+        const int y = y0 + rg;
+        unsigned* dst = reinterpret_cast<unsigned*>(plane + rg * lp);
+#pragma unroll
+        for (int j = 0; j < kStageRows + 2; ++j) {
+            const int row = L.deint ? min(max(y - 1 + j, 0), L.h - 1) : min(y + max(j - 1, 0), L.h - 1) * L.row_step;
+            Raw4<pix_t>::request_lds(rS, dst + j * nl * Raw4<pix_t>::kDwordsPerLane, (unsigned)sx * ES, row * pitch * (int)ES, nl);
+        }
+    };
+    auto pickup_raw = [&](int nrows, const f2* plane, Raw4<pix_t> (&raw)[kStageRows + 2]) {
+        const int rg = kStageRows * wave;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the LDS-direct loads are counted with the vector-memory loads
+        if (rg >= nrows || !slane) return;
+        const unsigned* src = reinterpret_cast<const unsigned*>(plane + rg * lp);
+#pragma unroll
+        for (int j = 0; j < kStageRows + 2; ++j) raw[j].from_lds(src + j * nl * Raw4<pix_t>::kDwordsPerLane, lane, nl);
+    };
     auto load_ab = [&](int y0, f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
         const int y = y0 + kStageRows * wave;
 #pragma unroll
@@ -231,12 +270,40 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             bv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)sx * 4u, ro, 0));
         }
     };
+    // the band's logo coefficients are the same for every frame: kept in LDS as {a, b} pairs, written and read by the wave that
+    // stages those rows (no barrier involved)
+    // (the column offset is made opaque where LDS addresses are formed: hoisted out of the iteration loop they would be kept in
+    //  registers the loop does not have, i.e. spilled to scratch and re-read every iteration)
+    auto ab_to_lds = [&](const f4 (&av)[kStageRows], const f4 (&bv)[kStageRows]) {
+        if (!slane) return;
+        int sxl = sx;
+        asm volatile("" : "+v"(sxl));
+#pragma unroll
+        for (int j = 0; j < kStageRows; ++j) {
+            f4* d = reinterpret_cast<f4*>(abp + (kStageRows * wave + j) * lp + sxl);
+            d[0] = f4{av[j][0], bv[j][0], av[j][1], bv[j][1]};
+            d[1] = f4{av[j][2], bv[j][2], av[j][3], bv[j][3]};
+        }
+    };
+    auto ab_from_lds = [&](f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
+        int sxl = sx;
+        asm volatile("" : "+v"(sxl));
+#pragma unroll
+        for (int j = 0; j < kStageRows; ++j) {
+            const f4* d = reinterpret_cast<const f4*>(abp + (kStageRows * wave + j) * lp + min(sxl, lp - 4));
+            const f4 lo = d[0], hi = d[1];
+            av[j] = f4{lo[0], lo[2], hi[0], hi[2]};
+            bv[j] = f4{lo[1], lo[3], hi[1], hi[3]};
+        }
+    };
     // Samples are converted byte-wise and the [1 2 1] vertical blend of DeintY (LogoScan.hpp:763-780) is done on the floats: every
     // intermediate is an integer below 2^24, so (r0 + 2 r1 + r2 + 2) * 0.25 equals the reference's (float)(int sum) / 4.0f bit for bit
     auto convert_store = [&](f2* plane, int y0, int nrows, const Raw4<pix_t> (&raw)[kStageRows + 2], const f4 (&av)[kStageRows],
                              const f4 (&bv)[kStageRows]) {
         const int rg = kStageRows * wave;
         if (!slane) return;
+        int sxl = sx;
+        asm volatile("" : "+v"(sxl));
         f4 fr[kStageRows + 2];
 #pragma unroll
         for (int j = 0; j < kStageRows + 2; ++j)
@@ -253,7 +320,7 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
                 } else {
                     sv = fr[j + 1];
                 }
-                store_pairs(plane + (rg + j) * lp + sx, sv, av[j], bv[j], maxv);
+                store_pairs(plane + (rg + j) * lp + sxl, sv, av[j], bv[j], maxv);
             }
         }
     };
@@ -266,6 +333,7 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
         f4 av[kStageRows], bv[kStageRows];
         load_raw(frame_rsrc(0), B.y0, raw);
         load_ab(B.y0, av, bv);
+        ab_to_lds(av, bv);
         convert_store(planes, B.y0, B.nrows, raw, av, bv);
     }
     bool act = false;
@@ -297,10 +365,12 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
         const bool next_band = g + 1 == gcount;
         const int ng = next_band ? 0 : g + 1;
         EvalBand Bn = B;
-        if (has_next && next_band) Bn = bands[X.band0 + bi + 1];
-        // ---- 1. request the next iteration's raw rows ----
-        Raw4<pix_t> raw[kStageRows + 2];
-        if (has_next) load_raw(frame_rsrc(ng), Bn.y0, raw);
+        if (has_next && next_band) {
+            const EvalBand* nb = bands + X.band0 + bi + 1;
+            Bn.m0 = nb->m0; Bn.npix = nb->npix; Bn.y0 = nb->y0; Bn.nrows = nb->nrows;
+        }
+        // ---- 1. request the next iteration's raw rows (LDS-direct: no registers held) ----
+        if (has_next) request_raw(frame_rsrc(ng), Bn.y0, Bn.nrows, planes + (cur ^ 1) * plane_cap);
         // ---- 2. fold the previous iteration's per-wave sums into the running sums (fixed order: deterministic) ----
         if (it > 0 && tid < nfades) {
             const float* wp = wpart + (cur ^ 1) * kWaves * NFMAX + tid;
@@ -326,9 +396,7 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             R = window_corr(Kp, W, M);
         }
 #endif
-        // ---- 4. request the next iteration's logo coefficients (the window registers are free again) ----
         f4 av[kStageRows], bv[kStageRows];
-        if (has_next) load_ab(Bn.y0, av, bv);
         // ---- 5. all fades from the two pairs: interpolated mean -> bin -> scale gather, all in flight together; while they travel
         //      the next iteration's rows are converted into the other plane (loads return in order: raw rows and coefficients
         //      were requested earlier); then correlation and per-pixel term (LogoScan.hpp:305-308), summed over the wave.
@@ -347,7 +415,13 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
             const int q = (int)__builtin_fmaf(fade, dMq, m0q);
             emin = min(emin, (unsigned)(q + dq) & 0x7FFFu);
+#ifdef AMT_LIN_NO_GATHER
+            dst = f2{1e-4f * (float)(q >> 15), 0.5f};
+#elif defined(AMT_LIN_GATHER_BIN0)
+            dst = gld<f2>(gScales, __umul24((unsigned)min(max(q >> 25, 0), 31), cpad8) + m8);     // every lane reads bin 0: fully coalesced
+#else
             dst = gld<f2>(gScales, __umul24((unsigned)min(max(q >> 15, 0), 31), cpad8) + m8);
+#endif
         };
         auto finish = [&](int f, const f2& sc) {
             const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
@@ -381,6 +455,9 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             }
         }
 #endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next && next_band) load_ab(Bn.y0, av, bv);     // once per band: from memory (the wave sums below cover the trip)
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef AMT_LIN_NO_REDUCE
         if (lane == 63) wpart[(cur * kWaves + wave) * NFMAX] = term[0] + term[NFMAX - 1];
 #else
@@ -393,10 +470,15 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
         }
 #endif
 #ifndef AMT_LIN_NO_STAGE
-        if (has_next) convert_store(planes + (cur ^ 1) * plane_cap, Bn.y0, Bn.nrows, raw, av, bv);
+        if (has_next) {
+            Raw4<pix_t> raw[kStageRows + 2];
+            pickup_raw(Bn.nrows, planes + (cur ^ 1) * plane_cap, raw);
+            if (next_band) ab_to_lds(av, bv); else ab_from_lds(av, bv);
+            convert_store(planes + (cur ^ 1) * plane_cap, Bn.y0, Bn.nrows, raw, av, bv);
+        }
 #endif
         __syncthreads();                         // next plane and this iteration's wave sums complete; current plane consumed
-        if (next_band) { B = Bn; ++bi; }
+        if (next_band) { B.m0 = Bn.m0; B.npix = Bn.npix; B.y0 = Bn.y0; B.nrows = Bn.nrows; ++bi; }
         g = ng;
     }
     // the last iteration's wave sums
@@ -426,7 +508,7 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     const int ngroups = (nframes + G - 1) / G;
     const float maxv = (float)((1 << bits) - 1);
     const int nfmax = nfades == 11 ? 11 : kLinMaxFades;
-    const size_t lds = ((size_t)4 * plane_cap + (size_t)2 * (kLinThreads / 64) * nfmax + (size_t)G * nfades) * sizeof(float);
+    const size_t lds = ((size_t)6 * plane_cap + (size_t)2 * (kLinThreads / 64) * nfmax + (size_t)G * nfades) * sizeof(float);
     dim3 grid((unsigned)((long long)ngroups * nlogos));
 #define AMT_LAUNCH(T, N)                                                                                                              \
     hipLaunchKernelGGL((logo_eval_linear_kernel<T, N>), grid, dim3(kLinThreads), lds, st, dlogos, dlins, dbands, dfades, nfades, fade0,   \

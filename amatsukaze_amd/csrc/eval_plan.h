@@ -39,7 +39,8 @@ constexpr int kLinThreads = 512;    // threads per workgroup = mask pixels per b
 constexpr int kLinBandPix = kLinThreads;
 constexpr int kLinBandRows = 2 * (kLinThreads / 64);   // rows a band may touch: each wave stages two rows per iteration
 constexpr int kLinMaxFades = 12;    // fades per launch (11 for AMTAnalyzeLogo)
-constexpr int kLinPlaneCap = 3328;  // {s,bg} pairs an LDS plane holds (8 B each): 12 rows of a 256-wide logo
+constexpr int kLinPlaneCap = 3200;  // pairs an LDS plane holds (8 B each; 12 rows of a 256-wide logo): two {s,bg} planes + one {a,b}
+                                    // plane + the sums = 78 KB per workgroup, two workgroups per CU
 struct LinLogoDev {
     const float2* kpix;      // [13][count_pad]  taps of mask pixel m as pairs {k[2j], k[2j+1]} (k[25] = 0), pair-major
     const uint32_t* pos;     // [count_pad]  (y << 16) | x of mask pixel m

@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive (streamed) measurement")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-erase", action="store_true")
+    ap.add_argument("--no-alt-mode", action="store_true", help="do not time the other analysis mode after the timed region (profiling runs)")
     ap.add_argument("--analysis-mode", choices=("linear", "exact"), default="linear",
                     help="AMTAnalyzeLogo evaluation: linear = all fades from one window evaluation of s and bg, decisions guarded by exact "
                          "re-evaluation (identical fades / erased frames, scores within 1e-4); exact = the reference's fp32 order for every fade")
@@ -512,7 +513,7 @@ def main():
 
     # the other analysis mode, for the record (outside the timed region): the same 10 000-frame launch
     alt_prof = {}
-    if rank == 0:
+    if rank == 0 and not args.no_alt_mode:
         alt = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO, mode="exact" if args.analysis_mode == "linear" else "linear")
         alt.analyze_device(dclip.Y, 8, d_analysis)
         torch.cuda.synchronize()
