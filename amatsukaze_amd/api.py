@@ -298,7 +298,7 @@ class LogoFrame:
 class AMTAnalyzeLogo:
     """logo::AMTAnalyzeLogo (LogoScan.hpp:1106-1236); GetFrames returns 33 floats per source frame."""
 
-    MODES = {"exact": 0, "linear": 1}
+    MODES = {"exact": 0, "linear": 1, "linear_unguarded": 2}
 
     def __init__(self, ctx: Context, logo, maskratio: float = 0.35, mode: str = "exact"):
         """mode "exact": records bit-identical to the reference's; "linear": all fades from one evaluation of the source and one

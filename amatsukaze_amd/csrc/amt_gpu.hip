@@ -474,6 +474,7 @@ static void analyze_run(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride,
     if (an->dList.size() < (size_t)nframes) an->dList.alloc(nframes);
     if (an->dCount.size() < 1) an->dCount.alloc(1);
     an->engine->run_linear(dY, frame_stride, pitch, bits, nframes, dout);
+    if (an->mode == AMTGPU_ANALYZE_LINEAR_UNGUARDED) return;
     float eps[3];
     for (int k = 0; k < 3; ++k) eps[k] = 2.0f * an->engine->linear_error_bound(k, bits);
     const int sp = an->ctx->prof_begin("analysis_mark_kernel");
@@ -538,8 +539,9 @@ int amtgpu_analyze_batch(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride
 int amtgpu_analyze_set_mode(AmtGpuAnalyze* an, int mode)
 {
     return guard(an->ctx, [&] {
-        if (mode != AMTGPU_ANALYZE_EXACT && mode != AMTGPU_ANALYZE_LINEAR_GUARDED) throw std::runtime_error("unknown analysis mode");
-        if (mode == AMTGPU_ANALYZE_LINEAR_GUARDED) (void)an->engine->linear_error_bound(0, 8);   // builds the tables; throws for logos the kernel does not take (wider than 256)
+        if (mode != AMTGPU_ANALYZE_EXACT && mode != AMTGPU_ANALYZE_LINEAR_GUARDED && mode != AMTGPU_ANALYZE_LINEAR_UNGUARDED)
+            throw std::runtime_error("unknown analysis mode");
+        if (mode != AMTGPU_ANALYZE_EXACT) (void)an->engine->linear_error_bound(0, 8);   // builds the tables; throws for logos the kernel does not take (wider than 256)
         an->mode = mode;
     });
 }
@@ -548,7 +550,7 @@ int amtgpu_analyze_last_refined(AmtGpuAnalyze* an)
 {
     int n = -1;
     guard(an->ctx, [&] {
-        if (an->mode == AMTGPU_ANALYZE_EXACT || an->dCount.size() < 1) { n = 0; return; }
+        if (an->mode != AMTGPU_ANALYZE_LINEAR_GUARDED || an->dCount.size() < 1) { n = 0; return; }
         an->ctx->bind();
         AMT_HIP(hipMemcpyAsync(&n, an->dCount.get(), sizeof(int), hipMemcpyDeviceToHost, an->ctx->stream));
         AMT_HIP(hipStreamSynchronize(an->ctx->stream));

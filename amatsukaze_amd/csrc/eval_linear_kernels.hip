@@ -256,6 +256,9 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     auto pickup_raw = [&](int nrows, const f2* plane, Raw4<pix_t> (&raw)[kStageRows + 2]) {
         const int rg = kStageRows * wave;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the LDS-direct loads are counted with the vector-memory loads
+#ifdef AMT_LIN_DMA_BARRIER
+        __syncthreads();
+#endif
         if (rg >= nrows || !slane) return;
         const unsigned* src = reinterpret_cast<const unsigned*>(plane + rg * lp);
 #pragma unroll
@@ -274,22 +277,24 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     // stages those rows (no barrier involved)
     // (the column offset is made opaque where LDS addresses are formed: hoisted out of the iteration loop they would be kept in
     //  registers the loop does not have, i.e. spilled to scratch and re-read every iteration)
-    auto ab_to_lds = [&](const f4 (&av)[kStageRows], const f4 (&bv)[kStageRows]) {
+    auto ab_to_lds = [&](int nrows, const f4 (&av)[kStageRows], const f4 (&bv)[kStageRows]) {
         if (!slane) return;
         int sxl = sx;
         asm volatile("" : "+v"(sxl));
 #pragma unroll
         for (int j = 0; j < kStageRows; ++j) {
+            if (kStageRows * wave + j >= nrows) break;         // the plane holds the rows of the tallest band, not 2 * kWaves
             f4* d = reinterpret_cast<f4*>(abp + (kStageRows * wave + j) * lp + sxl);
             d[0] = f4{av[j][0], bv[j][0], av[j][1], bv[j][1]};
             d[1] = f4{av[j][2], bv[j][2], av[j][3], bv[j][3]};
         }
     };
-    auto ab_from_lds = [&](f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
+    auto ab_from_lds = [&](int nrows, f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
         int sxl = sx;
         asm volatile("" : "+v"(sxl));
 #pragma unroll
         for (int j = 0; j < kStageRows; ++j) {
+            if (kStageRows * wave + j >= nrows) break;
             const f4* d = reinterpret_cast<const f4*>(abp + (kStageRows * wave + j) * lp + min(sxl, lp - 4));
             const f4 lo = d[0], hi = d[1];
             av[j] = f4{lo[0], lo[2], hi[0], hi[2]};
@@ -333,7 +338,7 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
         f4 av[kStageRows], bv[kStageRows];
         load_raw(frame_rsrc(0), B.y0, raw);
         load_ab(B.y0, av, bv);
-        ab_to_lds(av, bv);
+        ab_to_lds(B.nrows, av, bv);
         convert_store(planes, B.y0, B.nrows, raw, av, bv);
     }
     bool act = false;
@@ -370,7 +375,9 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             Bn.m0 = nb->m0; Bn.npix = nb->npix; Bn.y0 = nb->y0; Bn.nrows = nb->nrows;
         }
         // ---- 1. request the next iteration's raw rows (LDS-direct: no registers held) ----
+#ifndef AMT_LIN_NO_DMA
         if (has_next) request_raw(frame_rsrc(ng), Bn.y0, Bn.nrows, planes + (cur ^ 1) * plane_cap);
+#endif
         // ---- 2. fold the previous iteration's per-wave sums into the running sums (fixed order: deterministic) ----
         if (it > 0 && tid < nfades) {
             const float* wp = wpart + (cur ^ 1) * kWaves * NFMAX + tid;
@@ -472,8 +479,12 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
 #ifndef AMT_LIN_NO_STAGE
         if (has_next) {
             Raw4<pix_t> raw[kStageRows + 2];
+#ifdef AMT_LIN_NO_DMA
+            load_raw(frame_rsrc(ng), Bn.y0, raw);
+#else
             pickup_raw(Bn.nrows, planes + (cur ^ 1) * plane_cap, raw);
-            if (next_band) ab_to_lds(av, bv); else ab_from_lds(av, bv);
+#endif
+            if (next_band) ab_to_lds(Bn.nrows, av, bv); else ab_from_lds(Bn.nrows, av, bv);
             convert_store(planes + (cur ^ 1) * plane_cap, Bn.y0, Bn.nrows, raw, av, bv);
         }
 #endif

@@ -457,8 +457,17 @@ def main():
     h_analysis = torch.empty((N, 33), dtype=torch.float32).pin_memory()
     an_ready = torch.cuda.Event()
     last = {}
+    # AMTEraseLogo rewrites the logo rectangle in place; every frame is erased ONCE in a real run, so the step puts the rectangles
+    # back (48 KB per frame, device to device) instead of analysing frames that were already erased by the previous step
+    rect = (dclip.Y[:, IMGY:IMGY + LH, IMGX:IMGX + LW].clone(), dclip.U[:, IMGY // 2:(IMGY + LH) // 2, IMGX // 2:(IMGX + LW) // 2].clone(),
+            dclip.V[:, IMGY // 2:(IMGY + LH) // 2, IMGX // 2:(IMGX + LW) // 2].clone())
 
-    def step(collective=True):
+    def restore_rectangles():
+        dclip.Y[:, IMGY:IMGY + LH, IMGX:IMGX + LW].copy_(rect[0])
+        dclip.U[:, IMGY // 2:(IMGY + LH) // 2, IMGX // 2:(IMGX + LW) // 2].copy_(rect[1])
+        dclip.V[:, IMGY // 2:(IMGY + LH) // 2, IMGX // 2:(IMGX + LW) // 2].copy_(rect[2])
+
+    def step(collective=True, restore=True):
         analyzer.analyze_device(dclip.Y, 8, d_analysis)              # a11: 33 evaluations per frame
         h_analysis.copy_(d_analysis, non_blocking=True)              # stream-ordered behind the analysis kernel
         an_ready.record()
@@ -469,6 +478,8 @@ def main():
             fades = eraser.calc_fades(h_analysis.numpy(), N)         # a12 CalcFade / CalcFade2
             eraser.erase(dclip, fades)                               # a12 Delogo, in place
             last["fades"] = fades
+            if restore:
+                restore_rectangles()                                 # bench housekeeping (inside the timed region, ~0.3 ms)
         if world > 1 and collective:
             ev = torch.from_numpy(lf.evalResults).to(dev)
             SH.gather_frame_records(ev, N * world)                   # the scan's one exchange step (RCCL all_gather)
@@ -498,13 +509,18 @@ def main():
         for (b0, bn) in blocks:
             pristine[(b0, bn)] = (dclip.Y[b0:b0 + bn].cpu().numpy(), dclip.U[b0:b0 + bn].cpu().numpy(), dclip.V[b0:b0 + bn].cpu().numpy(),
                                   dclip.Y[b0 - 1].cpu().numpy() if b0 > 0 else None)
-        step(collective=False)                                       # rank 0 alone
+        step(collective=False, restore=False)                        # rank 0 alone; the erased frames are what gets checked
         torch.cuda.synchronize()
         outputs = (lf.evalResults, h_analysis.numpy(), last.get("fades"), dclip, d_stats.cpu().numpy().astype(np.uint64))
         verified = verify_step(N, blocks, outputs, pristine, logos_np, not args.no_erase, 1e-4 if args.analysis_mode == "linear" else 0.0)
         verified["analysis_mode"] = args.analysis_mode
         verified["analysis_compare"] = "bytes" if args.analysis_mode == "exact" else "abs <= 1e-4 (fades and erased frames: bytes)"
         verified["guard_refined_frames"] = analyzer.last_refined()
+        if args.analysis_mode == "linear" and verified["guard_refined_frames"] > N // 20:
+            # the guard re-evaluates close calls; if it has to redo a large share of the batch the linear kernel itself is off
+            # (its errors would be masked by the exact re-evaluation and paid for in time)
+            verified["ok"] = False
+            verified["guard_overused"] = True
         if not verified["ok"]:
             print(json.dumps({"verified": verified}), file=sys.stderr, flush=True)
             raise SystemExit("bench verification FAILED: the timed configuration's outputs differ from the CPU oracle")
@@ -585,7 +601,7 @@ def main():
         for name, (calls, ms) in alt_prof.items():
             if calls and name not in out_kern:
                 out_kern[name] = kernel_entry(name, calls, ms, N, False)
-        timed = {n: e for n, e in out_kern.items() if e["inside_timed_region"]}
+        timed = {n: e for n, e in out_kern.items() if e["inside_timed_region"] and "bound" in e}
         dom = max(timed, key=lambda n: timed[n]["avg_ms"] * timed[n]["launches"]) if timed else None
         roofline = None
         if dom:

@@ -172,6 +172,7 @@ int  amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_
  *     the exact kernel before the batch is handed out -- amtgpu_erase_calc_fades returns identical fades in both modes. */
 #define AMTGPU_ANALYZE_EXACT 0
 #define AMTGPU_ANALYZE_LINEAR_GUARDED 1
+#define AMTGPU_ANALYZE_LINEAR_UNGUARDED 2   /* the linear evaluation alone, without the argmin guard: for accuracy tests and profiling */
 int   amtgpu_analyze_set_mode(AmtGpuAnalyze* an, int mode);
 /* frames of the most recent batch that the guard re-evaluated exactly (synchronises); 0 in exact mode, -1 on error */
 int   amtgpu_analyze_last_refined(AmtGpuAnalyze* an);

@@ -114,3 +114,43 @@ def test_mask_ratio_extremes(gpu, maskratio):
     want = np.zeros(cfg["N"] * 33, np.float32)
     cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
     assert got.reshape(-1).tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("bits", [8, 10, 16])
+@pytest.mark.parametrize("shape,maskratio", [("w98_ragged", 0.35), ("origin_mod4_2", 0.35), ("tall_narrow", 0.35), ("w98_ragged", 1.0),
+                                             ("origin_mod4_2", 0.02)])
+def test_analyze_linear_mode_shapes(gpu, shape, maskratio, bits):
+    """The guarded linear mode on the shapes its staging special-cases: a ragged right edge (w % 4 == 2: the last lane group is
+    shifted left), an origin that is not 4-byte aligned, a narrow tall logo (short LDS rows hold the LDS-direct raw rows, bands
+    capped at 16 rows), every pixel / a few dozen pixels in the mask, 16-bit samples.  Scores within 1e-4 and inside the
+    library's bound; fades identical."""
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo
+    W, H, LW, LH, X, Y0, N = SHAPES[shape]
+    cfg = dict(W=W, H=H, LW=LW, LH=LH, IMGX=X, IMGY=Y0, N=N, period=4, fade=2, flat=3)
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=32)
+    an = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], maskratio, mode="linear")
+    got = an.analyze(cs["dclip"])
+    raw = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], maskratio, mode="linear_unguarded").analyze(cs["dclip"])
+    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"], maskratio)
+    Y = cs["clip"]["Y"]
+    want = np.zeros(N * 33, np.float32)
+    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], bits, N, _ptr(want))
+    want = want.reshape(N, 33)
+    err = np.abs(got - want)
+    tol = 1e-4 * np.maximum(1.0, np.abs(want))            # scores of a 16-bit clip evaluated on the 8-bit scale run to hundreds
+    assert (err <= tol).all(), (float(err.max()), an.last_refined())
+    assert (np.abs(raw - want) <= tol).all(), float(np.abs(raw - want).max())     # the kernel's own accuracy, nothing re-evaluated
+    for k in range(3):
+        assert err[:, 11 * k:11 * k + 11].max() <= an.error_bound(k, bits) * max(1.0, float(np.abs(want).max()))
+    er = AMTEraseLogo(gpu["ctx"], cs["logo"], "", 0, 16)
+    assert er.calc_fades(got, N).tobytes() == er.calc_fades(want, N).tobytes()
+
+
+def test_linear_mode_refuses_logos_it_does_not_take(gpu):
+    """wider than 256 columns: one staging column group only -- the mode is refused loudly, the exact mode still works"""
+    from amatsukaze_amd import AMTAnalyzeLogo, AmtError
+    W, H, LW, LH, X, Y0, N = SHAPES["w322_two_groups"]
+    cs = make_case(gpu, dict(W=W, H=H, LW=LW, LH=LH, IMGX=X, IMGY=Y0, N=N, period=4, fade=2, flat=3), bits=8, pitch_pad=0)
+    with pytest.raises(AmtError, match="too wide"):
+        AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35, mode="linear")
+    assert AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"]).shape == (N, 33)

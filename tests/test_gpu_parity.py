@@ -364,10 +364,13 @@ def test_analyze_linear_guarded_mode(gpu, cfgname, bits):
     want = np.zeros(n * 33, np.float32)
     orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], bits, n, _ptr(want))
     want = want.reshape(n, 33)
+    # the linear evaluation by itself (no guard: nothing is re-evaluated exactly, so this is the kernel's own accuracy)
+    raw = AMTAnalyzeLogo(ctx, cs["logo"], 0.35, mode="linear_unguarded").analyze(cs["dclip"])
+    assert np.abs(raw - want).max() <= 1e-4, float(np.abs(raw - want).max())
     an = AMTAnalyzeLogo(ctx, cs["logo"], 0.35, mode="linear")
     got = an.analyze(cs["dclip"])
     refined = an.last_refined()
-    assert 0 <= refined <= n
+    assert 0 <= refined <= n // 4, refined                    # the guard is for the rare close calls, not a crutch
     err = np.abs(got - want)
     bounds = [an.error_bound(k, bits) for k in range(3)]
     assert all(0 < e < 0.05 for e in bounds), bounds
