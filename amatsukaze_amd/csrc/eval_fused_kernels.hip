@@ -145,13 +145,9 @@ __device__ __forceinline__
 void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands,
                           const float* __restrict__ fades, int nfades, int fade0,
                           const pix_t* __restrict__ Y, const int* __restrict__ frame_map, long long frame_stride, int pitch,
-                          float maxv, int nframes_in, int G, int ngroups, float* __restrict__ out, int out_frame_stride,
-                          int take_abs, int plane_cap, int sc_pitch, int dbg_in, const int* __restrict__ nframes_dev, int scatter)
+                          float maxv, int nframes, int G, int ngroups, float* __restrict__ out, int out_frame_stride,
+                          int take_abs, int plane_cap, int sc_pitch, int dbg_in, int bid, int scatter)
 {
-    // listed re-evaluation (decision guard of the linear mode): the number of frames present sits on the device, the grid is
-    // sized for the worst case, surplus workgroups leave at once
-    const int nframes = nframes_dev ? min(*nframes_dev, nframes_in) : nframes_in;
-    if ((int)(blockIdx.x % (unsigned)ngroups) * G >= nframes) return;
 #ifdef AMT_EXPERIMENT
     const int dbg = dbg_in;      // timing ablations of instrumented builds only (amatsukaze_amd/build.py build_variant)
 #else
@@ -163,8 +159,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
     float* const sc = lds + 2 * FPI * plane_cap;     // [FPI][nfades][sc_pitch]  per-pixel terms of the current (band, frames)
     float* const accs = sc + FPI * nfades * sc_pitch;  // [G][nfades]  running sums
 
-    const int logo = blockIdx.x / ngroups;
-    const int grp = blockIdx.x - logo * ngroups;
+    const int logo = bid / ngroups;
+    const int grp = bid - logo * ngroups;
     const int F0 = grp * G;
     const int gcount = min(G, nframes - F0);
     const EvalLogoDev L = logos[logo];
@@ -172,7 +168,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
     const unsigned cpad = (unsigned)L.count_pad;
     const unsigned spad = (unsigned)L.nslots_pad;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: the staging rows' address math goes to the scalar unit
     const int w = L.w, lp = L.lp;
     constexpr unsigned ES = sizeof(pix_t);
 
@@ -434,10 +431,22 @@ void logo_eval_fused_kernel(const EvalLogoDev* __restrict__ logos, const EvalBan
                             int nfades, int fade0, const pix_t* __restrict__ Y, const int* __restrict__ frame_map,
                             long long frame_stride, int pitch, float maxv, int nframes, int G, int ngroups, float* __restrict__ out,
                             int out_frame_stride, int take_abs, int plane_cap, int sc_pitch, int dbg, const int* __restrict__ nframes_dev,
-                            int scatter)
+                            int scatter, int nlogos)
 {
-    logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, nframes, G, ngroups, out,
-                                     out_frame_stride, take_abs, plane_cap, sc_pitch, dbg, nframes_dev, scatter);
+    if (!nframes_dev) {
+        logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, nframes, G, ngroups, out,
+                                         out_frame_stride, take_abs, plane_cap, sc_pitch, dbg, (int)blockIdx.x, scatter);
+        return;
+    }
+    // listed re-evaluation (decision guard of the linear mode): the number of frames present sits on the device and is usually a
+    // handful, so a small fixed grid walks the (logo, group) pairs that exist instead of launching the worst case
+    const int present = min(*nframes_dev, nframes);
+    const int groups = (present + G - 1) / G;
+    for (int b = (int)blockIdx.x; b < groups * nlogos; b += (int)gridDim.x) {
+        logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, present, G, groups, out,
+                                         out_frame_stride, take_abs, plane_cap, sc_pitch, dbg, b, scatter);
+        __syncthreads();
+    }
 }
 
 static size_t fused_lds_bytes(int plane_cap, int nfades, int sc_pitch, int G, int fpi)
@@ -466,7 +475,8 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
     const int ngroups = (nframes + G - 1) / G;
     const float maxv = (float)((1 << bits) - 1);
     const int sc_pitch = kEvalBandPixels + kEvalScorePad;
-    dim3 grid((unsigned)((long long)ngroups * nlogos));
+    // listed mode: a fixed small grid that strides over the (logo, group) pairs present
+    dim3 grid(dnframes ? (unsigned)std::min<long long>((long long)ngroups * nlogos, 1024) : (unsigned)((long long)ngroups * nlogos));
     // two frames per iteration while the planes and score rows of both fit half a CU's LDS (two workgroups per CU)
     int fpi = fpi_env > 0 ? std::min(2, fpi_env) : 2;
     if (G < 2 || fused_lds_bytes(plane_cap, nfades, sc_pitch, G, 2) > 80 * 1024 - 512) fpi = 1;
@@ -474,7 +484,7 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
 #define AMT_LAUNCH(T, F)                                                                                                          \
     hipLaunchKernelGGL((logo_eval_fused_kernel<T, F>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,         \
                        (const T*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, \
-                       plane_cap, sc_pitch, dbg, dnframes, scatter)
+                       plane_cap, sc_pitch, dbg, dnframes, scatter, nlogos)
     if (fpi == 2) { if (bits <= 8) AMT_LAUNCH(uint8_t, 2); else AMT_LAUNCH(uint16_t, 2); }
     else { if (bits <= 8) AMT_LAUNCH(uint8_t, 1); else AMT_LAUNCH(uint16_t, 1); }
 #undef AMT_LAUNCH
