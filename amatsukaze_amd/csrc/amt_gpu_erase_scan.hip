@@ -2,6 +2,7 @@
 #include "../../include/amt_gpu.h"
 
 #include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -17,7 +18,7 @@ struct EraseGeom {
     int uvparity;
 };
 hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
-                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades);
+                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades, int zero_identity);
 hipError_t launch_scan_border(hipStream_t st, int bits, const void* dY, const void* dU, const void* dV, long long strideY,
                               long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy, int w, int h,
                               int wUV, int hUV, int thy, int nframes, int4* dout);
@@ -38,6 +39,7 @@ struct AmtGpuErase {
     bool haveLogof = false;
     std::string logofText;
     int mode = 0, maxFade = 16;
+    bool zeroIdentity = false;      // every a*s + b*maxv of this logo is finite: Delogo with fade 0 returns the frame unchanged
     DevBuf<float> dPlanes;
     DevBuf<float2> dFades;
 };
@@ -52,6 +54,9 @@ static AmtGpuErase* erase_new(AmtGpuContext* c, LogoPlanes logo, const std::stri
     er->haveLogof = haveLogof;
     er->logofText = logofText;
     if (haveLogof) (void)parse_logoframe(logofText, 0);     // report a malformed file at construction, like the filter does
+    // fade 0: dst = (pixel)min(max(0*bg + 1*s + 0.5, 0), maxv) == s as long as bg = a*s + b*maxv cannot overflow to inf / NaN
+    er->zeroIdentity = true;
+    for (float v : er->logo.data) er->zeroIdentity = er->zeroIdentity && std::fabs(v) < 1e30f;
     c->bind();
     er->dPlanes.upload(er->logo.data, c->stream);
     return er.release();
@@ -125,7 +130,7 @@ int amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t st
         g.uvparity = (P.imgy / 2) % 2;
         const int sp = er->ctx->prof_begin("delogo_kernel");
         AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
-                              nframes, er->dFades.get()));
+                              nframes, er->dFades.get(), er->zeroIdentity ? 1 : 0));
         er->ctx->prof_end(sp);
         // the fades came from pageable host memory: make sure the copy has been consumed before returning
         AMT_HIP(hipStreamSynchronize(er->ctx->stream));

@@ -30,6 +30,24 @@ constexpr int kDelogoRows = 16;
 constexpr int kDelogoThreads = 256;
 constexpr int kDelogoFrames = 8;       // frames a workgroup walks through with the row's logo coefficients in registers
 
+// four adjacent samples in one access (rows whose width is a multiple of 4: one wave moves 256 / 512 contiguous bytes per row)
+template <typename pix_t> struct PixQuad;
+template <> struct PixQuad<uint8_t> {
+    typedef uint32_t __attribute__((aligned(2))) type;
+    static __device__ __forceinline__ float get(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }
+    static __device__ __forceinline__ uint32_t pack(float r0, float r1, float r2, float r3)
+    {
+        return (uint32_t)(uint8_t)r0 | ((uint32_t)(uint8_t)r1 << 8) | ((uint32_t)(uint8_t)r2 << 16) | ((uint32_t)(uint8_t)r3 << 24);
+    }
+};
+template <> struct PixQuad<uint16_t> {
+    typedef uint64_t __attribute__((aligned(4))) type;
+    static __device__ __forceinline__ float get(uint64_t v, int k) { return (float)((v >> (16 * k)) & 0xFFFFu); }
+    static __device__ __forceinline__ uint64_t pack(float r0, float r1, float r2, float r3)
+    {
+        return (uint64_t)(uint16_t)r0 | ((uint64_t)(uint16_t)r1 << 16) | ((uint64_t)(uint16_t)r2 << 32) | ((uint64_t)(uint16_t)r3 << 48);
+    }
+};
 template <typename pix_t> struct PixPair;
 template <> struct PixPair<uint8_t> { typedef uint16_t type; };
 template <> struct PixPair<uint16_t> { typedef uint32_t type; };
@@ -46,9 +64,11 @@ template <typename pix_t>
 __global__ __launch_bounds__(kDelogoThreads)
 void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restrict__ V, long long strideY,
                    long long strideUV, int pitchY, int pitchUV, const float* __restrict__ planes, EraseGeom g,
-                   float maxv, const float2* __restrict__ fades, int pairY, int pairUV, int nframes)
+                   float maxv, const float2* __restrict__ fades, int pairY, int pairUV, int nframes, int quadY, int quadUV,
+                   int zero_identity)
 {
     typedef typename PixPair<pix_t>::type pair_t;
+    typedef typename PixQuad<pix_t>::type quad_t;
     constexpr int SH = 8 * sizeof(pix_t);
     const int f0 = blockIdx.y * kDelogoFrames;
     const int f1 = min(nframes, f0 + kDelogoFrames);
@@ -60,17 +80,17 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
         // 8 B per sample against 2 B of frame traffic, so they are read once and kept in registers
         pix_t* row0;
         const float *A, *B;
-        int roww, paired, y, pl;
+        int roww, paired, quad, y, pl;
         long long stride;
         if (r < g.h) {
             y = r; pl = 0;
-            roww = g.w; paired = pairY; stride = strideY;
+            roww = g.w; paired = pairY; quad = quadY; stride = strideY;
             row0 = Y + (long long)(g.imgy + y) * pitchY + g.imgx;
             A = planes + (size_t)y * g.w; B = planes + ysz + (size_t)y * g.w;
         } else {
             pl = (r - g.h) >= g.hUV ? 2 : 1;
             y = r - g.h - (pl - 1) * g.hUV;
-            roww = g.wUV; paired = pairUV; stride = strideUV;
+            roww = g.wUV; paired = pairUV; quad = quadUV; stride = strideUV;
             row0 = (pl == 2 ? V : U) + (long long)(g.cy + y) * pitchUV + g.cx;
             const float* base = planes + 2 * ysz + (size_t)(pl - 1) * 2 * csz;
             A = base + (size_t)y * g.wUV; B = base + csz + (size_t)y * g.wUV;
@@ -78,10 +98,40 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
         auto fade_of = [&](float2 fd, bool& skip) {
             const bool frameMode = fd.x == fd.y;
             skip = pl != 0 && !frameMode && y >= 2 * (g.hUV / 2);   // field mode leaves an odd last chroma row alone
+            // fade 0 writes back what it read (0*bg + 1*s + 0.5 truncates to s) whenever bg is finite, which the host has checked
+            // for this logo (zero_identity): frames without a logo cost no traffic
+            skip = skip || (zero_identity && fd.x == 0.0f && fd.y == 0.0f);
             if (frameMode) return fd.x;
             return pl == 0 ? ((y & 1) ? fd.y : fd.x) : (((y & 1) == g.uvparity) ? fd.x : fd.y);
         };
-        if (paired) {
+        if (quad) {
+            for (int x = 4 * lane; x < roww; x += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(A + x);
+                const float4 b = *reinterpret_cast<const float4*>(B + x);
+                float fd[kDelogoFrames];
+                bool live[kDelogoFrames];
+#pragma unroll
+                for (int k = 0; k < kDelogoFrames; ++k) {
+                    bool skip = true;
+                    fd[k] = f0 + k < f1 ? fade_of(fades[f0 + k], skip) : 0.0f;
+                    live[k] = !skip;
+                }
+                typename PixQuad<pix_t>::type v[kDelogoFrames];          // all live frames' loads in flight before the first use
+#pragma unroll
+                for (int k = 0; k < kDelogoFrames; ++k)
+                    if (live[k]) v[k] = *reinterpret_cast<const quad_t*>(row0 + (long long)(f0 + k) * stride + x);
+#pragma unroll
+                for (int k = 0; k < kDelogoFrames; ++k) {
+                    if (!live[k]) continue;
+                    typedef PixQuad<pix_t> Q;
+                    const float r0 = delogo_px(Q::get(v[k], 0), a.x, b.x, maxv, fd[k]);
+                    const float r1 = delogo_px(Q::get(v[k], 1), a.y, b.y, maxv, fd[k]);
+                    const float r2 = delogo_px(Q::get(v[k], 2), a.z, b.z, maxv, fd[k]);
+                    const float r3 = delogo_px(Q::get(v[k], 3), a.w, b.w, maxv, fd[k]);
+                    *reinterpret_cast<quad_t*>(row0 + (long long)(f0 + k) * stride + x) = Q::pack(r0, r1, r2, r3);
+                }
+            }
+        } else if (paired) {
             for (int x = 2 * lane; x < roww; x += 128) {
                 const float2 a = *reinterpret_cast<const float2*>(A + x);
                 const float2 b = *reinterpret_cast<const float2*>(B + x);
@@ -117,7 +167,7 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
 }
 
 hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
-                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades)
+                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades, int zero_identity)
 {
     if (nframes <= 0) return hipSuccess;
     const int rows = g.h + 2 * g.hUV;
@@ -130,12 +180,15 @@ hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV,
     const int pairY = even(g.w) && even(g.imgx) && even(pitchY) && even(strideY) && ((uintptr_t)dY % (2 * es) == 0);
     const int pairUV = even(g.wUV) && even(g.cx) && even(pitchUV) && even(strideUV) && ((uintptr_t)dU % (2 * es) == 0) &&
                        ((uintptr_t)dV % (2 * es) == 0);
+    // four samples per lane where a row is a multiple of 4 wide (coefficient rows are then 16-byte aligned float4s)
+    const int quadY = pairY && g.w % 4 == 0;
+    const int quadUV = pairUV && g.wUV % 4 == 0;
     if (bits <= 8)
         hipLaunchKernelGGL(delogo_kernel<uint8_t>, grid, block, 0, st, (uint8_t*)dY, (uint8_t*)dU, (uint8_t*)dV, strideY,
-                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes);
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes, quadY, quadUV, zero_identity);
     else
         hipLaunchKernelGGL(delogo_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)dY, (uint16_t*)dU, (uint16_t*)dV, strideY,
-                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes);
+                           strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes, quadY, quadUV, zero_identity);
     return hipGetLastError();
 }
 

@@ -319,7 +319,7 @@ void EvalEngine::run_listed(const void* dY, int64_t frame_stride_bytes, int pitc
     const int nf_all = (int)fades_.size();
     for (int f0 = 0; f0 < nf_all; f0 += kEvalMaxFades) {
         const int nf = std::min(kEvalMaxFades, nf_all - f0);
-        const int G = std::max(1, std::min(2, kEvalThreads / nf));      // few frames are expected: small groups, surplus workgroups exit
+        const int G = 1;      // a handful of frames is expected: one per workgroup, so that the pass lasts one frame's walk over the bands
         const int sp = ctx_->prof_begin((prof_name_ + "_refine").c_str());
         AMT_HIP(launch_logo_eval_fused(ctx_->stream, bits, d_logos_.get(), nl, d_bands_.get(), d_fades_.get(), nf, f0, dY, dlist,
                                        frame_stride_bytes / es, pitch, max_frames, G, dout, out_frame_stride_, take_abs_ ? 1 : 0,
