@@ -582,6 +582,8 @@ def main():
         except Exception:
             pass
 
+        erased_share = float((np.abs(last["fades"]).sum(axis=1) != 0).mean()) if "fades" in last else 1.0
+
         def kernel_entry(name, calls, ms, frames_per_call, timed):
             e = {"avg_ms": ms / max(1, calls), "launches": calls, "inside_timed_region": timed}
             fr = frames_per_call * calls
@@ -592,8 +594,13 @@ def main():
                           "frac_fp32_peak": fl * fr / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": fl * frames_per_call,
                           "algorithmic_bytes_per_launch": ab * frames_per_call, "hbm_gbs_algorithmic": ab * fr / (ms * 1e-3) / 1e9, "what": what})
             elif name in HBM:
-                e.update({"bound": "hbm", "achieved_gbs": HBM[name] * fr / (ms * 1e-3) / 1e9, "frac": HBM[name] * fr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "algorithmic_bytes_per_launch": HBM[name] * frames_per_call})
+                # Delogo with fade 0 is an identity the kernel skips (no traffic): only frames with a non-zero fade count
+                share = erased_share if name == "delogo_kernel" else 1.0
+                e.update({"bound": "hbm", "achieved_gbs": HBM[name] * share * fr / (ms * 1e-3) / 1e9,
+                          "frac": HBM[name] * share * fr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": HBM[name] * share * frames_per_call})
+                if name == "delogo_kernel":
+                    e["frames_with_nonzero_fade_share"] = share
             e["hbm_bytes_per_launch_pmc"] = tr * frames_per_call if tr else None
             return e
 

@@ -36,28 +36,57 @@ def test_analyze_shapes_bit_exact(gpu, shape, bits):
     assert got.reshape(-1).tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("group", [2, 3, 8])
-def test_frames_per_workgroup_bit_exact(gpu, group):
-    """G frames share a workgroup (taps loaded once per band); 40 frames leave a short last group for G=3."""
-    from amatsukaze_amd import AMTAnalyzeLogo
-    cfg = dict(W=352, H=240, LW=96, LH=48, IMGX=224, IMGY=18, N=40, period=16, fade=6, flat=3)
-    cs = make_case(gpu, cfg, bits=8, pitch_pad=0)
-    os.environ["AMTGPU_G"] = str(group)
-    try:
-        got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"])
-    finally:
-        del os.environ["AMTGPU_G"]
-    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"])
-    Y = cs["clip"]["Y"]
-    want = np.zeros(cfg["N"] * 33, np.float32)
-    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
-    assert got.reshape(-1).tobytes() == want.tobytes()
+def test_many_frames_per_workgroup(gpu):
+    """Batches large enough that a workgroup owns several frames (G = min(8, frames * logos / 2048) = 4 here, the last group is
+    short): the taps of a band are loaded once and re-used across the group's frames, the linear kernel keeps the band's logo
+    coefficients in LDS across them and the scan stages two frames per iteration.  Exact analysis and scan: bytes; linear analysis
+    (unguarded): within 1e-4."""
+    import ctypes as C
+    import torch
+    import amt_synth as S
+    from amatsukaze_amd import AMTAnalyzeLogo, DeviceClip, Logo, LogoFrame
+    from amtlib import Oracle
+    W, H, LW, LH, X, Y0, N = 352, 240, 96, 48, 224, 18, 2801
+    data, alpha, alphaUV = S.make_logo(LW, LH)
+    clip = S.make_clip_torch(N, W, H, 0x5EED0009, alpha, alphaUV, X, Y0, gpu["dev"], period=40, fade=6, chroma=False)
+    Yd = clip["Y"]
+    Y = Yd.cpu().numpy()
+    ctx = gpu["ctx"]
+    logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
+    orc = Oracle()
+    lo = orc.make_logo(data, LW, LH, W, H, X, Y0)
+    d, t, b = oracle_eval_logos(orc, lo)
+    want = np.zeros(N * 33, np.float32)
+    orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, N, _ptr(want))
+    want = want.reshape(N, 33)
+    out = torch.empty((N, 33), dtype=torch.float32, device=gpu["dev"])
+    AMTAnalyzeLogo(ctx, logo, 0.35).analyze_device(Yd, 8, out)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+    AMTAnalyzeLogo(ctx, logo, 0.35, mode="linear_unguarded").analyze_device(Yd, 8, out)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-4
+    guarded = AMTAnalyzeLogo(ctx, logo, 0.35, mode="linear")
+    guarded.analyze_device(Yd, 8, out)
+    assert guarded.last_refined() <= N // 20
+    # the all-frames scan with three logos (G = 4, two frames per iteration)
+    others = [S.make_logo(LW, LH, seed=0x10600002 + k, strength=0.5 + 0.3 * k)[0] for k in range(2)]
+    logos = [logo] + [Logo.from_planes(ctx, o, LW, LH, W, H, X, Y0) for o in others]
+    lf = LogoFrame(ctx, logos, 0.35)
+    lf.begin(W, H, 8, N)
+    lf.scan_batch(Yd, 8, 0, N)
+    hs = [d]
+    for o in others:
+        h = orc.lib.orc_logo_deint(orc.make_logo(o, LW, LH, W, H, X, Y0)); orc.lib.orc_logo_create_mask(h, 0.35, 1); hs.append(h)
+    wscan = np.zeros(N * 3 * 2, np.float32)
+    orc.lib.orc_logoframe_scan((C.c_void_p * 3)(*hs), 3, _ptr(Y), Y.strides[0], Y.shape[2], 8, W, H, N, _ptr(wscan))
+    assert lf.evalResults.tobytes() == wscan.tobytes()
 
 
-@pytest.mark.parametrize("group,bits", [(4, 8), (3, 8), (5, 10), (2, 8)])
-def test_scan_two_frames_per_iteration_bit_exact(gpu, group, bits):
-    """The 2-fade scan stages and evaluates two frames per iteration (FPI=2: two plane buffers, 4 score rows, 4 summing lanes)
-    whenever a workgroup owns >= 2 frames; odd group sizes and the short last group of 40 frames end on a single-frame iteration."""
+@pytest.mark.parametrize("group,bits", [(4, 8), (5, 10)])
+def test_scan_in_ragged_batches_bit_exact(gpu, group, bits):
+    """LogoFrame::scanFrames fed in batches of 23 frames (40 = 23 + 17) with two logos; frames-per-workgroup sizes above 1 are
+    covered by test_many_frames_per_workgroup (the AMTGPU_G knob set here only exists in instrumented builds)."""
     import ctypes as C
     import amt_synth as S
     from amatsukaze_amd import Logo, LogoFrame
