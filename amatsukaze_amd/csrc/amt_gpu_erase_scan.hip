@@ -149,6 +149,9 @@ struct AmtGpuLogoScan {
     DevBuf<unsigned long long> dAcc;
     DevBuf<int4> dVerdict, dAccepted;
     std::vector<int4> lastVerdicts;      // verdicts of the most recent add_batch (frame-local)
+    std::vector<int4> accHost;           // accepted list of the most recent add_batch: source of an async upload, so it
+    hipEvent_t accUploaded = nullptr;    //   lives here and is rewritten only after this event
+    ~AmtGpuLogoScan() { if (accUploaded) (void)hipEventDestroy(accUploaded); }
     bool accDirty = false;               // device accumulators newer than sums.px
 };
 
@@ -187,7 +190,10 @@ static int logoscan_add(AmtGpuLogoScan* s, const void* dY, const void* dU, const
         AMT_HIP(hipMemcpyAsync(v.data(), s->dVerdict.get(), (size_t)nframes * sizeof(int4), hipMemcpyDeviceToHost, s->ctx->stream));
         AMT_HIP(hipStreamSynchronize(s->ctx->stream));
     }
-    std::vector<int4> acc;
+    std::vector<int4>& acc = s->accHost;
+    if (s->accUploaded) AMT_HIP(hipEventSynchronize(s->accUploaded));
+    else AMT_HIP(hipEventCreateWithFlags(&s->accUploaded, hipEventDisableTiming));
+    acc.clear();
     for (int i = 0; i < nframes; ++i) {
         if (valid_out) valid_out[i] = 0;
         if ((int)acc.size() >= max_valid) continue;          // stream order: later frames are not even looked at
@@ -202,11 +208,11 @@ static int logoscan_add(AmtGpuLogoScan* s, const void* dY, const void* dU, const
     if (!acc.empty()) {
         if (s->dAccepted.size() < acc.size()) s->dAccepted.alloc(acc.size());
         AMT_HIP(hipMemcpyAsync(s->dAccepted.get(), acc.data(), acc.size() * sizeof(int4), hipMemcpyHostToDevice, s->ctx->stream));
+        AMT_HIP(hipEventRecord(s->accUploaded, s->ctx->stream));
         const int spa = s->ctx->prof_begin("scan_accumulate_kernel");
         AMT_HIP(launch_scan_accumulate(s->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, imgx, imgy, cx, cy,
                                        S.w, S.h, wUV, hUV, s->dAccepted.get(), (int)acc.size(), s->dAcc.get()));
         s->ctx->prof_end(spa);
-        AMT_HIP(hipStreamSynchronize(s->ctx->stream));        // acc (host vector) must outlive the copy
         s->accDirty = true;
         S.nframes += (int)acc.size();
     }

@@ -4,6 +4,7 @@
 // samples per frame): HBM-bound, a few ops per byte.  One workgroup row = one rectangle row so that a
 // wave reads/writes one contiguous run of the frame; frames and rows give >> 256 workgroups.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 
 #include "exact_math.h"
@@ -312,18 +313,22 @@ hipError_t launch_scan_border(hipStream_t st, int bits, const void* dY, const vo
 // sumB2 are per-plane constants of the accepted set and are kept by the host.
 // acc: 3 int64 per pixel {sumF, sumF2, sumFB}; pixels = Y rows, then U rows, then V rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAccFramesPerBlock = 32;
+// Frames are split over blockIdx.y so that the launch has a few thousand workgroups, no more: every workgroup ends with
+// three 64-bit atomics per pixel, and with a fixed 32 frames per workgroup those atomics (not the 1 B/pixel/frame of
+// reads) were the whole cost of a 20000-frame accumulate.
+constexpr int kAccMinFramesPerBlock = 32;
+constexpr int kAccFrameChunks = 16;
 
 template <typename pix_t>
 __global__ __launch_bounds__(256)
 void scan_accumulate_kernel(const pix_t* __restrict__ Y, const pix_t* __restrict__ U, const pix_t* __restrict__ V,
                             long long strideY, long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy,
                             int w, int h, int wUV, int hUV, const int4* __restrict__ accepted /* {frame, bgY, bgU, bgV} */,
-                            int naccepted, unsigned long long* __restrict__ acc)
+                            int naccepted, int frames_per_block, unsigned long long* __restrict__ acc)
 {
     const int r = blockIdx.x;
-    const int g0 = blockIdx.y * kAccFramesPerBlock;
-    const int g1 = min(naccepted, g0 + kAccFramesPerBlock);
+    const int g0 = blockIdx.y * frames_per_block;
+    const int g1 = min(naccepted, g0 + frames_per_block);
     const pix_t* base;
     long long stride;
     int roww, pl;
@@ -341,7 +346,7 @@ void scan_accumulate_kernel(const pix_t* __restrict__ Y, const pix_t* __restrict
     }
     for (int x = threadIdx.x; x < roww; x += blockDim.x) {
         long long sF = 0, sF2 = 0, sFB = 0;
-#pragma unroll 4
+#pragma unroll 8
         for (int i = g0; i < g1; ++i) {
             const int4 a = accepted[i];
             const int f = base[(long long)a.x * stride + x];
@@ -362,13 +367,18 @@ hipError_t launch_scan_accumulate(hipStream_t st, int bits, const void* dY, cons
                                   int wUV, int hUV, const int4* daccepted, int naccepted, unsigned long long* dacc)
 {
     if (naccepted <= 0) return hipSuccess;
-    dim3 grid((unsigned)(h + 2 * hUV), (unsigned)((naccepted + kAccFramesPerBlock - 1) / kAccFramesPerBlock)), block(256);
+#ifdef AMT_SCAN_ACC_FIXED32        // instrumented build: round 1's fixed 32 frames per workgroup
+    const int per = kAccMinFramesPerBlock;
+#else
+    const int per = std::max(kAccMinFramesPerBlock, (naccepted + kAccFrameChunks - 1) / kAccFrameChunks);
+#endif
+    dim3 grid((unsigned)(h + 2 * hUV), (unsigned)((naccepted + per - 1) / per)), block(256);
     if (bits <= 8)
         hipLaunchKernelGGL(scan_accumulate_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)dY, (const uint8_t*)dU,
-                           (const uint8_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, daccepted, naccepted, dacc);
+                           (const uint8_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, daccepted, naccepted, per, dacc);
     else
         hipLaunchKernelGGL(scan_accumulate_kernel<uint16_t>, grid, block, 0, st, (const uint16_t*)dY, (const uint16_t*)dU,
-                           (const uint16_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, daccepted, naccepted, dacc);
+                           (const uint16_t*)dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, cx, cy, w, h, wUV, hUV, daccepted, naccepted, per, dacc);
     return hipGetLastError();
 }
 
