@@ -20,11 +20,12 @@ def gpu():
     return dict(torch=torch, ctx=Context(0), dev=torch.device("cuda:0"))
 
 
-@pytest.mark.parametrize("W,H,bits,pad", [(352, 240, 8, 0), (360, 242, 8, 24), (1440, 1080, 8, 32), (352, 240, 10, 0), (2304, 64, 8, 0)])
+@pytest.mark.parametrize("W,H,bits,pad", [(352, 240, 8, 0), (360, 242, 8, 24), (1440, 1080, 8, 32), (352, 240, 10, 0), (2304, 64, 8, 0),
+                                          (1920, 1080, 10, 0), (720, 480, 8, 16), (48, 34, 8, 0), (16, 18, 8, 0)])
 def test_frame_metrics_bit_exact(gpu, W, H, bits, pad):
     from amatsukaze_amd import DeviceClip, FrameStats
     torch = gpu["torch"]
-    N = 37 if W < 1000 else 5      # 37: more than one 16-frame run, ragged tail
+    N = 70 if W < 400 else (37 if W < 1000 else 5)      # 37 / 70: more than one frame run, ragged tail
     clip = S.make_clip_np(N, W, H, 0x5EED0003, bits=bits, pitchY=W + pad, pitchUV=W // 2 + pad // 2)
     Y = clip["Y"]
     t = torch.from_numpy(Y.view(np.uint8 if bits <= 8 else np.int16)).to(gpu["dev"])
