@@ -360,6 +360,20 @@ class AMTEraseLogo:
         self.ctx.check(self.ctx.lib.amtgpu_erase_batch(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV,
                                                        clip.pitchY, clip.pitchUV, clip.bits, clip.num_frames, _p(fades)))
 
+    @property
+    def rect(self):
+        """(imgx, imgy, w, h, fade0_is_identity): the rectangle Delogo rewrites"""
+        out = (C.c_int * 5)()
+        self.ctx.check(self.ctx.lib.amtgpu_erase_get_rect(self.h, out), "erase_get_rect")
+        return tuple(out)
+
+    def erase_rect(self, Y, U, V, bits, fades):
+        """Delogo on device planes that hold only the logo rectangle: Y [n, h, w], U / V [n, h/2, w/2] (any row pitch)"""
+        fades = np.ascontiguousarray(fades, np.float32)
+        es = 1 if bits <= 8 else 2
+        self.ctx.check(self.ctx.lib.amtgpu_erase_rect_batch(self.h, _p(Y), _p(U), _p(V), int(Y.stride(0)) * es, int(U.stride(0)) * es,
+                                                            int(Y.stride(1)), int(U.stride(1)), bits, int(Y.shape[0]), _p(fades)))
+
     def __del__(self):
         try:
             if self.h:

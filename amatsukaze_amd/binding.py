@@ -39,6 +39,7 @@ SIGNATURES = {
     "amtgpu_frames_upload_strided": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_u64, c_i]),
     "amtgpu_frames_upload_wait": (c_i, [c_p]),
     "amtgpu_download": (c_i, [c_p, c_p, c_p, c_u64]),
+    "amtgpu_download_strided": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_u64, c_i]),
     "amtgpu_weave_fields_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
                                         c_i64, c_i64, c_i, c_i, c_i]),
     "amtgpu_amts_load": (c_p, [c_p, c_s]),
@@ -78,6 +79,8 @@ SIGNATURES = {
     "amtgpu_erase_destroy": (None, [c_p]),
     "amtgpu_erase_calc_fades": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "amtgpu_erase_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "amtgpu_erase_rect_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "amtgpu_erase_get_rect": (c_i, [c_p, c_p]),
     "amtgpu_logoscan_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
     "amtgpu_logoscan_destroy": (None, [c_p]),
     "amtgpu_logoscan_add_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),

@@ -191,6 +191,19 @@ int amtgpu_download(AmtGpuContext* c, void* hdst, const void* dsrc, uint64_t byt
     });
 }
 
+int amtgpu_download_strided(AmtGpuContext* c, void* hdst, int64_t dst_stride, const void* dsrc, int64_t src_stride, uint64_t chunk_bytes,
+                            int nchunks)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (chunk_bytes == 0 || nchunks <= 0) return;
+        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
+        AMT_HIP(hipMemcpy2DAsync(hdst, (size_t)dst_stride, dsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyDeviceToHost,
+                                 c->stream));
+        AMT_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 // logo model
 // ---------------------------------------------------------------------------------------------

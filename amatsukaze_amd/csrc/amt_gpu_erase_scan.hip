@@ -111,30 +111,52 @@ int amtgpu_erase_calc_fades(AmtGpuErase* er, const float* analysis, int num_fram
     });
 }
 
+static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY, int pitchUV,
+                         int bits, int nframes, const float* fades, bool rect_only)
+{
+    if (bits < 8 || bits > 16) throw std::runtime_error("[AMTEraseLogo] Unsupported pixel format");
+    if (er->mode != 0) throw std::runtime_error("[AMTEraseLogo] only mode 0 is supported (debug overlay modes are out of scope)");
+    if (nframes <= 0) return;
+    const LogoPlanes& P = er->logo;
+    const int es = bits <= 8 ? 1 : 2;
+    if (strideY % es || strideUV % es) throw std::runtime_error("frame stride not a multiple of the sample size");
+    if (rect_only && (pitchY < P.w || pitchUV < P.wUV())) throw std::runtime_error("[AMTEraseLogo] rectangle pitch smaller than the logo width");
+    er->ctx->bind();
+    if (er->dFades.size() < (size_t)nframes) er->dFades.alloc(nframes);
+    AMT_HIP(hipMemcpyAsync(er->dFades.get(), fades, (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
+    EraseGeom g;
+    g.w = P.w; g.h = P.h; g.wUV = P.wUV(); g.hUV = P.hUV();
+    // rectangle-only planes start at the logo's top-left sample; the chroma row parity is a property of the logo's position in
+    // the frame (LogoScan.hpp:1374-1397), not of the buffer
+    g.imgx = rect_only ? 0 : P.imgx; g.imgy = rect_only ? 0 : P.imgy;
+    g.cx = rect_only ? 0 : P.imgx >> P.logUVx; g.cy = rect_only ? 0 : P.imgy >> P.logUVy;
+    g.uvparity = (P.imgy / 2) % 2;
+    const int sp = er->ctx->prof_begin("delogo_kernel");
+    AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
+                          nframes, er->dFades.get(), er->zeroIdentity ? 1 : 0));
+    er->ctx->prof_end(sp);
+    // the fades came from pageable host memory: make sure the copy has been consumed before returning
+    AMT_HIP(hipStreamSynchronize(er->ctx->stream));
+}
+
 int amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY,
                        int pitchUV, int bits, int nframes, const float* fades)
 {
-    return guard(er->ctx, [&] {
-        if (bits < 8 || bits > 16) throw std::runtime_error("[AMTEraseLogo] Unsupported pixel format");
-        if (er->mode != 0) throw std::runtime_error("[AMTEraseLogo] only mode 0 is supported (debug overlay modes are out of scope)");
-        if (nframes <= 0) return;
-        const LogoPlanes& P = er->logo;
-        const int es = bits <= 8 ? 1 : 2;
-        if (strideY % es || strideUV % es) throw std::runtime_error("frame stride not a multiple of the sample size");
-        er->ctx->bind();
-        if (er->dFades.size() < (size_t)nframes) er->dFades.alloc(nframes);
-        AMT_HIP(hipMemcpyAsync(er->dFades.get(), fades, (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
-        EraseGeom g;
-        g.w = P.w; g.h = P.h; g.wUV = P.wUV(); g.hUV = P.hUV();
-        g.imgx = P.imgx; g.imgy = P.imgy; g.cx = P.imgx >> P.logUVx; g.cy = P.imgy >> P.logUVy;
-        g.uvparity = (P.imgy / 2) % 2;
-        const int sp = er->ctx->prof_begin("delogo_kernel");
-        AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
-                              nframes, er->dFades.get(), er->zeroIdentity ? 1 : 0));
-        er->ctx->prof_end(sp);
-        // the fades came from pageable host memory: make sure the copy has been consumed before returning
-        AMT_HIP(hipStreamSynchronize(er->ctx->stream));
-    });
+    return guard(er->ctx, [&] { erase_launch(er, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, nframes, fades, false); });
+}
+
+int amtgpu_erase_rect_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY,
+                            int pitchUV, int bits, int nframes, const float* fades)
+{
+    return guard(er->ctx, [&] { erase_launch(er, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, nframes, fades, true); });
+}
+
+int amtgpu_erase_get_rect(const AmtGpuErase* er, int* out5)
+{
+    if (!er || !out5) return 0;
+    const LogoPlanes& P = er->logo;
+    out5[0] = P.imgx; out5[1] = P.imgy; out5[2] = P.w; out5[3] = P.h; out5[4] = er->zeroIdentity ? 1 : 0;
+    return 1;
 }
 
 } // extern "C"

@@ -218,19 +218,32 @@ public:
         need_analysis(n - reach, n + reach, env);
         float fades[2];
         if (!amtgpu_erase_calc_fades(er_, analysis_.data(), vi.num_frames, n, 1, fades)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        const uint64_t by = (uint64_t)frame->GetPitch(PLANAR_Y) * frame->GetHeight(PLANAR_Y);
-        const uint64_t buv = (uint64_t)frame->GetPitch(PLANAR_U) * frame->GetHeight(PLANAR_U);
+        /* Delogo rewrites the logo rectangle and nothing else (LogoScan.hpp:1248-1261): only its rows cross PCIe -- w*h luma and
+         * 2 * w/2*h/2 chroma samples up and back instead of two whole frames -- and a frame whose fades are both 0 is returned as
+         * it came (the reference's arithmetic is the identity there) */
+        int rc[5];
+        if (!amtgpu_erase_get_rect(er_, rc)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+        const int imgx = rc[0], imgy = rc[1], w = rc[2], h = rc[3];
+        if (rc[4] && fades[0] == 0.0f && fades[1] == 0.0f) return frame;
+        if (imgx < 0 || imgy < 0 || imgx + w > vi.width || imgy + h > vi.height) env->ThrowError("[AMTEraseLogo] logo rectangle outside the frame");
+        const int wUV = w >> 1, hUV = h >> 1, cx = imgx >> 1, cy = imgy >> 1;
+        const uint64_t by = (uint64_t)w * h * es, buv = (uint64_t)wUV * hUV * es;
         dbuf_.reserve(by + 2 * buv);
         uint8_t *dY = dbuf_.at(0), *dU = dbuf_.at(by), *dV = dbuf_.at(by + buv);
         AmtGpuContext* g = ctx_->get();
-        if (!amtgpu_frames_upload(g, dY, frame->GetReadPtr(PLANAR_Y), by) || !amtgpu_frames_upload(g, dU, frame->GetReadPtr(PLANAR_U), buv) ||
-            !amtgpu_frames_upload(g, dV, frame->GetReadPtr(PLANAR_V), buv) || !amtgpu_frames_upload_wait(g))
+        const int pY = frame->GetPitch(PLANAR_Y), pUV = frame->GetPitch(PLANAR_U);
+        uint8_t* hY = frame->GetWritePtr(PLANAR_Y) + (size_t)imgy * pY + (size_t)imgx * es;
+        uint8_t* hU = frame->GetWritePtr(PLANAR_U) + (size_t)cy * pUV + (size_t)cx * es;
+        uint8_t* hV = frame->GetWritePtr(PLANAR_V) + (size_t)cy * pUV + (size_t)cx * es;
+        if (!amtgpu_frames_upload_strided(g, dY, (int64_t)w * es, hY, pY, (uint64_t)w * es, h) ||
+            !amtgpu_frames_upload_strided(g, dU, (int64_t)wUV * es, hU, pUV, (uint64_t)wUV * es, hUV) ||
+            !amtgpu_frames_upload_strided(g, dV, (int64_t)wUV * es, hV, pUV, (uint64_t)wUV * es, hUV) || !amtgpu_frames_upload_wait(g))
             env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        if (!amtgpu_erase_batch(er_, dY, dU, dV, (int64_t)by, (int64_t)buv, frame->GetPitch(PLANAR_Y) / es, frame->GetPitch(PLANAR_U) / es,
-                                vi.BitsPerComponent(), 1, fades))
+        if (!amtgpu_erase_rect_batch(er_, dY, dU, dV, (int64_t)by, (int64_t)buv, w, wUV, vi.BitsPerComponent(), 1, fades))
             env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        if (!amtgpu_download(g, frame->GetWritePtr(PLANAR_Y), dY, by) || !amtgpu_download(g, frame->GetWritePtr(PLANAR_U), dU, buv) ||
-            !amtgpu_download(g, frame->GetWritePtr(PLANAR_V), dV, buv))
+        if (!amtgpu_download_strided(g, hY, pY, dY, (int64_t)w * es, (uint64_t)w * es, h) ||
+            !amtgpu_download_strided(g, hU, pUV, dU, (int64_t)wUV * es, (uint64_t)wUV * es, hUV) ||
+            !amtgpu_download_strided(g, hV, pUV, dV, (int64_t)wUV * es, (uint64_t)wUV * es, hUV))
             env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
         return frame;
     }

@@ -77,6 +77,10 @@ int   amtgpu_frames_upload_strided(AmtGpuContext* ctx, void* ddst, int64_t dst_s
                                    uint64_t chunk_bytes, int nchunks);
 int   amtgpu_frames_upload_wait(AmtGpuContext* ctx);   /* make the compute stream wait for pending uploads */
 int   amtgpu_download(AmtGpuContext* ctx, void* hdst, const void* dsrc, uint64_t bytes);        /* synchronous */
+/* nchunks pieces of chunk_bytes, src_stride apart on the device, dst_stride apart on the host (an erased rectangle back into
+ * the rows of a host frame).  synchronous */
+int   amtgpu_download_strided(AmtGpuContext* ctx, void* hdst, int64_t dst_stride, const void* dsrc, int64_t src_stride,
+                              uint64_t chunk_bytes, int nchunks);
 
 /* ---- frame assembly: replaces AMTSource::MakeFrame -> MergeField / Copy1 / Copy2 (AMTSource.hpp:291-366) on decoded
  *      pictures already in HBM (uploaded with amtgpu_frames_upload): output frame i takes its even rows from picture
@@ -191,6 +195,14 @@ int  amtgpu_erase_calc_fades(AmtGpuErase* er, const float* analysis, int num_fra
 /* in-place erase of a device batch with the given per-frame fades (host array nframes*2).  async */
 int  amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
                         int pitchY, int pitchUV, int bits, int nframes, const float* fades);
+/* the same on planes that hold ONLY the logo rectangle (w x h luma, w/2 x h/2 chroma samples per frame, first sample = the
+ * rectangle's top-left): what a per-frame host filter ships instead of whole frames -- Delogo touches nothing else
+ * (LogoScan.hpp:1248-1261, 1374-1397).  async */
+int  amtgpu_erase_rect_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
+                             int pitchY, int pitchUV, int bits, int nframes, const float* fades);
+/* out5 = {imgx, imgy, w, h, fade0_is_identity}: the rectangle Delogo rewrites; the last word is 1 when a frame whose two fades
+ * are 0 comes back unchanged (every a*s + b*maxv of this logo is finite), i.e. the host may skip the call for such frames */
+int  amtgpu_erase_get_rect(const AmtGpuErase* er, int* out5);
 
 /* ---- logo generation: replaces logo::LogoScan (AddFrame :594-659, AddScanFrame :568-592,
  *      Normalize :471-488, GetLogo :490-566) and LogoAnalyzer / the exported ScanLogo (:794-1098) ---- */

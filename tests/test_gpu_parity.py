@@ -210,6 +210,52 @@ def test_erase_field_mode_odd_chroma_rows(gpu):
     assert np.array_equal(cs["dclip"].V.cpu().numpy(), V)
 
 
+@pytest.mark.parametrize("bits,imgy", [(8, 16), (10, 18)])
+def test_erase_rectangle_only_planes(gpu, bits, imgy):
+    """amtgpu_erase_rect_batch on planes that hold only the logo rectangle == the oracle's Delogo on whole frames, including the
+    chroma row parity that depends on the rectangle's position in the frame (LogoScan.hpp:1374-1397); the strided upload /
+    download pair moves only the rectangle's rows between a host frame and the device."""
+    import ctypes as C
+    from amatsukaze_amd import AMTEraseLogo
+    torch = gpu["torch"]
+    cfg = dict(SMALL, IMGY=imgy, N=4)
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=32)
+    er = AMTEraseLogo(gpu["ctx"], cs["logo"])
+    X, Y0, LW, LH = cfg["IMGX"], cfg["IMGY"], cfg["LW"], cfg["LH"]
+    assert er.rect == (X, Y0, LW, LH, 1)
+    fades = np.array([[0.3, 0.8], [1.0, 1.0], [0.0, 0.0], [0.5, 0.0]], np.float32)
+    Y, U, V = (cs["clip"][k].copy() for k in "YUV")
+    for i in range(4):
+        cs["orc"].lib.orc_erase_frame(cs["lo"], _ptr(Y[i]), _ptr(U[i]), _ptr(V[i]), Y.shape[2], U.shape[2], bits, float(fades[i, 0]), float(fades[i, 1]))
+    d = cs["dclip"]
+    rY = d.Y[:, Y0:Y0 + LH, X:X + LW].contiguous()
+    rU = d.U[:, Y0 // 2:(Y0 + LH) // 2, X // 2:(X + LW) // 2].contiguous()
+    rV = d.V[:, Y0 // 2:(Y0 + LH) // 2, X // 2:(X + LW) // 2].contiguous()
+    er.erase_rect(rY, rU, rV, bits, fades)
+    view = (lambda x: x.cpu().numpy().view(np.uint16)) if bits > 8 else (lambda x: x.cpu().numpy())
+    assert np.array_equal(view(rY), Y[:, Y0:Y0 + LH, X:X + LW])
+    assert np.array_equal(view(rU), U[:, Y0 // 2:(Y0 + LH) // 2, X // 2:(X + LW) // 2])
+    assert np.array_equal(view(rV), V[:, Y0 // 2:(Y0 + LH) // 2, X // 2:(X + LW) // 2])
+    # host frame -> rectangle rows up, erase, rows back: the per-frame path of include/amt_filters.hpp
+    lib, ctx = gpu["ctx"].lib, gpu["ctx"]
+    es = 1 if bits <= 8 else 2
+    host = cs["clip"]["Y"][0].copy()
+    pitch = host.strides[0]
+    dev = torch.zeros(LW * LH * es, dtype=torch.uint8, device=gpu["dev"])
+    off = Y0 * pitch + X * es
+    ctx.check(lib.amtgpu_frames_upload_strided(ctx.h, C.c_void_p(dev.data_ptr()), LW * es, C.c_void_p(host.ctypes.data + off), pitch, LW * es, LH))
+    ctx.check(lib.amtgpu_frames_upload_wait(ctx.h))
+    ctx.synchronize()
+    got = dev.cpu().numpy().view(host.dtype).reshape(LH, LW)
+    assert np.array_equal(got, cs["clip"]["Y"][0][Y0:Y0 + LH, X:X + LW])
+    dev.fill_(7)
+    ctx.check(lib.amtgpu_download_strided(ctx.h, C.c_void_p(host.ctypes.data + off), pitch, C.c_void_p(dev.data_ptr()), LW * es, LW * es, LH))
+    want = cs["clip"]["Y"][0].copy()
+    want[Y0:Y0 + LH, X:X + LW] = 0x0707 if es == 2 else 7
+    assert np.array_equal(host, want)
+    assert not lib.amtgpu_download_strided(ctx.h, C.c_void_p(host.ctypes.data), 4, C.c_void_p(dev.data_ptr()), LW * es, LW * es, 2)
+
+
 def test_logoscan_sums_and_logo_bit_exact(gpu):
     from amatsukaze_amd import LogoScan
     cs = make_case(gpu, SMALL, pitch_pad=32)
