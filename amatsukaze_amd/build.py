@@ -20,6 +20,7 @@ SOURCES = [
     "eval_engine.hip",
     "eval_fused_kernels.hip",
     "eval_linear_kernels.hip",
+    "eval_pair_kernels.hip",
     "erase_scan_kernels.hip",
     "stats_kernels.hip",
     "ingest_kernels.hip",

@@ -127,6 +127,9 @@ private:
     DevBuf<EvalLogoDev> d_logos_;
     DevBuf<EvalBand> d_bands_;
     DevBuf<float> d_fades_;
+    // fades {0, 1} (the LogoFrame scan): both evaluations as one packed instruction stream (eval_pair_kernels.hip); decided once
+    bool pair_eligible();
+    int pair_state_ = -1;                          // -1 undecided, 0 generic kernel, 1 pair kernel
     // linear mode (built on first use)
     void ensure_linear();
     bool linear_ready_ = false;
@@ -150,6 +153,10 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
                                    const EvalBand* dbands, const float* dfades, int nfades, int fade0, const void* dY,
                                    const int* dframe_map, long long frame_stride_elems, int pitch, int nframes, int G, float* dout,
                                    int out_frame_stride, int take_abs, int plane_cap, float bin_delta);
+// eval_pair_kernels.hip: fades {0, 1} of every logo, bit-exact
+hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const LinLogoDev* dlins, int nlogos,
+                                 const EvalBand* dbands, const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,
+                                 int nframes, int G, float* dout, int out_frame_stride, int take_abs, int plane_cap);
 hipError_t launch_analysis_mark(hipStream_t st, const float* drec, int stride, int nframes, int ngroups, int nfades, const float* eps3,
                                 int* dlist, int* dcount);
 

@@ -179,6 +179,16 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
     const int nl = (int)specs_.size();
     int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
     const int nf_all = (int)fades_.size();
+    if (pair_eligible()) {
+        // fades {0, 1}: the window of s and the window of bg are the two blends themselves
+        const size_t dot = prof_name_.find('.');
+        const int sp = ctx_->prof_begin(("logo_eval_pair_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
+        AMT_HIP(launch_logo_eval_pair(ctx_->stream, bits, d_logos_.get(), d_lins_.get(), nl, d_lin_bands_.get(), dY, dframe_map,
+                                      frame_stride_bytes / es, pitch, nframes, std::max(2, G & ~1), dout, out_frame_stride_, take_abs_ ? 1 : 0,
+                                      lin_plane_cap_));
+        ctx_->prof_end(sp);
+        return;
+    }
     for (int f0 = 0; f0 < nf_all; f0 += kEvalMaxFades) {
         const int nf = std::min(kEvalMaxFades, nf_all - f0);
         G = std::max(1, std::min(G, kEvalThreads / nf));
@@ -188,6 +198,31 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
                                        plane_cap_));
         ctx_->prof_end(sp);
     }
+}
+
+// The pair kernel evaluates fade 0 on s and fade 1 on bg = a*s + b*maxv directly.  That equals the reference's blend
+// fade*bg + (1-fade)*s bit for bit as long as 0*bg == 0, i.e. bg is finite: every coefficient finite and small enough that
+// a*65535 + b*65535 cannot overflow.  Anything else (and shapes the one-pixel-per-thread tables do not cover) keeps the generic kernel.
+bool EvalEngine::pair_eligible()
+{
+    if (pair_state_ >= 0) return pair_state_ == 1;
+    pair_state_ = 0;
+#ifdef AMT_EXPERIMENT
+    if (std::getenv("AMTGPU_NO_PAIR")) return false;       // instrumented builds: time the generic kernel on the scan
+#endif
+    if (fades_.size() != 2 || fades_[0] != 0.0f || fades_[1] != 1.0f || specs_.empty()) return false;
+    for (const EvalLogoSpec& S : specs_) {
+        const int w = S.planes.w, h = S.planes.h;
+        if (5 * lds_pitch(w) > kLinPlaneCap || w > 256 || w < 4 || S.tables.count <= 0) return false;
+        if ((size_t)S.tables.count + kTablePad >= (1u << 21)) return false;
+        const float* a = S.planes.A(0);
+        const float* b = S.planes.B(0);
+        for (int p = 0; p < w * h; ++p)
+            if (!(std::fabs(a[p]) < 1e30f) || !(std::fabs(b[p]) < 1e30f)) return false;       // NaN fails both comparisons
+    }
+    ensure_linear();
+    pair_state_ = 1;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,148 @@
+// eval_lds_stage.h -- helpers shared by the one-pixel-per-thread evaluation kernels (eval_linear_kernels.hip,
+// eval_pair_kernels.hip): raw sample groups and their LDS-direct loads, {s, bg} pair planes, window reads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "eval_plan.h"
+#include "exact_math.h"
+
+namespace amt {
+
+namespace lin {
+
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef f4 __attribute__((aligned(4))) f4u;
+template <typename T> __device__ __forceinline__ T gld(gptr_t base, unsigned byteoff)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(base + byteoff);
+}
+__device__ __forceinline__ f2 bc_lo(f2 v) { return __builtin_shufflevector(v, v, 0, 0); }
+__device__ __forceinline__ f2 bc_hi(f2 v) { return __builtin_shufflevector(v, v, 1, 1); }
+__device__ __forceinline__ int score_bin_dev(float mean)
+{
+    const int bin = (int)__builtin_amdgcn_fmed3f(mean, 0.0f, 255.0f) >> 3;     // == exact_math.h score_bin below 2^31
+    return mean >= 2147483648.0f ? 0 : bin;
+}
+__device__ __forceinline__ f2 div25_pk(f2 x)
+{
+    const f2 z = {0.04f, 0.04f};
+    const f2 q = x * z;
+    const f2 r = __builtin_elementwise_fma(f2{-25.0f, -25.0f}, q, x);
+    return __builtin_elementwise_fma(r, z, q);
+}
+
+template <typename pix_t> struct Raw4;
+template <> struct Raw4<uint8_t> {
+    unsigned v;
+    __device__ __forceinline__ void load(gptr_t base, unsigned byteoff)
+    {
+        typedef unsigned __attribute__((aligned(1))) ua_t;
+        v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
+    }
+    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+    // buffer_load ... lds: the four samples go straight to LDS (lane l to dst[l]), no register is held while they travel
+    static __device__ __forceinline__ void request_lds(__amdgpu_buffer_rsrc_t r, unsigned* dst, unsigned voff, int soff, int)
+    {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 4, voff, soff, 0, 0);
+    }
+    __device__ __forceinline__ void from_lds(const unsigned* src, int lane, int) { v = src[lane]; }
+    static constexpr int kDwordsPerLane = 1;
+    __device__ __forceinline__ int get(int k) const { return (int)((v >> (8 * k)) & 0xFFu); }
+};
+template <> struct Raw4<uint16_t> {
+    u2 v;
+    __device__ __forceinline__ void load(gptr_t base, unsigned byteoff)
+    {
+        typedef u2 __attribute__((aligned(2))) ua_t;
+        v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
+    }
+    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+    static __device__ __forceinline__ void request_lds(__amdgpu_buffer_rsrc_t r, unsigned* dst, unsigned voff, int soff, int nl)
+    {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 4, voff, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + nl), 4, voff + 4u, soff, 0, 0);
+    }
+    __device__ __forceinline__ void from_lds(const unsigned* src, int lane, int nl) { v = u2{src[lane], src[nl + lane]}; }
+    static constexpr int kDwordsPerLane = 2;
+    __device__ __forceinline__ int get(int k) const { return (int)((v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu); }
+};
+
+constexpr int kWaves = kLinThreads / 64;
+constexpr int kStageRows = 2;                  // rows a wave stages per trip
+constexpr int kPartPitch = kLinThreads + 4;    // one LDS row of per-pixel terms per fade
+constexpr int kGatherChunk = 6;                // fades whose scale gathers are in flight together
+
+// the 5x5 window of one pixel, element (r, c) at W[r*5+c] = {s, bg}
+__device__ __forceinline__ void load_window(const f2* plane, int woff, int lp, f2 (&W)[25])
+{
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) W[r * 5 + c] = plane[woff + r * lp + c];
+}
+// {mean(s), mean(bg)} in the reference's order: column sums ((r0+r1)+(r2+r3))+r4, hsum5, /25
+__device__ __forceinline__ f2 window_means(const f2 (&W)[25])
+{
+    f2 c[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = ((W[i] + W[5 + i]) + (W[10 + i] + W[15 + i])) + W[20 + i];
+    return div25_pk(((c[0] + c[4]) + c[2]) + (c[1] + c[3]));
+}
+// {corr(k, s), corr(k, bg)} = sum_i k_i (w_i - mean) = sum_i k_i w_i - mean * sum_i k_i: 25 packed FMAs + one (this path is not
+// the reference's evaluation order; its rounding is covered by EvalEngine::linear_error_bound).  Taps as pairs
+// Kp[j] = {k[2j], k[2j+1]} with Kp[12].y = sum_i k_i, broadcast per use.
+__device__ __forceinline__ f2 window_corr(const f2 (&Kp)[13], const f2 (&W)[25], f2 M)
+{
+    f2 acc0 = {0.0f, 0.0f}, acc1 = acc0;         // two chains: the FMAs of one depend on each other
+#pragma unroll
+    for (int e = 0; e < 25; ++e) {
+        const f2 kk = (e & 1) ? bc_hi(Kp[e >> 1]) : bc_lo(Kp[e >> 1]);
+        if (e & 1) acc1 = __builtin_elementwise_fma(kk, W[e], acc1);
+        else acc0 = __builtin_elementwise_fma(kk, W[e], acc0);
+    }
+    return __builtin_elementwise_fma(-bc_hi(Kp[12]), M, acc0 + acc1);
+}
+// is v within delta of a bin edge that matters: multiples of 8 in [8, 248] ((int)avg clamped to 0..255, >> 3)
+__device__ __forceinline__ bool near_bin_edge(float v, float delta)
+{
+    const float t = v * 0.125f;
+    const float e = __builtin_rintf(t);
+    return fabsf(t - e) * 8.0f < delta && e >= 1.0f && e <= 31.0f;
+}
+// mean of the blended window exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it (LogoScan.hpp:244-251)
+__device__ __forceinline__ float exact_blend_mean(const f2* plane, int woff, int lp, float fade, float omf)
+{
+    float c[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float v[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const f2 e = plane[woff + r * lp + i];
+            v[r] = fade_mix(fade, e.y, e.x);
+        }
+        c[i] = ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
+    }
+    return div25(hsum5(c[0], c[1], c[2], c[3], c[4]));
+}
+
+// a*s + b*maxv for the four pixels a lane stages, given s; LDS layout {s0,bg0,s1,bg1} {s2,bg2,s3,bg3}
+__device__ __forceinline__ void store_pairs(f2* dst, const f4& sv, const f4& av, const f4& bv, float maxv)
+{
+    f4 lo, hi;
+    lo[0] = sv[0]; lo[1] = unblend_bg(av[0], bv[0], maxv, sv[0]);
+    lo[2] = sv[1]; lo[3] = unblend_bg(av[1], bv[1], maxv, sv[1]);
+    hi[0] = sv[2]; hi[1] = unblend_bg(av[2], bv[2], maxv, sv[2]);
+    hi[2] = sv[3]; hi[3] = unblend_bg(av[3], bv[3], maxv, sv[3]);
+    reinterpret_cast<f4*>(dst)[0] = lo;
+    reinterpret_cast<f4*>(dst)[1] = hi;
+}
+
+
+} // namespace lin
+
+} // namespace amt

@@ -407,7 +407,7 @@ def main():
                     same_cpu &= ol.scan(Yp.cpu().numpy(), 16).tobytes() == np.ascontiguousarray(rec[p0:p0 + 16]).tobytes()
             if not (same and same_cpu):
                 raise SystemExit(f"strong_scan verification FAILED: sharded == single-launch: {same}, == CPU oracle: {same_cpu}")
-            calls, ms = prof.get(EVAL + ".scan", (0, 0.0))
+            calls, ms = prof.get("logo_eval_pair_kernel.scan", prof.get(EVAL + ".scan", (0, 0.0)))
             out = {"workload": f"BASELINE configs[3]: {NT}-frame (60 min) 1440x1080i Y-only LogoFrame scan, 3 logos, frames sharded "
                                f"over {world} GPU(s) by contiguous range, all_gather of the records, selectLogo on rank 0",
                    "frames_total": NT, "frames_per_gpu": nloc, "n_gpus": world, "steps": args.strong_steps,
@@ -574,7 +574,9 @@ def main():
         VALU = {"logo_eval_fused_kernel.analysis": (flops_an, LW * LH + 132, "every fade in the reference's fp32 order (bit-exact records)"),
                 "logo_eval_linear_kernel.analysis": (flops_an, LW * LH + 132, "all 11 fades from one window evaluation of s and of bg; flops are the "
                                                      "ALGORITHMIC count of the reference (the kernel issues ~4x fewer), so this fraction may pass 0.5"),
-                "logo_eval_fused_kernel.scan": (flops_scan, 3 * LW * LH + 24, "3 logos x fades {0,1}, reference order (bit-exact records)")}
+                "logo_eval_fused_kernel.scan": (flops_scan, 3 * LW * LH + 24, "3 logos x fades {0,1}, reference order (bit-exact records)"),
+                "logo_eval_pair_kernel.scan": (flops_scan, 3 * LW * LH + 24, "3 logos x fades {0,1}: the window of s and the window of bg as the two halves "
+                                               "of one packed instruction stream, reference order (bit-exact records)")}
         HBM = {"frame_stats_kernel": W * H, "delogo_kernel": 2 * (LW * LH + 2 * (LW // 2) * (LH // 2))}
         pmc = {}
         try:

@@ -90,6 +90,34 @@ def test_logoframe_scan_bit_exact(gpu, tmp_path, cfgname, bits, pad):
         assert ln > 0
 
 
+def test_logoframe_scan_kernel_choice(gpu):
+    """The scan's two fades {0, 1} run on the pair kernel (s and bg evaluated as the two halves of one packed instruction
+    stream) when every logo coefficient is finite and below 1e30, and on the generic blend kernel otherwise; both give the
+    oracle's bytes.  A coefficient of 1e31 keeps bg finite (so the oracle's result is an ordinary number) and forces the generic one."""
+    from amatsukaze_amd import Logo, LogoFrame
+    cs = make_case(gpu, SMALL)
+    cfg, orc, ctx = cs["cfg"], cs["orc"], gpu["ctx"]
+    big = cs["data"].copy()
+    big.reshape(-1)[cfg["LW"] * 2 + 5] = 1e31               # A plane of Y, row 2
+    Y = cs["clip"]["Y"]
+    n = Y.shape[0]
+    for data, kernel in ((cs["data"], "logo_eval_pair_kernel.scan"), (big, "logo_eval_fused_kernel.scan")):
+        logo = Logo.from_planes(ctx, data, cfg["LW"], cfg["LH"], cfg["W"], cfg["H"], cfg["IMGX"], cfg["IMGY"])
+        lf = LogoFrame(ctx, [logo], 0.35)
+        ctx.profile(True)
+        lf.scanFrames(cs["dclip"])
+        got = lf.evalResults
+        used = [k for k, (calls, _) in ctx.profile_report().items() if calls]
+        ctx.profile(False)
+        assert used == [kernel], used
+        lo = orc.make_logo(data, cfg["LW"], cfg["LH"], cfg["W"], cfg["H"], cfg["IMGX"], cfg["IMGY"])
+        d = orc.lib.orc_logo_deint(lo); orc.lib.orc_logo_create_mask(d, 0.35, 1)
+        want = np.zeros(n * 2, np.float32)
+        orc.lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["W"], cfg["H"], n, _ptr(want))
+        assert got.reshape(-1).tobytes() == want.tobytes()
+        assert np.isfinite(want).all()
+
+
 @pytest.mark.parametrize("cfgname,bits", [("small", 8), ("small", 12), ("hd", 8)])
 def test_analyze_logo_bit_exact(gpu, cfgname, bits):
     from amatsukaze_amd import AMTAnalyzeLogo

@@ -46,6 +46,7 @@ def pmc(mode):
 N = 10000
 def name_of(k, mode):
     if "logo_eval_linear_kernel" in k: return "logo_eval_linear_kernel.analysis"
+    if "logo_eval_pair_kernel" in k: return "logo_eval_pair_kernel.scan"
     if "logo_eval_fused_kernel" in k:
         if ", 2>" in k: return "logo_eval_fused_kernel.scan"
         return "logo_eval_fused_kernel.analysis" if mode == "exact" else "logo_eval_fused_kernel.analysis_refine"
