@@ -36,13 +36,10 @@ constexpr int kPairFPI = 2;                                      // frames per i
 constexpr int kPairRows = 2 * kPairFPI;                          // score rows per iteration: (frame, fade)
 constexpr int kPairRowPitch = kLinBandPix + kEvalScorePad;       // floats; the sum reads ahead of the row's end
 
-// {corr(k, s), corr(k, bg)} and the two window means in the reference's order (exact_math.h corr5x5_strided), both halves at once
-__device__ __forceinline__ f2 window_corr_exact(const f2 (&Kp)[13], const f2 (&W)[25], f2& M)
+// {corr(k, s), corr(k, bg)} around the window means M = window_means(W) in the reference's order (exact_math.h corr5x5_strided),
+// both halves at once
+__device__ __forceinline__ f2 window_corr_exact(const f2 (&Kp)[13], const f2 (&W)[25], f2 M)
 {
-    f2 c[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) c[i] = ((W[i] + W[5 + i]) + (W[10 + i] + W[15 + i])) + W[20 + i];
-    M = div25_pk(((c[0] + c[4]) + c[2]) + (c[1] + c[3]));
     f2 p[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -83,6 +80,13 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
     const int w = L.w, lp = L.lp;
     constexpr unsigned ES = sizeof(pix_t);
 
+#ifdef AMT_PAIR_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#define AMT_PTICK(k) do { const long long t_ = clock64(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define AMT_PTICK(k) do { } while (0)
+#endif
     if (tid < 2 * G) accs[tid] = 0.0f;
     const int npairs = (gcount + kPairFPI - 1) / kPairFPI;
     const int niter = X.nbands * npairs;
@@ -105,7 +109,9 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
             prev_g = pr * kPairFPI;
             prev_rows = 2 * min(kPairFPI, gcount - prev_g);
             if (++pr == npairs) { pr = 0; ++bi; }
+            AMT_PTICK(2);
             __syncthreads();
+            AMT_PTICK(6);
         }
         if (niter > 0 && lane < prev_rows) {
             float* a = accs + prev_g * 2 + lane;
@@ -116,8 +122,11 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
         // ---------------- evaluation waves ----------------
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.a), 0, 0x7FFFFFFF, 0x00020000);
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.b), 0, 0x7FFFFFFF, 0x00020000);
-        // staging of one (band, frame): a wave owns rows 2*wave, 2*wave+1 of the band, a lane four adjacent columns (w <= 256);
-        // a ragged right edge (w % 4 == 2) is covered by shifting the last lane group left
+        // Staging unit = one row of the band of one of the iteration's frames; the nrows * kPairFPI units of an iteration are dealt
+        // round-robin to the 8 waves (unit u -> wave u % 8: a 10-row band gives every wave 2 or 3 units; whole rows per wave left
+        // three waves idle and the rest with 4).  A lane stages four adjacent columns (w <= 256); a ragged right edge (w % 4 == 2)
+        // is covered by shifting the last lane group left.
+        constexpr int kMaxUnits = (kLinBandRows * kPairFPI + kPairEvalWaves - 1) / kPairEvalWaves;      // 4
         const bool slane = 4 * lane < w;
         const int sx = min(4 * lane, w - 4);
         const int nl = (w + 3) >> 2;
@@ -127,119 +136,109 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
             const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
         };
-        auto src_row = [&](int y, int j) {
-            return L.deint ? min(max(y - 1 + j, 0), L.h - 1) : min(y + max(j - 1, 0), L.h - 1) * L.row_step;
-        };
-        auto load_raw = [&](const __amdgpu_buffer_rsrc_t rS, int y0, Raw4<pix_t> (&raw)[kStageRows + 2]) {
-            const int y = y0 + kStageRows * wave;
-#pragma unroll
-            for (int j = 0; j < kStageRows + 2; ++j) raw[j].load_buf(rS, (unsigned)sx * ES, src_row(y, j) * pitch * (int)ES);
-        };
-        // LDS-direct request of the next iteration's raw rows into the first of the wave's own rows of the plane they will be
-        // converted into (4 * nl * sizeof(sample) * 4 <= one plane row); collected by pickup_raw after the evaluation
-        auto request_raw = [&](const __amdgpu_buffer_rsrc_t rS, int y0, int nrows, f2* plane) {
-            const int rg = kStageRows * wave;
-            if (rg >= nrows || !slane) return;
-            const int y = y0 + rg;
-            unsigned* dst = reinterpret_cast<unsigned*>(plane + rg * lp);
-#pragma unroll
-            for (int j = 0; j < kStageRows + 2; ++j)
-                Raw4<pix_t>::request_lds(rS, dst + j * nl * Raw4<pix_t>::kDwordsPerLane, (unsigned)sx * ES, src_row(y, j) * pitch * (int)ES, nl);
-        };
-        auto pickup_raw = [&](int nrows, const f2* plane, Raw4<pix_t> (&raw)[kStageRows + 2]) {
-            const int rg = kStageRows * wave;
-            if (rg >= nrows || !slane) return;
-            const unsigned* src = reinterpret_cast<const unsigned*>(plane + rg * lp);
-#pragma unroll
-            for (int j = 0; j < kStageRows + 2; ++j) raw[j].from_lds(src + j * nl * Raw4<pix_t>::kDwordsPerLane, lane, nl);
-        };
-        auto load_ab = [&](int y0, f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
-            const int y = y0 + kStageRows * wave;
-#pragma unroll
-            for (int j = 0; j < kStageRows; ++j) {
-                const int ro = min(y + j, L.h - 1) * w * 4;
-                av[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)sx * 4u, ro, 0));
-                bv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)sx * 4u, ro, 0));
+        // raw source rows of logo row y: y-1, y, y+1 (clamped) under DeintY's [1 2 1] blend, the row itself for field logos.
+        // LDS-direct request of a unit's raw rows into the plane row they will be converted into (3 * nl * sizeof(sample) * 4 bytes
+        // <= one plane row); collected after the evaluation.  All address arithmetic is wave-uniform (scalar unit): one multiply
+        // per unit, the neighbours by adding the pitch.
+        const int pitchB = pitch * (int)ES;
+        auto request_unit = [&](const __amdgpu_buffer_rsrc_t rS, int y, f2* prow) {
+            if (!slane) return;
+            unsigned* dst = reinterpret_cast<unsigned*>(prow);
+            constexpr int kD = Raw4<pix_t>::kDwordsPerLane;
+            if (L.deint) {
+                const int o1 = y * pitchB;
+                Raw4<pix_t>::request_lds(rS, dst, (unsigned)sx * ES, y > 0 ? o1 - pitchB : o1, nl);
+                Raw4<pix_t>::request_lds(rS, dst + nl * kD, (unsigned)sx * ES, o1, nl);
+                Raw4<pix_t>::request_lds(rS, dst + 2 * nl * kD, (unsigned)sx * ES, y < L.h - 1 ? o1 + pitchB : o1, nl);
+            } else {
+                Raw4<pix_t>::request_lds(rS, dst, (unsigned)sx * ES, y * L.row_step * pitchB, nl);
             }
         };
-        // the band's coefficients as {a, b*maxv} pairs in LDS (the product is rounded once, exactly as in a*s + b*maxv), written and
-        // read by the wave that stages those rows (no barrier involved); the column offset is made opaque where LDS addresses are
-        // formed (hoisted, they would be spilled)
-        auto ab_to_lds = [&](int nrows, const f4 (&av)[kStageRows], const f4 (&bv)[kStageRows]) {
+        // bg = a*s + b*maxv (LogoScan.hpp:247); bmv holds b*maxv, the same two roundings
+        auto convert_unit = [&](f2* prow, int y, const f4& av, const f4& bmv) {
+            if (!slane) return;
+            int sxl = sx;
+            asm volatile("" : "+v"(sxl));      // hoisted LDS addresses would be spilled
+            const unsigned* src = reinterpret_cast<const unsigned*>(prow);
+            f4 sv;
+            if (L.deint && y != 0 && y != L.h - 1) {
+                // byte-wise conversion; the [1 2 1] blend on floats: every intermediate is an integer below 2^24, so
+                // (r0 + 2 r1 + r2 + 2) * 0.25 equals the reference's (float)(int sum) / 4.0f bit for bit (LogoScan.hpp:763-780)
+                Raw4<pix_t> r0, r1, r2;
+                r0.from_lds(src, lane, nl);
+                r1.from_lds(src + nl * Raw4<pix_t>::kDwordsPerLane, lane, nl);
+                r2.from_lds(src + 2 * nl * Raw4<pix_t>::kDwordsPerLane, lane, nl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k] = (((float)r0.get(k) + 2.0f * (float)r1.get(k)) + ((float)r2.get(k) + 2.0f)) * 0.25f;
+            } else {
+                Raw4<pix_t> r1;
+                r1.from_lds(src + (L.deint ? nl * Raw4<pix_t>::kDwordsPerLane : 0), lane, nl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k] = (float)r1.get(k);
+            }
+            f2* dst = prow + sxl;
+            reinterpret_cast<f4*>(dst)[0] = f4{sv[0], av[0] * sv[0] + bmv[0], sv[1], av[1] * sv[1] + bmv[1]};
+            reinterpret_cast<f4*>(dst)[1] = f4{sv[2], av[2] * sv[2] + bmv[2], sv[3], av[3] * sv[3] + bmv[3]};
+        };
+        auto load_ab_row = [&](int y, f4& av, f4& bmv) {
+            const int ro = min(y, L.h - 1) * w * 4;
+            av = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)sx * 4u, ro, 0));
+            const f4 bv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)sx * 4u, ro, 0));
+            bmv = bv * maxv;
+        };
+        // the band's coefficients as {a, b*maxv} pairs in LDS; written during the band's first conversion by the wave that owns the
+        // row's frame-0 unit, read from the second iteration on (a barrier lies in between)
+        auto ab_row_to_lds = [&](int r, const f4& av, const f4& bmv) {
             if (!slane) return;
             int sxl = sx;
             asm volatile("" : "+v"(sxl));
-#pragma unroll
-            for (int j = 0; j < kStageRows; ++j) {
-                if (kStageRows * wave + j >= nrows) break;
-                f4* d = reinterpret_cast<f4*>(abp + (kStageRows * wave + j) * lp + sxl);
-                d[0] = f4{av[j][0], bv[j][0] * maxv, av[j][1], bv[j][1] * maxv};
-                d[1] = f4{av[j][2], bv[j][2] * maxv, av[j][3], bv[j][3] * maxv};
-            }
+            f4* d = reinterpret_cast<f4*>(abp + r * lp + sxl);
+            d[0] = f4{av[0], bmv[0], av[1], bmv[1]};
+            d[1] = f4{av[2], bmv[2], av[3], bmv[3]};
         };
-        auto ab_from_lds = [&](int nrows, f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
+        auto ab_row_from_lds = [&](int r, f4& av, f4& bmv) {
             int sxl = sx;
             asm volatile("" : "+v"(sxl));
-#pragma unroll
-            for (int j = 0; j < kStageRows; ++j) {
-                if (kStageRows * wave + j >= nrows) break;
-                const f4* d = reinterpret_cast<const f4*>(abp + (kStageRows * wave + j) * lp + min(sxl, lp - 4));
-                const f4 lo = d[0], hi = d[1];
-                av[j] = f4{lo[0], lo[2], hi[0], hi[2]};
-                bv[j] = f4{lo[1], lo[3], hi[1], hi[3]};
-            }
+            const f4* d = reinterpret_cast<const f4*>(abp + r * lp + min(sxl, lp - 4));
+            const f4 lo = d[0], hi = d[1];
+            av = f4{lo[0], lo[2], hi[0], hi[2]};
+            bmv = f4{lo[1], lo[3], hi[1], hi[3]};
         };
-        // byte-wise conversion; the [1 2 1] blend of DeintY (LogoScan.hpp:763-780) on floats: every intermediate is an integer below
-        // 2^24, so (r0 + 2 r1 + r2 + 2) * 0.25 equals the reference's (float)(int sum) / 4.0f bit for bit
-        auto convert_store = [&](f2* plane, int y0, int nrows, const Raw4<pix_t> (&raw)[kStageRows + 2], const f4 (&av)[kStageRows],
-                                 const f4 (&bv)[kStageRows]) {
-            const int rg = kStageRows * wave;
-            if (!slane) return;
-            int sxl = sx;
-            asm volatile("" : "+v"(sxl));
-            f4 fr[kStageRows + 2];
+        // this thread's mask pixel of a band: window offset, table index, taps
+        auto load_pixel = [&](const EvalBand& Bd, bool& act_, int& woff_, unsigned& m8_, f2 (&K)[13]) {
+            act_ = tid < Bd.npix;
+            const unsigned m = (unsigned)(Bd.m0 + (act_ ? tid : 0));
+            const unsigned pos = gld<unsigned>(gPos, m * 4u);
+            woff_ = ((int)(pos >> 16) - 2 - Bd.y0) * lp + (int)(pos & 0xFFFFu) - 2;
+            m8_ = m * 8u;
 #pragma unroll
-            for (int j = 0; j < kStageRows + 2; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) fr[j][k] = (float)raw[j].get(k);
-#pragma unroll
-            for (int j = 0; j < kStageRows; ++j) {
-                const int yy = y0 + rg + j;
-                if (rg + j < nrows) {
-                    f4 sv;
-                    if (L.deint && yy != 0 && yy != L.h - 1) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) sv[k] = ((fr[j][k] + 2.0f * fr[j + 1][k]) + (fr[j + 2][k] + 2.0f)) * 0.25f;
-                    } else {
-                        sv = fr[j + 1];
-                    }
-                    // bv holds b*maxv: bg = a*s + b*maxv (LogoScan.hpp:247), the same two roundings
-                    f2* dst = plane + (rg + j) * lp + sxl;
-                    reinterpret_cast<f4*>(dst)[0] = f4{sv[0], av[j][0] * sv[0] + bv[j][0], sv[1], av[j][1] * sv[1] + bv[j][1]};
-                    reinterpret_cast<f4*>(dst)[1] = f4{sv[2], av[j][2] * sv[2] + bv[j][2], sv[3], av[j][3] * sv[3] + bv[j][3]};
-                }
-            }
+            for (int j = 0; j < 13; ++j) K[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
         };
 
         EvalBand B = bands[X.band0];
-        // prologue: the first iteration's rows
-        {
-            f4 av[kStageRows], bv[kStageRows];
-            load_ab(B.y0, av, bv);
-            ab_to_lds(B.nrows, av, bv);
-            ab_from_lds(B.nrows, av, bv);                 // bv = b*maxv from here on
-#pragma unroll
-            for (int fr = 0; fr < kPairFPI; ++fr) {
-                Raw4<pix_t> raw[kStageRows + 2];
-                load_raw(frame_rsrc(fr), B.y0, raw);
-                convert_store(planes + fr * plane_cap, B.y0, B.nrows, raw, av, bv);
-            }
-        }
         bool act = false;
         unsigned m8 = 0;
         int woff = 0;
         const unsigned cpad8 = cpad * 8u;
         f2 Kp[13];
+        load_pixel(B, act, woff, m8, Kp);
+        // prologue: the first iteration's rows, straight from memory
+        {
+            const int U = B.nrows * kPairFPI;
+#pragma unroll
+            for (int k = 0; k < kMaxUnits; ++k) {
+                const int u = wave + kPairEvalWaves * k;
+                if (u >= U) break;
+                const int fr = u >= B.nrows ? 1 : 0, r = u - fr * B.nrows;
+                f2* prow = planes + fr * plane_cap + r * lp;
+                request_unit(frame_rsrc(fr), B.y0 + r, prow);
+                f4 av, bmv;
+                load_ab_row(B.y0 + r, av, bmv);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (fr == 0) ab_row_to_lds(r, av, bmv);
+                convert_unit(prow, B.y0 + r, av, bmv);
+            }
+        }
         __syncthreads();
 
         int bi = 0, pr = 0;
@@ -247,16 +246,6 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
             const int cur = it & 1;
             f2* const plane = planes + cur * kPairFPI * plane_cap;
             f2* const nplane = planes + (cur ^ 1) * kPairFPI * plane_cap;
-            if (pr == 0) {
-                // ---- a new band: this thread's mask pixel, its window offset and its taps ----
-                act = tid < B.npix;
-                const unsigned m = (unsigned)(B.m0 + (act ? tid : 0));
-                const unsigned pos = gld<unsigned>(gPos, m * 4u);
-                woff = ((int)(pos >> 16) - 2 - B.y0) * lp + (int)(pos & 0xFFFFu) - 2;
-                m8 = m * 8u;
-#pragma unroll
-                for (int j = 0; j < 13; ++j) Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
-            }
             const bool has_next = it + 1 < niter;
             const bool next_band = pr + 1 == npairs;
             const int npr = next_band ? 0 : pr + 1;
@@ -265,15 +254,24 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
                 const EvalBand* nb = bands + X.band0 + bi + 1;
                 Bn.m0 = nb->m0; Bn.npix = nb->npix; Bn.y0 = nb->y0; Bn.nrows = nb->nrows;
             }
+            const int Un = Bn.nrows * kPairFPI;
+            AMT_PTICK(0);
             // ---- 1. request the next iteration's raw rows ----
 #ifndef AMT_PAIR_NO_STAGE
             if (has_next) {
 #else
             if (false) {
 #endif
+                const __amdgpu_buffer_rsrc_t rs0 = frame_rsrc(npr * kPairFPI), rs1 = frame_rsrc(npr * kPairFPI + 1);
 #pragma unroll
-                for (int fr = 0; fr < kPairFPI; ++fr) request_raw(frame_rsrc(npr * kPairFPI + fr), Bn.y0, Bn.nrows, nplane + fr * plane_cap);
+                for (int k = 0; k < kMaxUnits; ++k) {
+                    const int u = wave + kPairEvalWaves * k;
+                    if (u >= Un) break;
+                    const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
+                    request_unit(fr ? rs1 : rs0, Bn.y0 + r, nplane + fr * plane_cap + r * lp);
+                }
             }
+            AMT_PTICK(1);
             // ---- 2. both fades of both frames: one packed window evaluation per frame ----
             // (the taps are loop-invariant: LICM would hoist their {k,k} broadcasts and keep 50 registers of copies; the empty asm
             //  makes them opaque per iteration and the broadcast folds into the multiply's op_sel)
@@ -288,8 +286,11 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
                 M = plane[fr * plane_cap + woff]; R[fr] = Kp[fr] * M;
 #else
                 load_window(plane + fr * plane_cap, woff, lp, W);        // surplus threads read pixel B.m0's window: never written out
+                M = window_means(W);
                 R[fr] = window_corr_exact(Kp, W, M);
 #endif
+                // (issuing the two scale gathers right after the means, ahead of the correlation's 75 packed ops, measured slower:
+                //  5.30 vs 5.16 ms per 10 000 frames)
 #ifdef AMT_PAIR_NO_GATHER
                 sc0[fr] = f2{1e-4f * (float)score_bin_dev(M.x), 0.5f}; sc1[fr] = f2{1e-4f * (float)score_bin_dev(M.y), 0.5f};
 #else
@@ -297,16 +298,20 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
                 sc1[fr] = gld<f2>(gScales, __umul24((unsigned)score_bin_dev(M.y), cpad8) + m8);
 #endif
             }
-            f4 av[kStageRows], bv[kStageRows];
-            if (has_next && next_band) load_ab(Bn.y0, av, bv);           // once per band, from memory
+#ifdef AMT_PAIR_TIMING
+            if (R[0].x == 123456.0f && R[1].y == 123456.0f) tacc[7] += 1;
+#endif
+            AMT_PTICK(2);
             // ---- 3. per-pixel terms (LogoScan.hpp:305-308) -> the score rows ----
+            const bool act_now = act;
 #pragma unroll
             for (int fr = 0; fr < kPairFPI; ++fr) {
-                if (act) {
+                if (act_now) {
                     myrows[(fr * 2 + 0) * kPairRowPitch] = score_term(R[fr].x, sc0[fr].x, sc0[fr].y);
                     myrows[(fr * 2 + 1) * kPairRowPitch] = score_term(R[fr].y, sc1[fr].x, sc1[fr].y);
                 }
             }
+            AMT_PTICK(3);
             // ---- 4. the next iteration's rows: raw -> {s, bg} in place (holding the terms back until after the conversion so that it
             //      covers the scale gathers' trip was tried: 36 registers spilled, 5.4 -> 8.2 ms per 10 000 frames) ----
 #ifdef AMT_PAIR_NO_STAGE
@@ -314,22 +319,51 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
 #else
             if (has_next) {
 #endif
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-direct loads are counted with the vector-memory loads
-                if (next_band) ab_to_lds(Bn.nrows, av, bv);
-                ab_from_lds(Bn.nrows, av, bv);
+                f4 av[kMaxUnits], bmv[kMaxUnits];
+                if (next_band) {
 #pragma unroll
-                for (int fr = 0; fr < kPairFPI; ++fr) {
-                    Raw4<pix_t> raw[kStageRows + 2];
-                    pickup_raw(Bn.nrows, nplane + fr * plane_cap, raw);
-                    convert_store(nplane + fr * plane_cap, Bn.y0, Bn.nrows, raw, av, bv);
+                    for (int k = 0; k < kMaxUnits; ++k) {
+                        const int u = wave + kPairEvalWaves * k;
+                        if (u >= Un) break;
+                        const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
+                        load_ab_row(Bn.y0 + r, av[k], bmv[k]);           // once per band, from memory
+                    }
+                    // the band's last evaluation is done: the next band's pixel and taps (14 loads, issued after everything the
+                    // conversion needs) travel while the rows are converted
+                    asm volatile("" ::: "memory");
+                    load_pixel(Bn, act, woff, m8, Kp);
+                    asm volatile("" ::: "memory");
+                }
+                // the LDS-direct loads were issued before everything else and vector-memory loads return in order: what may stay
+                // outstanding here are the next band's 14 pixel / tap loads (when one starts), never the raw rows or the coefficients
+                if (next_band) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                AMT_PTICK(4);
+#pragma unroll
+                for (int k = 0; k < kMaxUnits; ++k) {
+                    const int u = wave + kPairEvalWaves * k;
+                    if (u >= Un) break;
+                    const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
+                    if (next_band) { if (fr == 0) ab_row_to_lds(r, av[k], bmv[k]); }
+                    else ab_row_from_lds(r, av[k], bmv[k]);
+                    convert_unit(nplane + fr * plane_cap + r * lp, Bn.y0 + r, av[k], bmv[k]);
                 }
             }
+            AMT_PTICK(5);
             __syncthreads();                     // next planes and this iteration's score rows complete; current planes consumed
+            AMT_PTICK(6);
             if (next_band) { B.m0 = Bn.m0; B.npix = Bn.npix; B.y0 = Bn.y0; B.nrows = Bn.nrows; ++bi; }
             pr = npr;
         }
         __syncthreads();                         // the summing wave's last rows
     }
+#ifdef AMT_PAIR_TIMING
+    if (lane == 0 && blockIdx.x == gridDim.x / 2 && (wave == 0 || wave == 3 || wave == 7 || wave == 8)) {
+        long long* tb = reinterpret_cast<long long*>(out + (long long)nframes * out_frame_stride);   // host reserves room
+        const int slot = wave == 0 ? 0 : (wave == 3 ? 1 : (wave == 7 ? 2 : 3));
+        for (int k = 0; k < 8; ++k) tb[slot * 8 + k] = tacc[k];
+    }
+#endif
     if (tid < gcount * 2) {
         const int gg = tid >> 1, f = tid & 1;
         float r = accs[tid] / L.blackScore;

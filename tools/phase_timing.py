@@ -19,7 +19,7 @@ ap.add_argument("--frames", type=int, default=2048)
 a = ap.parse_args()
 if a.build:
     from amatsukaze_amd import build as b
-    print(b.build_variant("timing", ["AMT_FUSED_TIMING"]))
+    print(b.build_variant("timing", ["AMT_FUSED_TIMING", "AMT_PAIR_TIMING"]))
     sys.exit(0)
 
 import torch
@@ -51,6 +51,15 @@ else:
         an.analyze_device(dclip.Y[: a.frames], 8, out)
     torch.cuda.synchronize()
     t = out[a.frames:].reshape(-1)[:64].contiguous().view(torch.int64).cpu().numpy().reshape(4, 8)
+if a.what == "scan":
+    pn = ["band start (pixel, taps)", "request raw rows (LDS-direct)", "windows + evaluation / ordered sum", "gathers landed, terms, row writes",
+          "wait for the raw rows", "convert -> {s,bg}", "wait at the barrier", "-"]
+    tot = t[:, :7].sum(1)
+    print("pair kernel: cycles (s_memtime ticks) of the middle workgroup; waves 0, 3, 7 evaluate, wave 8 sums:")
+    for k in range(7):
+        print(f"  {pn[k]:36s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
+    print("  total                                " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
+    sys.exit(0)
 names = ["band prologue (slot, taps)", "staging loads+LDS writes", "ordered sum (one wave)", "wait B1", "window reads", "fade loop",
          "wait B0", "-"]
 tot = t[:, :7].sum(1)
