@@ -142,6 +142,91 @@ __device__ __forceinline__ void store_pairs(f2* dst, const f4& sv, const f4& av,
     reinterpret_cast<f4*>(dst)[1] = hi;
 }
 
+// Staging of ONE row of an evaluation logo's band for one frame ("unit"), shared by the pair and the linear kernel.  A lane stages
+// four adjacent columns (w <= 256); a ragged right edge (w % 4 == 2) is covered by shifting the last lane group left, its two
+// duplicated columns are written twice with the same values.  Everything except the column offset is wave-uniform.
+template <typename pix_t> struct RowStager {
+    static constexpr unsigned ES = sizeof(pix_t);
+    static constexpr int kD = Raw4<pix_t>::kDwordsPerLane;
+    int w, h, lp, lane, nl, sx, pitchB, row_step, deint;
+    bool slane;
+    float maxv;
+    __device__ __forceinline__ RowStager(const EvalLogoDev& L, int lane_, int pitch, float maxv_)
+        : w(L.w), h(L.h), lp(L.lp), lane(lane_), nl((L.w + 3) >> 2), sx(min(4 * lane_, L.w - 4)), pitchB(pitch * (int)ES),
+          row_step(L.row_step), deint(L.deint), slane(4 * lane_ < L.w), maxv(maxv_) {}
+
+    // LDS-direct request (buffer_load ... lds: no registers held while the samples travel) of the raw source rows of logo row y --
+    // y-1, y, y+1 (clamped) under DeintY's [1 2 1] blend (LogoScan.hpp:763-780), the row itself for field logos -- into the plane
+    // row they will be converted into (3 * nl * sizeof(sample) * 4 bytes <= one plane row of lp pairs).  One multiply per unit,
+    // the neighbours by adding the pitch.
+    __device__ __forceinline__ void request(const __amdgpu_buffer_rsrc_t rS, int y, f2* prow) const
+    {
+        if (!slane) return;
+        unsigned* dst = reinterpret_cast<unsigned*>(prow);
+        if (deint) {
+            const int o1 = y * pitchB;
+            Raw4<pix_t>::request_lds(rS, dst, (unsigned)sx * ES, y > 0 ? o1 - pitchB : o1, nl);
+            Raw4<pix_t>::request_lds(rS, dst + nl * kD, (unsigned)sx * ES, o1, nl);
+            Raw4<pix_t>::request_lds(rS, dst + 2 * nl * kD, (unsigned)sx * ES, y < h - 1 ? o1 + pitchB : o1, nl);
+        } else {
+            Raw4<pix_t>::request_lds(rS, dst, (unsigned)sx * ES, y * row_step * pitchB, nl);
+        }
+    }
+    // raw samples (landed in prow) -> {s, bg = a*s + b*maxv} pairs in place (LogoScan.hpp:247); bmv holds b*maxv -- the same two
+    // roundings.  Byte-wise conversion; the [1 2 1] blend on floats: every intermediate is an integer below 2^24, so
+    // (r0 + 2 r1 + r2 + 2) * 0.25 equals the reference's (float)(int sum) / 4.0f bit for bit.
+    __device__ __forceinline__ void convert(f2* prow, int y, const f4& av, const f4& bmv) const
+    {
+        if (!slane) return;
+        int sxl = sx;
+        asm volatile("" : "+v"(sxl));      // LDS addresses hoisted out of the iteration loop would be spilled
+        const unsigned* src = reinterpret_cast<const unsigned*>(prow);
+        f4 sv;
+        if (deint && y != 0 && y != h - 1) {
+            Raw4<pix_t> r0, r1, r2;
+            r0.from_lds(src, lane, nl);
+            r1.from_lds(src + nl * kD, lane, nl);
+            r2.from_lds(src + 2 * nl * kD, lane, nl);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = (((float)r0.get(k) + 2.0f * (float)r1.get(k)) + ((float)r2.get(k) + 2.0f)) * 0.25f;
+        } else {
+            Raw4<pix_t> r1;
+            r1.from_lds(src + (deint ? nl * kD : 0), lane, nl);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = (float)r1.get(k);
+        }
+        f2* dst = prow + sxl;
+        reinterpret_cast<f4*>(dst)[0] = f4{sv[0], av[0] * sv[0] + bmv[0], sv[1], av[1] * sv[1] + bmv[1]};
+        reinterpret_cast<f4*>(dst)[1] = f4{sv[2], av[2] * sv[2] + bmv[2], sv[3], av[3] * sv[3] + bmv[3]};
+    }
+    // the logo coefficients of row y from memory: a and b*maxv (the product is rounded once, exactly as in a*s + b*maxv)
+    __device__ __forceinline__ void load_ab(const __amdgpu_buffer_rsrc_t rA, const __amdgpu_buffer_rsrc_t rB, int y, f4& av, f4& bmv) const
+    {
+        const int ro = min(y, h - 1) * w * 4;
+        av = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)sx * 4u, ro, 0));
+        const f4 bv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)sx * 4u, ro, 0));
+        bmv = bv * maxv;
+    }
+    // ... kept in LDS as {a, b*maxv} pairs across the frames of a workgroup (abrow = the row's pairs)
+    __device__ __forceinline__ void ab_to_lds(f2* abrow, const f4& av, const f4& bmv) const
+    {
+        if (!slane) return;
+        int sxl = sx;
+        asm volatile("" : "+v"(sxl));
+        f4* d = reinterpret_cast<f4*>(abrow + sxl);
+        d[0] = f4{av[0], bmv[0], av[1], bmv[1]};
+        d[1] = f4{av[2], bmv[2], av[3], bmv[3]};
+    }
+    __device__ __forceinline__ void ab_from_lds(const f2* abrow, f4& av, f4& bmv) const
+    {
+        int sxl = sx;
+        asm volatile("" : "+v"(sxl));
+        const f4* d = reinterpret_cast<const f4*>(abrow + min(sxl, lp - 4));
+        const f4 lo = d[0], hi = d[1];
+        av = f4{lo[0], lo[2], hi[0], hi[2]};
+        bmv = f4{lo[1], lo[3], hi[1], hi[3]};
+    }
+};
 
 } // namespace lin
 

@@ -78,160 +78,78 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
     // bin edges in 1/4096 fixed point: a mean within dq of a multiple of 8 takes the exact path
     const int dq = (int)(bin_delta * 4096.0f) + 2;
 
+#ifdef AMT_LIN_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = clock64();
+#define AMT_LTICK(k) do { const long long t_ = clock64(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define AMT_LTICK(k) do { } while (0)
+#endif
     if (tid < G * nfades) accs[tid] = 0.0f;
     const int fade_bits = __builtin_bit_cast(int, fades[fade0 + min(lane, nfades - 1)]);     // lane f holds fade f
     // buffer descriptors: loads below are (descriptor, per-lane column offset, wave-uniform row offset) -- no per-load address math
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.a), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.b), 0, 0x7FFFFFFF, 0x00020000);
 
-    // ---- staging of one (band, frame): a wave owns rows rg = 2*wave, 2*wave+1 of the band (bands have <= 2*kWaves rows, host),
-    //      a lane four adjacent columns (w <= 256, host); a ragged right edge (w % 4 == 2) is covered by shifting the last lane
-    //      group left, its two duplicated columns are written twice with the same values ----
-    const bool slane = 4 * lane < w;
-    const int sx = min(4 * lane, w - 4);
-    struct RowSet { int y, nrows; };
+    // ---- staging: unit = one row of the band (RowStager, eval_lds_stage.h); row r belongs to wave r % 8 -- rows 2w, 2w+1 per wave put
+    //      twice the conversion work on the SIMD that hosts waves 0 and 4 of a typical 10-row band.  The raw rows of the next iteration
+    //      are requested at the top of an iteration with buffer_load ... lds (no registers held) into the plane row they are
+    //      converted into after the fade code; the row's logo coefficients {a, b*maxv} stay in LDS across the frames of the
+    //      workgroup, written and read by the wave that owns the row (no barrier involved) ----
+    constexpr int kMaxUnits = kLinBandRows / kWaves;               // 2
+    const RowStager<pix_t> st(L, lane, pitch, maxv);
     auto frame_rsrc = [&](int g) {
         const int frame = F0 + g;
         const int srcFrame = frame_map ? frame_map[frame] : frame;
         const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
     };
-    auto load_raw = [&](const __amdgpu_buffer_rsrc_t rS, int y0, Raw4<pix_t> (&raw)[kStageRows + 2]) {
-        const int y = y0 + kStageRows * wave;
-#pragma unroll
-        for (int j = 0; j < kStageRows + 2; ++j) {
-            const int row = L.deint ? min(max(y - 1 + j, 0), L.h - 1) : min(y + max(j - 1, 0), L.h - 1) * L.row_step;
-            raw[j].load_buf(rS, (unsigned)sx * ES, row * pitch * (int)ES);
-        }
-    };
-    // The same request without registers: the raw rows travel straight into LDS, into the first of the wave's OWN rows of the plane
-    // they will be converted into.  Only the lanes that stage columns take part (nl = ceil(w/4) of them), so the four raw rows occupy
-    // 4 * nl * sizeof(sample) * 4 <= 8 * (w + 8) bytes: one plane row always holds them.  pickup_raw collects them after the fade
-    // code; issued at the top of an iteration, the whole iteration covers the trip to HBM.
-    const int nl = (w + 3) >> 2;
-    auto request_raw = [&](const __amdgpu_buffer_rsrc_t rS, int y0, int nrows, f2* plane) {
-        const int rg = kStageRows * wave;
-        if (rg >= nrows || !slane) return;
-        const int y = y0 + rg;
-        unsigned* dst = reinterpret_cast<unsigned*>(plane + rg * lp);
-#pragma unroll
-        for (int j = 0; j < kStageRows + 2; ++j) {
-            const int row = L.deint ? min(max(y - 1 + j, 0), L.h - 1) : min(y + max(j - 1, 0), L.h - 1) * L.row_step;
-            Raw4<pix_t>::request_lds(rS, dst + j * nl * Raw4<pix_t>::kDwordsPerLane, (unsigned)sx * ES, row * pitch * (int)ES, nl);
-        }
-    };
-    auto pickup_raw = [&](int nrows, const f2* plane, Raw4<pix_t> (&raw)[kStageRows + 2]) {
-        const int rg = kStageRows * wave;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the LDS-direct loads are counted with the vector-memory loads
-#ifdef AMT_LIN_DMA_BARRIER
-        __syncthreads();
-#endif
-        if (rg >= nrows || !slane) return;
-        const unsigned* src = reinterpret_cast<const unsigned*>(plane + rg * lp);
-#pragma unroll
-        for (int j = 0; j < kStageRows + 2; ++j) raw[j].from_lds(src + j * nl * Raw4<pix_t>::kDwordsPerLane, lane, nl);
-    };
-    auto load_ab = [&](int y0, f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
-        const int y = y0 + kStageRows * wave;
-#pragma unroll
-        for (int j = 0; j < kStageRows; ++j) {
-            const int ro = min(y + j, L.h - 1) * w * 4;
-            av[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)sx * 4u, ro, 0));
-            bv[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)sx * 4u, ro, 0));
-        }
-    };
-    // the band's logo coefficients are the same for every frame: kept in LDS as {a, b} pairs, written and read by the wave that
-    // stages those rows (no barrier involved)
-    // (the column offset is made opaque where LDS addresses are formed: hoisted out of the iteration loop they would be kept in
-    //  registers the loop does not have, i.e. spilled to scratch and re-read every iteration)
-    auto ab_to_lds = [&](int nrows, const f4 (&av)[kStageRows], const f4 (&bv)[kStageRows]) {
-        if (!slane) return;
-        int sxl = sx;
-        asm volatile("" : "+v"(sxl));
-#pragma unroll
-        for (int j = 0; j < kStageRows; ++j) {
-            if (kStageRows * wave + j >= nrows) break;         // the plane holds the rows of the tallest band, not 2 * kWaves
-            f4* d = reinterpret_cast<f4*>(abp + (kStageRows * wave + j) * lp + sxl);
-            d[0] = f4{av[j][0], bv[j][0], av[j][1], bv[j][1]};
-            d[1] = f4{av[j][2], bv[j][2], av[j][3], bv[j][3]};
-        }
-    };
-    auto ab_from_lds = [&](int nrows, f4 (&av)[kStageRows], f4 (&bv)[kStageRows]) {
-        int sxl = sx;
-        asm volatile("" : "+v"(sxl));
-#pragma unroll
-        for (int j = 0; j < kStageRows; ++j) {
-            if (kStageRows * wave + j >= nrows) break;
-            const f4* d = reinterpret_cast<const f4*>(abp + (kStageRows * wave + j) * lp + min(sxl, lp - 4));
-            const f4 lo = d[0], hi = d[1];
-            av[j] = f4{lo[0], lo[2], hi[0], hi[2]};
-            bv[j] = f4{lo[1], lo[3], hi[1], hi[3]};
-        }
-    };
-    // Samples are converted byte-wise and the [1 2 1] vertical blend of DeintY (LogoScan.hpp:763-780) is done on the floats: every
-    // intermediate is an integer below 2^24, so (r0 + 2 r1 + r2 + 2) * 0.25 equals the reference's (float)(int sum) / 4.0f bit for bit
-    auto convert_store = [&](f2* plane, int y0, int nrows, const Raw4<pix_t> (&raw)[kStageRows + 2], const f4 (&av)[kStageRows],
-                             const f4 (&bv)[kStageRows]) {
-        const int rg = kStageRows * wave;
-        if (!slane) return;
-        int sxl = sx;
-        asm volatile("" : "+v"(sxl));
-        f4 fr[kStageRows + 2];
-#pragma unroll
-        for (int j = 0; j < kStageRows + 2; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) fr[j][k] = (float)raw[j].get(k);
-#pragma unroll
-        for (int j = 0; j < kStageRows; ++j) {
-            const int yy = y0 + rg + j;
-            if (rg + j < nrows) {
-                f4 sv;
-                if (L.deint && yy != 0 && yy != L.h - 1) {       // uniform per row
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sv[k] = ((fr[j][k] + 2.0f * fr[j + 1][k]) + (fr[j + 2][k] + 2.0f)) * 0.25f;
-                } else {
-                    sv = fr[j + 1];
-                }
-                store_pairs(plane + (rg + j) * lp + sxl, sv, av[j], bv[j], maxv);
-            }
-        }
-    };
 
     const int niter = X.nbands * gcount;
     EvalBand B = bands[X.band0];
     // prologue: the first iteration's rows
     {
-        Raw4<pix_t> raw[kStageRows + 2];
-        f4 av[kStageRows], bv[kStageRows];
-        load_raw(frame_rsrc(0), B.y0, raw);
-        load_ab(B.y0, av, bv);
-        ab_to_lds(B.nrows, av, bv);
-        convert_store(planes, B.y0, B.nrows, raw, av, bv);
+        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(0);
+#pragma unroll
+        for (int k = 0; k < kMaxUnits; ++k) {
+            const int r = wave + kWaves * k;
+            if (r >= B.nrows) break;
+            f4 av, bmv;
+            st.request(rs, B.y0 + r, planes + r * lp);
+            st.load_ab(rA, rB, B.y0 + r, av, bmv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st.ab_to_lds(abp + r * lp, av, bmv);
+            st.convert(planes + r * lp, B.y0 + r, av, bmv);
+        }
     }
     bool act = false;
     unsigned m = 0, m8 = 0;
     int woff = 0;
     const unsigned cpad8 = cpad * 8u;
     f2 Kp[13];
+    // a band's mask pixel of this thread: window offset, table index, taps (a surplus thread gets zero taps: it evaluates to exactly 0,
+    // no branches in the fade code)
+    auto load_pixel = [&](const EvalBand& Bd) {
+        act = tid < Bd.npix;
+        m = (unsigned)(Bd.m0 + (act ? tid : 0));
+        const unsigned pos = gld<unsigned>(gPos, m * 4u);
+        woff = ((int)(pos >> 16) - 2 - Bd.y0) * lp + (int)(pos & 0xFFFFu) - 2;          // plane offset of the window's top-left element
+        m8 = m * 8u;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
+            if (!act) Kp[j] = f2{0.0f, 0.0f};
+        }
+    };
+    load_pixel(B);
     __syncthreads();
 
     int bi = 0, g = 0;
     for (int it = 0; it < niter; ++it) {
         const int cur = it & 1;
         f2* const plane = planes + cur * plane_cap;
-        if (g == 0) {
-            // ---- a new band: this thread's mask pixel, its window offset and its taps ----
-            act = tid < B.npix;
-            m = (unsigned)(B.m0 + (act ? tid : 0));
-            const unsigned pos = gld<unsigned>(gPos, m * 4u);
-            woff = ((int)(pos >> 16) - 2 - B.y0) * lp + (int)(pos & 0xFFFFu) - 2;          // plane offset of the window's top-left element
-            m8 = m * 8u;
-#pragma unroll
-            for (int j = 0; j < 13; ++j) {
-                Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
-                if (!act) Kp[j] = f2{0.0f, 0.0f};      // a surplus thread evaluates to exactly 0 (no branches in the fade code below)
-            }
-        }
+        // (a band's pixel and taps are requested behind the previous band's last evaluation, see load_pixel below)
+        AMT_LTICK(0);
         // the next iteration: same band / next frame, or the next band / first frame
         const bool has_next = it + 1 < niter;
         const bool next_band = g + 1 == gcount;
@@ -242,9 +160,16 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             Bn.m0 = nb->m0; Bn.npix = nb->npix; Bn.y0 = nb->y0; Bn.nrows = nb->nrows;
         }
         // ---- 1. request the next iteration's raw rows (LDS-direct: no registers held) ----
-#ifndef AMT_LIN_NO_DMA
-        if (has_next) request_raw(frame_rsrc(ng), Bn.y0, Bn.nrows, planes + (cur ^ 1) * plane_cap);
-#endif
+        if (has_next) {
+            const __amdgpu_buffer_rsrc_t rs = frame_rsrc(ng);
+#pragma unroll
+            for (int k = 0; k < kMaxUnits; ++k) {
+                const int r = wave + kWaves * k;
+                if (r >= Bn.nrows) break;
+                st.request(rs, Bn.y0 + r, planes + (cur ^ 1) * plane_cap + r * lp);
+            }
+        }
+        AMT_LTICK(1);
         // ---- 2. fold the previous iteration's per-wave sums into the running sums (fixed order: deterministic) ----
         if (it > 0 && tid < nfades) {
             const float* wp = wpart + (cur ^ 1) * kWaves * NFMAX + tid;
@@ -270,7 +195,11 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             R = window_corr(Kp, W, M);
         }
 #endif
-        f4 av[kStageRows], bv[kStageRows];
+#ifdef AMT_LIN_TIMING
+        if (R.x == 123456.0f && M.y == 123456.0f) tacc[7] += 1;
+#endif
+        AMT_LTICK(2);
+        f4 av[kMaxUnits], bmv[kMaxUnits];
         // ---- 5. all fades from the two pairs: interpolated mean -> bin -> scale gather, all in flight together; while they travel
         //      the next iteration's rows are converted into the other plane (loads return in order: raw rows and coefficients
         //      were requested earlier); then correlation and per-pixel term (LogoScan.hpp:305-308), summed over the wave.
@@ -329,8 +258,19 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             }
         }
 #endif
+#ifdef AMT_LIN_TIMING
+        if (term[0] == 123456.0f && term[NFMAX - 1] == 123456.0f) tacc[7] += 1;
+#endif
+        AMT_LTICK(3);
         __builtin_amdgcn_sched_barrier(0);
-        if (has_next && next_band) load_ab(Bn.y0, av, bv);     // once per band: from memory (the wave sums below cover the trip)
+        if (has_next && next_band) {                           // once per band: from memory (the wave sums below cover the trip)
+#pragma unroll
+            for (int k = 0; k < kMaxUnits; ++k) {
+                const int r = wave + kWaves * k;
+                if (r >= Bn.nrows) break;
+                st.load_ab(rA, rB, Bn.y0 + r, av[k], bmv[k]);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef AMT_LIN_NO_REDUCE
         if (lane == 63) wpart[(cur * kWaves + wave) * NFMAX] = term[0] + term[NFMAX - 1];
@@ -343,19 +283,25 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
             }
         }
 #endif
+        AMT_LTICK(4);
 #ifndef AMT_LIN_NO_STAGE
         if (has_next) {
-            Raw4<pix_t> raw[kStageRows + 2];
-#ifdef AMT_LIN_NO_DMA
-            load_raw(frame_rsrc(ng), Bn.y0, raw);
-#else
-            pickup_raw(Bn.nrows, planes + (cur ^ 1) * plane_cap, raw);
-#endif
-            if (next_band) ab_to_lds(Bn.nrows, av, bv); else ab_from_lds(Bn.nrows, av, bv);
-            convert_store(planes + (cur ^ 1) * plane_cap, Bn.y0, Bn.nrows, raw, av, bv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the LDS-direct loads are counted with the vector-memory loads
+            AMT_LTICK(5);
+            // the band's last evaluation is long done: the next band's pixel and taps travel while the rows are converted
+            if (next_band) load_pixel(Bn);
+#pragma unroll
+            for (int k = 0; k < kMaxUnits; ++k) {
+                const int r = wave + kWaves * k;
+                if (r >= Bn.nrows) break;
+                if (next_band) st.ab_to_lds(abp + r * lp, av[k], bmv[k]); else st.ab_from_lds(abp + r * lp, av[k], bmv[k]);
+                st.convert(planes + (cur ^ 1) * plane_cap + r * lp, Bn.y0 + r, av[k], bmv[k]);
+            }
         }
 #endif
+        AMT_LTICK(6);
         __syncthreads();                         // next plane and this iteration's wave sums complete; current plane consumed
+        AMT_LTICK(7);
         if (next_band) { B.m0 = Bn.m0; B.npix = Bn.npix; B.y0 = Bn.y0; B.nrows = Bn.nrows; ++bi; }
         g = ng;
     }
@@ -368,6 +314,13 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
         accs[(gcount - 1) * nfades + tid] += s;
     }
     __syncthreads();
+#ifdef AMT_LIN_TIMING
+    if (lane == 0 && blockIdx.x == gridDim.x / 6 && (wave == 0 || wave == 3 || wave == 5 || wave == 7)) {      // a workgroup of logo 0 (the deint logo)
+        long long* tb = reinterpret_cast<long long*>(out + (long long)nframes * out_frame_stride);            // host reserves room
+        const int slot = wave == 0 ? 0 : (wave == 3 ? 1 : (wave == 5 ? 2 : 3));
+        for (int k = 0; k < 8; ++k) tb[slot * 8 + k] = tacc[k];
+    }
+#endif
     if (tid < gcount * nfades) {
         const int gg = tid / nfades, f = tid - gg * nfades;
         float r = accs[tid] / L.blackScore;

@@ -127,83 +127,13 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
         // three waves idle and the rest with 4).  A lane stages four adjacent columns (w <= 256); a ragged right edge (w % 4 == 2)
         // is covered by shifting the last lane group left.
         constexpr int kMaxUnits = (kLinBandRows * kPairFPI + kPairEvalWaves - 1) / kPairEvalWaves;      // 4
-        const bool slane = 4 * lane < w;
-        const int sx = min(4 * lane, w - 4);
-        const int nl = (w + 3) >> 2;
         auto frame_rsrc = [&](int g) {
             const int frame = F0 + min(g, gcount - 1);            // the second frame of a ragged last pair repeats the first
             const int srcFrame = frame_map ? frame_map[frame] : frame;
             const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
         };
-        // raw source rows of logo row y: y-1, y, y+1 (clamped) under DeintY's [1 2 1] blend, the row itself for field logos.
-        // LDS-direct request of a unit's raw rows into the plane row they will be converted into (3 * nl * sizeof(sample) * 4 bytes
-        // <= one plane row); collected after the evaluation.  All address arithmetic is wave-uniform (scalar unit): one multiply
-        // per unit, the neighbours by adding the pitch.
-        const int pitchB = pitch * (int)ES;
-        auto request_unit = [&](const __amdgpu_buffer_rsrc_t rS, int y, f2* prow) {
-            if (!slane) return;
-            unsigned* dst = reinterpret_cast<unsigned*>(prow);
-            constexpr int kD = Raw4<pix_t>::kDwordsPerLane;
-            if (L.deint) {
-                const int o1 = y * pitchB;
-                Raw4<pix_t>::request_lds(rS, dst, (unsigned)sx * ES, y > 0 ? o1 - pitchB : o1, nl);
-                Raw4<pix_t>::request_lds(rS, dst + nl * kD, (unsigned)sx * ES, o1, nl);
-                Raw4<pix_t>::request_lds(rS, dst + 2 * nl * kD, (unsigned)sx * ES, y < L.h - 1 ? o1 + pitchB : o1, nl);
-            } else {
-                Raw4<pix_t>::request_lds(rS, dst, (unsigned)sx * ES, y * L.row_step * pitchB, nl);
-            }
-        };
-        // bg = a*s + b*maxv (LogoScan.hpp:247); bmv holds b*maxv, the same two roundings
-        auto convert_unit = [&](f2* prow, int y, const f4& av, const f4& bmv) {
-            if (!slane) return;
-            int sxl = sx;
-            asm volatile("" : "+v"(sxl));      // hoisted LDS addresses would be spilled
-            const unsigned* src = reinterpret_cast<const unsigned*>(prow);
-            f4 sv;
-            if (L.deint && y != 0 && y != L.h - 1) {
-                // byte-wise conversion; the [1 2 1] blend on floats: every intermediate is an integer below 2^24, so
-                // (r0 + 2 r1 + r2 + 2) * 0.25 equals the reference's (float)(int sum) / 4.0f bit for bit (LogoScan.hpp:763-780)
-                Raw4<pix_t> r0, r1, r2;
-                r0.from_lds(src, lane, nl);
-                r1.from_lds(src + nl * Raw4<pix_t>::kDwordsPerLane, lane, nl);
-                r2.from_lds(src + 2 * nl * Raw4<pix_t>::kDwordsPerLane, lane, nl);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sv[k] = (((float)r0.get(k) + 2.0f * (float)r1.get(k)) + ((float)r2.get(k) + 2.0f)) * 0.25f;
-            } else {
-                Raw4<pix_t> r1;
-                r1.from_lds(src + (L.deint ? nl * Raw4<pix_t>::kDwordsPerLane : 0), lane, nl);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sv[k] = (float)r1.get(k);
-            }
-            f2* dst = prow + sxl;
-            reinterpret_cast<f4*>(dst)[0] = f4{sv[0], av[0] * sv[0] + bmv[0], sv[1], av[1] * sv[1] + bmv[1]};
-            reinterpret_cast<f4*>(dst)[1] = f4{sv[2], av[2] * sv[2] + bmv[2], sv[3], av[3] * sv[3] + bmv[3]};
-        };
-        auto load_ab_row = [&](int y, f4& av, f4& bmv) {
-            const int ro = min(y, L.h - 1) * w * 4;
-            av = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rA, (unsigned)sx * 4u, ro, 0));
-            const f4 bv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rB, (unsigned)sx * 4u, ro, 0));
-            bmv = bv * maxv;
-        };
-        // the band's coefficients as {a, b*maxv} pairs in LDS; written during the band's first conversion by the wave that owns the
-        // row's frame-0 unit, read from the second iteration on (a barrier lies in between)
-        auto ab_row_to_lds = [&](int r, const f4& av, const f4& bmv) {
-            if (!slane) return;
-            int sxl = sx;
-            asm volatile("" : "+v"(sxl));
-            f4* d = reinterpret_cast<f4*>(abp + r * lp + sxl);
-            d[0] = f4{av[0], bmv[0], av[1], bmv[1]};
-            d[1] = f4{av[2], bmv[2], av[3], bmv[3]};
-        };
-        auto ab_row_from_lds = [&](int r, f4& av, f4& bmv) {
-            int sxl = sx;
-            asm volatile("" : "+v"(sxl));
-            const f4* d = reinterpret_cast<const f4*>(abp + r * lp + min(sxl, lp - 4));
-            const f4 lo = d[0], hi = d[1];
-            av = f4{lo[0], lo[2], hi[0], hi[2]};
-            bmv = f4{lo[1], lo[3], hi[1], hi[3]};
-        };
+        const RowStager<pix_t> st(L, lane, pitch, maxv);
         // this thread's mask pixel of a band: window offset, table index, taps
         auto load_pixel = [&](const EvalBand& Bd, bool& act_, int& woff_, unsigned& m8_, f2 (&K)[13]) {
             act_ = tid < Bd.npix;
@@ -231,12 +161,12 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
                 if (u >= U) break;
                 const int fr = u >= B.nrows ? 1 : 0, r = u - fr * B.nrows;
                 f2* prow = planes + fr * plane_cap + r * lp;
-                request_unit(frame_rsrc(fr), B.y0 + r, prow);
+                st.request(frame_rsrc(fr), B.y0 + r, prow);
                 f4 av, bmv;
-                load_ab_row(B.y0 + r, av, bmv);
+                st.load_ab(rA, rB, B.y0 + r, av, bmv);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (fr == 0) ab_row_to_lds(r, av, bmv);
-                convert_unit(prow, B.y0 + r, av, bmv);
+                if (fr == 0) st.ab_to_lds(abp + r * lp, av, bmv);
+                st.convert(prow, B.y0 + r, av, bmv);
             }
         }
         __syncthreads();
@@ -268,7 +198,7 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
                     const int u = wave + kPairEvalWaves * k;
                     if (u >= Un) break;
                     const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
-                    request_unit(fr ? rs1 : rs0, Bn.y0 + r, nplane + fr * plane_cap + r * lp);
+                    st.request(fr ? rs1 : rs0, Bn.y0 + r, nplane + fr * plane_cap + r * lp);
                 }
             }
             AMT_PTICK(1);
@@ -326,7 +256,7 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
                         const int u = wave + kPairEvalWaves * k;
                         if (u >= Un) break;
                         const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
-                        load_ab_row(Bn.y0 + r, av[k], bmv[k]);           // once per band, from memory
+                        st.load_ab(rA, rB, Bn.y0 + r, av[k], bmv[k]);     // once per band, from memory
                     }
                     // the band's last evaluation is done: the next band's pixel and taps (14 loads, issued after everything the
                     // conversion needs) travel while the rows are converted
@@ -344,9 +274,9 @@ void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoD
                     const int u = wave + kPairEvalWaves * k;
                     if (u >= Un) break;
                     const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
-                    if (next_band) { if (fr == 0) ab_row_to_lds(r, av[k], bmv[k]); }
-                    else ab_row_from_lds(r, av[k], bmv[k]);
-                    convert_unit(nplane + fr * plane_cap + r * lp, Bn.y0 + r, av[k], bmv[k]);
+                    if (next_band) { if (fr == 0) st.ab_to_lds(abp + r * lp, av[k], bmv[k]); }
+                    else st.ab_from_lds(abp + r * lp, av[k], bmv[k]);
+                    st.convert(nplane + fr * plane_cap + r * lp, Bn.y0 + r, av[k], bmv[k]);
                 }
             }
             AMT_PTICK(5);

@@ -16,10 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")
 ap.add_argument("--what", default="analyze")
 ap.add_argument("--frames", type=int, default=2048)
+ap.add_argument("--mode", default="exact", help="analysis mode: exact | linear_unguarded")
 a = ap.parse_args()
 if a.build:
     from amatsukaze_amd import build as b
-    print(b.build_variant("timing", ["AMT_FUSED_TIMING", "AMT_PAIR_TIMING"]))
+    print(b.build_variant("timing", ["AMT_FUSED_TIMING", "AMT_PAIR_TIMING", "AMT_LIN_TIMING"]))
     sys.exit(0)
 
 import torch
@@ -46,7 +47,7 @@ if a.what == "scan":
     t = r.view(np.int64).reshape(4, 8)
 else:
     out = torch.zeros((a.frames + 8, 33), dtype=torch.float32, device=dev)     # the kernel dumps its counters past the results
-    an = AMTAnalyzeLogo(ctx, logo, 0.35)
+    an = AMTAnalyzeLogo(ctx, logo, 0.35, mode=a.mode)
     for _ in range(2):
         an.analyze_device(dclip.Y[: a.frames], 8, out)
     torch.cuda.synchronize()
@@ -58,6 +59,15 @@ if a.what == "scan":
     print("pair kernel: cycles (s_memtime ticks) of the middle workgroup; waves 0, 3, 7 evaluate, wave 8 sums:")
     for k in range(7):
         print(f"  {pn[k]:36s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
+    print("  total                                " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
+    sys.exit(0)
+if a.what != "scan" and a.mode != "exact":
+    ln = ["band start (pixel, taps)", "request raw rows (LDS-direct)", "fold sums, window evaluation", "fades (gathers, terms, fix-up)",
+          "coefficients, DPP wave sums", "wait for / pick up the raw rows", "convert -> {s,bg}", "wait at the barrier"]
+    tot = t.sum(1)
+    print("linear kernel: cycles (s_memtime ticks) of a workgroup of the deint logo; waves 0, 3, 5, 7:")
+    for k in range(8):
+        print(f"  {ln[k]:36s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
     print("  total                                " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
     sys.exit(0)
 names = ["band prologue (slot, taps)", "staging loads+LDS writes", "ordered sum (one wave)", "wait B1", "window reads", "fade loop",
