@@ -41,7 +41,20 @@ struct AmtGpuErase {
     int mode = 0, maxFade = 16;
     bool zeroIdentity = false;      // every a*s + b*maxv of this logo is finite: Delogo with fade 0 returns the frame unchanged
     DevBuf<float> dPlanes;
-    DevBuf<float2> dFades;
+    // the caller's fades go through two pinned slots (each with its own device copy and event), so that a batch returns without
+    // waiting for the stream: a slot is rewritten only after the upload that read it has completed
+    float2* hFades[2] = {nullptr, nullptr};
+    size_t fadesCap[2] = {0, 0};
+    DevBuf<float2> dFades[2];
+    hipEvent_t fadesUploaded[2] = {nullptr, nullptr};
+    int fadeSlot = 0;
+    ~AmtGpuErase()
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (hFades[i]) (void)hipHostFree(hFades[i]);
+            if (fadesUploaded[i]) (void)hipEventDestroy(fadesUploaded[i]);
+        }
+    }
 };
 
 static AmtGpuErase* erase_new(AmtGpuContext* c, LogoPlanes logo, const std::string& logofText, bool haveLogof, int mode, int maxfade)
@@ -122,8 +135,20 @@ static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t 
     if (strideY % es || strideUV % es) throw std::runtime_error("frame stride not a multiple of the sample size");
     if (rect_only && (pitchY < P.w || pitchUV < P.wUV())) throw std::runtime_error("[AMTEraseLogo] rectangle pitch smaller than the logo width");
     er->ctx->bind();
-    if (er->dFades.size() < (size_t)nframes) er->dFades.alloc(nframes);
-    AMT_HIP(hipMemcpyAsync(er->dFades.get(), fades, (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
+    const int slot = er->fadeSlot;
+    er->fadeSlot ^= 1;
+    if (!er->fadesUploaded[slot]) AMT_HIP(hipEventCreateWithFlags(&er->fadesUploaded[slot], hipEventDisableTiming));
+    else AMT_HIP(hipEventSynchronize(er->fadesUploaded[slot]));          // the upload two batches ago
+    if (er->fadesCap[slot] < (size_t)nframes) {
+        if (er->hFades[slot]) AMT_HIP(hipHostFree(er->hFades[slot]));
+        er->hFades[slot] = nullptr;
+        AMT_HIP(hipHostMalloc((void**)&er->hFades[slot], (size_t)nframes * sizeof(float2), hipHostMallocDefault));
+        er->fadesCap[slot] = (size_t)nframes;
+        er->dFades[slot].alloc(nframes);                                   // hipFree waits for the kernels that read the old copy
+    }
+    std::memcpy(er->hFades[slot], fades, (size_t)nframes * sizeof(float2));
+    AMT_HIP(hipMemcpyAsync(er->dFades[slot].get(), er->hFades[slot], (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
+    AMT_HIP(hipEventRecord(er->fadesUploaded[slot], er->ctx->stream));
     EraseGeom g;
     g.w = P.w; g.h = P.h; g.wUV = P.wUV(); g.hUV = P.hUV();
     // rectangle-only planes start at the logo's top-left sample; the chroma row parity is a property of the logo's position in
@@ -133,10 +158,8 @@ static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t 
     g.uvparity = (P.imgy / 2) % 2;
     const int sp = er->ctx->prof_begin("delogo_kernel");
     AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
-                          nframes, er->dFades.get(), er->zeroIdentity ? 1 : 0));
+                          nframes, er->dFades[slot].get(), er->zeroIdentity ? 1 : 0));
     er->ctx->prof_end(sp);
-    // the fades came from pageable host memory: make sure the copy has been consumed before returning
-    AMT_HIP(hipStreamSynchronize(er->ctx->stream));
 }
 
 int amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY,
