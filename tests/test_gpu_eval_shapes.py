@@ -112,6 +112,34 @@ def test_scan_in_ragged_batches_bit_exact(gpu, group, bits):
     assert got.reshape(-1).tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("bits", [8, 10])
+@pytest.mark.parametrize("shape,maskratio", [("w98_ragged", 0.35), ("origin_mod4_2", 0.35), ("tall_narrow", 0.35), ("w322_two_groups", 0.35),
+                                             ("w98_ragged", 1.0), ("origin_mod4_2", 0.02)])
+def test_scan_shapes_bit_exact(gpu, shape, maskratio, bits):
+    """LogoFrame scan on the shapes the pair kernel's staging special-cases (ragged last lane group, rectangle origins that are
+    even but not 4-byte aligned, bands of many short rows, dense and sparse masks); the 322-wide logo is outside its one column
+    group and runs on the generic kernel.  Records are the oracle's bytes either way."""
+    import ctypes as C
+    from amatsukaze_amd import LogoFrame
+    W, H, LW, LH, X, Y0, N = SHAPES[shape]
+    cfg = dict(W=W, H=H, LW=LW, LH=LH, IMGX=X, IMGY=Y0, N=N, period=4, fade=2, flat=3)
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=32)
+    ctx = gpu["ctx"]
+    lf = LogoFrame(ctx, [cs["logo"]], maskratio)
+    ctx.profile(True)
+    lf.scanFrames(cs["dclip"])
+    got = lf.evalResults
+    used = [k for k, (calls, _) in ctx.profile_report().items() if calls]
+    ctx.profile(False)
+    assert used == ["logo_eval_fused_kernel.scan" if LW > 256 else "logo_eval_pair_kernel.scan"], used
+    orc = cs["orc"]
+    d = orc.lib.orc_logo_deint(cs["lo"]); orc.lib.orc_logo_create_mask(d, maskratio, 1)
+    Y = cs["clip"]["Y"]
+    want = np.zeros(N * 2, np.float32)
+    orc.lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], Y.shape[2], bits, W, H, N, _ptr(want))
+    assert got.reshape(-1).tobytes() == want.tobytes()
+
+
 def test_widest_supported_logo_and_too_wide(gpu):
     """A band must hold the 5 rows of a window in its LDS plane (3072 floats): 576 columns is the widest logo that fits (row
     pitch 584, one mask row per band, three 256-column staging groups); wider logos are refused, not mis-evaluated."""
