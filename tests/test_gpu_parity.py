@@ -464,3 +464,49 @@ def test_analyze_linear_guarded_mode(gpu, cfgname, bits):
     exact = AMTAnalyzeLogo(ctx, cs["logo"], 0.35).analyze(cs["dclip"])
     assert exact.tobytes() == want.tobytes()
     print(f"linear mode {cfgname}/{bits}: max err {err.max():.2e}, bounds {bounds}, refined {refined}/{n}")
+
+
+def test_one_context_shared_by_two_host_threads(gpu):
+    """AviSynth's MT_NICE_FILTER runs GetFrame of filter instances that share one context on several threads
+    (include/amt_filters.hpp); the context serialises them (engine.hpp: the lock taken by every entry point).  Two threads hammer
+    the pinned upload ring, the analysis and the scan of one context at once (ctypes releases the GIL during the calls); every
+    result must equal the single-threaded one."""
+    import ctypes as C
+    import threading
+    from amatsukaze_amd import AMTAnalyzeLogo, LogoFrame
+    torch = gpu["torch"]
+    ctx, lib = gpu["ctx"], gpu["ctx"].lib
+    cs = make_case(gpu, SMALL)
+    an = AMTAnalyzeLogo(ctx, cs["logo"], 0.35)
+    want_an = an.analyze(cs["dclip"]).copy()
+    lf = LogoFrame(ctx, [cs["logo"]], 0.35)
+    lf.scanFrames(cs["dclip"])
+    want_scan = lf.evalResults.copy()
+    rng = np.random.default_rng(7)
+    host = [rng.integers(0, 256, 3 << 20, dtype=np.uint8) for _ in range(2)]      # 3 MB each: several ring slots per upload
+    errors = []
+
+    def worker(k):
+        try:
+            dev = torch.zeros(host[k].size, dtype=torch.uint8, device=gpu["dev"])
+            mine_an = AMTAnalyzeLogo(ctx, cs["logo"], 0.35) if k else an
+            mine_lf = LogoFrame(ctx, [cs["logo"]], 0.35)
+            for it in range(6):
+                ctx.check(lib.amtgpu_frames_upload(ctx.h, C.c_void_p(dev.data_ptr()), C.c_void_p(host[k].ctypes.data), host[k].size))
+                ctx.check(lib.amtgpu_frames_upload_wait(ctx.h))
+                got = mine_an.analyze(cs["dclip"])
+                mine_lf.scanFrames(cs["dclip"])
+                ctx.synchronize()
+                if got.tobytes() != want_an.tobytes() or mine_lf.evalResults.tobytes() != want_scan.tobytes():
+                    errors.append((k, it, "records differ"))
+                if not np.array_equal(dev.cpu().numpy(), host[k]):
+                    errors.append((k, it, "uploaded bytes differ"))
+        except Exception as e:      # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
