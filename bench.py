@@ -319,11 +319,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # AMT_BENCH_SHARED_GPU=1: every rank on device 0, collectives over gloo -- a dry run of the multi-rank control flow on a 1-GPU box
+    # (tests the launcher, the sharding and the exchange steps; its numbers mean nothing)
+    shared_gpu = os.environ.get("AMT_BENCH_SHARED_GPU") == "1"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if torch.cuda.device_count() < world:
-            raise SystemExit(f"--gpus {world}: only {torch.cuda.device_count()} HIP devices visible (one rank per GPU)")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"--gpus {world}: only {torch.cuda.device_count()} HIP devices visible (one rank per GPU)")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -114,3 +114,28 @@ def test_sharded_hip_path_world2(tmp_path):
         assert r["logoframe_equal"] and r["best"] == int(G.load()["logoframe_best"])
         assert r["fades_equal"] and r["erase_equal"]
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_multi_rank_control_flow_dry_run():
+    """`bench.py --gpus 2` on whatever box runs this: the launcher re-executes itself under torch.distributed.run, the ranks shard
+    the work and exchange their records.  On a 1-GPU box the ranks share device 0 and talk over gloo (AMT_BENCH_SHARED_GPU=1: a
+    dry run of the control flow, its numbers mean nothing); with >= 2 devices it is a real RCCL run."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env["AMT_BENCH_SHARED_GPU"] = "1"
+    common = ["--gpus", "2", "--strong-frames", "4096", "--strong-steps", "2"]
+    for extra, scaling in ((["--steps", "2", "--warmup", "1", "--frames", "512", "--no-ingest", "--cpu-frames", "0", "--no-alt-mode"], "weak"),
+                           (["--scaling", "strong"], "strong")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
+        ss = line["strong_scan"]
+        assert ss["n_gpus"] == 2 and ss["verified"]["sharded_equals_single_launch"] and ss["verified"]["equals_cpu_oracle"]
+        if scaling == "weak":
+            assert line["verified"]["ok"]
