@@ -81,6 +81,8 @@ SIGNATURES = {
     "amtgpu_erase_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_erase_rect_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_erase_get_rect": (c_i, [c_p, c_p]),
+    "amtgpu_analyze_get_rect": (c_i, [c_p, c_p]),
+    "amtgpu_logoframe_get_rows": (c_i, [c_p, c_p]),
     "amtgpu_logoscan_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
     "amtgpu_logoscan_destroy": (None, [c_p]),
     "amtgpu_logoscan_add_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),

@@ -379,6 +379,17 @@ static void logoframe_sync_results(AmtGpuLogoFrame* lf)
     lf->hostValid = true;
 }
 
+int amtgpu_logoframe_get_rows(const AmtGpuLogoFrame* lf, int* out2)
+{
+    if (!lf || !out2) return 0;
+    int lo = 0x7FFFFFFF, hi = 0;
+    for (const auto& l : lf->logos)
+        if (l) { lo = std::min(lo, l->imgy); hi = std::max(hi, l->imgy + l->h); }
+    if (lo >= hi) { lo = 0; hi = 0; }
+    out2[0] = lo; out2[1] = hi;
+    return 1;
+}
+
 int amtgpu_logoframe_get_results(AmtGpuLogoFrame* lf, float* out)
 {
     return guard(lf->ctx, [&] {
@@ -569,6 +580,13 @@ int amtgpu_analyze_last_refined(AmtGpuAnalyze* an)
         AMT_HIP(hipStreamSynchronize(an->ctx->stream));
     });
     return n;
+}
+
+int amtgpu_analyze_get_rect(const AmtGpuAnalyze* an, int* out4)
+{
+    if (!an || !out4) return 0;
+    out4[0] = an->logo.imgx; out4[1] = an->logo.imgy; out4[2] = an->logo.w; out4[3] = an->logo.h;
+    return 1;
 }
 
 float amtgpu_analyze_error_bound(AmtGpuAnalyze* an, int group, int bits)

@@ -103,6 +103,7 @@ class AMTAnalyzeLogo : public GenericVideoFilter {
     std::mutex mu_;
     int cache_first_ = -1;
     std::vector<float> cache_;                    /* [block_][8][33] */
+    int row0_ = 0, row1_ = 0;                     /* Y rows the analysis reads: the logo rectangle's */
 
     void fill(int first, IScriptEnvironment* env)
     {
@@ -121,7 +122,10 @@ class AMTAnalyzeLogo : public GenericVideoFilter {
             } else if (f->GetPitch(PLANAR_Y) != pitch) {
                 env->ThrowError("[AMTAnalyzeLogo] frames of one clip must share a pitch");
             }
-            if (!amtgpu_frames_upload(ctx_->get(), dY_.at(plane * k), f->GetReadPtr(PLANAR_Y), plane))
+            /* only the rows of the logo rectangle travel, to their place in the device frame: the analysis reads nothing else
+             * (LogoScan.hpp:1132-1141) -- h * pitch bytes per frame instead of the whole plane */
+            const uint64_t off = (uint64_t)row0_ * pitch;
+            if (!amtgpu_frames_upload(ctx_->get(), dY_.at(plane * k + off), f->GetReadPtr(PLANAR_Y) + off, (uint64_t)(row1_ - row0_) * pitch))
                 env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
         }
         if (!amtgpu_frames_upload_wait(ctx_->get())) env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
@@ -139,6 +143,10 @@ public:
     {
         an_ = amtgpu_analyze_create(ctx_->get(), logoPath.c_str(), maskratio);
         if (!an_) env->ThrowError("Failed to read logo file (%s)", logoPath.c_str());          /* LogoScan.hpp:1174 */
+        int rc[4] = {0, 0, 0, 0};
+        if (!amtgpu_analyze_get_rect(an_, rc)) env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
+        row0_ = std::max(0, std::min(srcvi_.height, rc[1]));
+        row1_ = std::max(row0_, std::min(srcvi_.height, rc[1] + rc[3]));
         const int out_bytes = (int)sizeof(float) * AMTGPU_ANALYZE_FLOATS * 8;                  /* sizeof(LogoAnalyzeFrame) * 8 */
         vi.pixel_type = VideoInfo::CS_BGR32;
         vi.width = 64;
@@ -284,6 +292,9 @@ public:
         check(amtgpu_logoframe_begin(lf_, vi.width, vi.height, vi.BitsPerComponent(), vi.num_frames, (int)vi.fps_numerator,
                                      (int)vi.fps_denominator));
         DeviceBuffer dY(ctx_);
+        int rows[2] = {0, 0};
+        check(amtgpu_logoframe_get_rows(lf_, rows));
+        const int r0 = std::max(0, std::min(vi.height, rows[0])), r1 = std::max(r0, std::min(vi.height, rows[1]));
         for (int n0 = 0; n0 < vi.num_frames; n0 += framesPerLaunch_) {
             const int nb = std::min(framesPerLaunch_, vi.num_frames - n0);
             uint64_t plane = 0;
@@ -297,7 +308,9 @@ public:
                 } else if (f->GetPitch(PLANAR_Y) != pitch) {
                     throw std::runtime_error("[LogoFrame] frames of one clip must share a pitch");
                 }
-                check(amtgpu_frames_upload(ctx_->get(), dY.at(plane * i), f->GetReadPtr(PLANAR_Y), plane));
+                /* only the rows some logo's rectangle covers travel (to their place in the device frame) */
+                const uint64_t off = (uint64_t)r0 * pitch;
+                check(amtgpu_frames_upload(ctx_->get(), dY.at(plane * i + off), f->GetReadPtr(PLANAR_Y) + off, (uint64_t)(r1 - r0) * pitch));
             }
             check(amtgpu_frames_upload_wait(ctx_->get()));
             check(amtgpu_logoframe_scan_batch(lf_, dY.at(0), (int64_t)plane, pitch / es, n0, nb));

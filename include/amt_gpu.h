@@ -145,6 +145,8 @@ int  amtgpu_logoframe_begin(AmtGpuLogoFrame* lf, int width, int height, int bits
 /* scan frames [first, first+nframes) of the clip from a device batch (Y plane only).  async */
 int  amtgpu_logoframe_scan_batch(AmtGpuLogoFrame* lf, const void* dY, int64_t frame_stride, int pitch, int first, int nframes);
 /* results: num_frames*nlogos*{corr0,corr1} (EvalResult, LogoScan.hpp:1532-1535) */
+/* out2 = {first row, one past the last row} of the Y plane that the scan of these logos reads (the union of their rectangles) */
+int  amtgpu_logoframe_get_rows(const AmtGpuLogoFrame* lf, int* out2);
 int  amtgpu_logoframe_get_results(AmtGpuLogoFrame* lf, float* out);
 /* sharded scans: install results computed elsewhere (other ranks) for frames [first, first+nframes) */
 int  amtgpu_logoframe_set_results(AmtGpuLogoFrame* lf, int first, int nframes, const float* evals);
@@ -162,6 +164,9 @@ void amtgpu_analyze_destroy(AmtGpuAnalyze* an);
 /* dout: device buffer of nframes*33 floats.  async */
 int  amtgpu_analyze_batch(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* dout);
 /* convenience: same, results copied to host (synchronises) */
+/* out4 = {imgx, imgy, w, h}: the rectangle the analysis reads (LogoScan.hpp:1132-1141) -- a host that uploads frames may ship only
+ * the rows [imgy, imgy+h) of every Y plane, at their place in the frame: nothing else is read */
+int  amtgpu_analyze_get_rect(const AmtGpuAnalyze* an, int* out4);
 int  amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride, int pitch, int bits, int nframes, float* hout);
 
 /* Evaluation mode of the 33 scores per frame.
