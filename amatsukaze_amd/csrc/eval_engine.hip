@@ -321,6 +321,10 @@ float EvalEngine::linear_error_bound(int logo, int bits) const
 void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout, const int* dframe_map)
 {
     if (nframes <= 0 || specs_.empty()) return;
+    // a logo without mask pixels (maskratio 0) has no bands for the one-pixel-per-thread kernels to walk: the generic kernel
+    // handles it (its results are 0 / blackScore = 0 / 0, as the reference's)
+    for (const EvalLogoSpec& S : specs_)
+        if (S.tables.count <= 0) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }
     ensure_linear();
     ctx_->bind();
     const int es = bits <= 8 ? 1 : 2;

@@ -140,6 +140,28 @@ def test_scan_shapes_bit_exact(gpu, shape, maskratio, bits):
     assert got.reshape(-1).tobytes() == want.tobytes()
 
 
+def test_logo_without_mask_pixels(gpu):
+    """maskratio 0 selects no mask pixel: every score is 0 / blackScore = 0 / 0.  The one-pixel-per-thread kernels (linear analysis,
+    pair scan) have no band to walk and hand such logos to the generic kernel; nothing faults and the records are NaN like the
+    oracle's."""
+    import ctypes as C
+    from amatsukaze_amd import AMTAnalyzeLogo, LogoFrame
+    cfg = dict(W=352, H=240, LW=96, LH=48, IMGX=224, IMGY=18, N=5, period=4, fade=2, flat=3)
+    cs = make_case(gpu, cfg)
+    orc = cs["orc"]
+    d = orc.lib.orc_logo_deint(cs["lo"]); orc.lib.orc_logo_create_mask(d, 0.0, 1)
+    Y = cs["clip"]["Y"]
+    want = np.zeros(cfg["N"] * 2, np.float32)
+    orc.lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["W"], cfg["H"], cfg["N"], _ptr(want))
+    assert np.isnan(want).all()
+    lf = LogoFrame(gpu["ctx"], [cs["logo"]], 0.0)
+    lf.scanFrames(cs["dclip"])
+    assert np.isnan(lf.evalResults).all()
+    for mode in ("exact", "linear"):
+        got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.0, mode=mode).analyze(cs["dclip"])
+        assert got.shape == (cfg["N"], 33) and np.isnan(got).all()
+
+
 def test_widest_supported_logo_and_too_wide(gpu):
     """A band must hold the 5 rows of a window in its LDS plane (3072 floats): 576 columns is the widest logo that fits (row
     pitch 584, one mask row per band, three 256-column staging groups); wider logos are refused, not mis-evaluated."""
