@@ -75,3 +75,35 @@ def test_cadence_and_scene_decisions(gpu, tmp_path):
     d = [int(x) for x in path.read_text().split()]
     assert d == FS.cadence_durations(cad, ph) and sum(d) == 2 * len(cad) and len(d) == n_out.value
     assert d.count(3) > 10
+
+
+def test_config3_frame_size_cadence_segments(gpu):
+    """BASELINE configs[2]'s shape (1920x1080 8-bit, 24p / 30i / 30p segments) generated on the device, 600 frames per segment:
+    metrics of probe blocks equal the numpy oracle's bytes at the full frame size and the host decisions equal the oracle's on the
+    whole clip's metrics."""
+    import amt_synth as S
+    from amatsukaze_amd import DeviceClip, FrameStats
+    torch = gpu["torch"]
+    W, H, SEG = 1920, 1080, 600
+    parts, start = [], 0
+    for cad in ("24p", "30i", "30p"):
+        parts.append(S.make_clip_torch(SEG, W, H, 0x5EED0003, None, None, 0, 0, gpu["dev"], cadence=cad, start=start, chroma=False)["Y"])
+        start += SEG
+    Y = torch.cat(parts)
+    del parts
+    N = Y.shape[0]
+    fs = FrameStats(gpu["ctx"], W, H, 8)
+    out = torch.zeros((N, 8), dtype=torch.int64, device=gpu["dev"])
+    fs.run_device(Y, out)
+    gpu["ctx"].synchronize()
+    m = out.cpu().numpy().astype(np.uint64)
+    for b0 in (0, SEG - 12, 2 * SEG - 12, N - 24):            # clip start, both cadence changes, clip end
+        blk = Y[max(0, b0 - 1):b0 + 24].cpu().numpy()
+        want = FS.frame_metrics(blk)
+        assert np.array_equal(m[b0:b0 + 24], want[(1 if b0 > 0 else 0):]), b0
+    cad, ph = fs.cadence(m)
+    ocad, oph = FS.classify_cadence(m, W, H)
+    assert np.array_equal(cad, ocad) and np.array_equal(ph, oph)
+    assert fs.scene_changes(m).tolist() == FS.scene_changes(m, W, H)
+    # (what the classifier makes of this generator's heavy per-field noise is not the point here: test_cadence_and_scene_decisions
+    #  checks the classes themselves on the gentler numpy clip)
