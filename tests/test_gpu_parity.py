@@ -382,6 +382,18 @@ def test_empty_and_error_paths(gpu):
     with pytest.raises(AmtError):
         lf.begin(SMALL["W"], SMALL["H"], 8, 4)
         lf.scan_batch(cs["dclip"].Y, 8, 2)                  # range outside the declared clip
+    # zero frames through the other passes: nothing is launched, nothing faults
+    from amatsukaze_amd import AMTEraseLogo, FrameStats, LogoScan
+    for mode in ("exact", "linear"):
+        assert AMTAnalyzeLogo(ctx, cs["logo"], 0.35, mode=mode).analyze(empty).shape == (0, 33)
+    er = AMTEraseLogo(ctx, cs["logo"])
+    assert er.calc_fades(np.zeros((0, 33), np.float32), 0).shape == (0, 2)
+    er.erase(empty, np.zeros((0, 2), np.float32))
+    assert FrameStats(ctx, SMALL["W"], SMALL["H"], 8).run(empty).shape == (0, 8)
+    scan = LogoScan(ctx, SMALL["LW"], SMALL["LH"], 12)
+    valid, nacc = scan.add_batch(empty, SMALL["IMGX"], SMALL["IMGY"])
+    assert len(valid) == 0 and nacc == 0 and scan.nframes == 0
+    ctx.synchronize()
 
 
 def test_score_bin_edge_means(gpu):
@@ -405,6 +417,13 @@ def test_score_bin_edge_means(gpu):
         want = np.zeros(cfg["N"] * 33, np.float32)
         orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["N"], _ptr(want))
         assert got.reshape(-1).tobytes() == want.tobytes(), (scale_a, scale_b)
+        # the scan's two fades on the same logo (pair kernel while the coefficients stay below 1e30, generic kernel beyond)
+        from amatsukaze_amd import LogoFrame
+        lf = LogoFrame(gpu["ctx"], [logo], 0.35)
+        lf.scanFrames(cs["dclip"])
+        want2 = np.zeros(cfg["N"] * 2, np.float32)
+        orc.lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], Y.shape[2], 8, cfg["W"], cfg["H"], cfg["N"], _ptr(want2))
+        assert lf.evalResults.reshape(-1).tobytes() == want2.tobytes(), (scale_a, scale_b)
 
 
 def test_experiment_environment_variables_are_ignored(gpu, monkeypatch):
