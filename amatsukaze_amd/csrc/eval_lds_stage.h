@@ -43,7 +43,6 @@ template <> struct Raw4<uint8_t> {
         typedef unsigned __attribute__((aligned(1))) ua_t;
         v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
     }
-    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
     // buffer_load ... lds: the four samples go straight to LDS (lane l to dst[l]), no register is held while they travel
     static __device__ __forceinline__ void request_lds(__amdgpu_buffer_rsrc_t r, unsigned* dst, unsigned voff, int soff, int)
     {
@@ -60,7 +59,6 @@ template <> struct Raw4<uint16_t> {
         typedef u2 __attribute__((aligned(2))) ua_t;
         v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
     }
-    __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { v = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
     static __device__ __forceinline__ void request_lds(__amdgpu_buffer_rsrc_t r, unsigned* dst, unsigned voff, int soff, int nl)
     {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 4, voff, soff, 0, 0);
@@ -72,9 +70,6 @@ template <> struct Raw4<uint16_t> {
 };
 
 constexpr int kWaves = kLinThreads / 64;
-constexpr int kStageRows = 2;                  // rows a wave stages per trip
-constexpr int kPartPitch = kLinThreads + 4;    // one LDS row of per-pixel terms per fade
-constexpr int kGatherChunk = 6;                // fades whose scale gathers are in flight together
 
 // the 5x5 window of one pixel, element (r, c) at W[r*5+c] = {s, bg}
 __device__ __forceinline__ void load_window(const f2* plane, int woff, int lp, f2 (&W)[25])
@@ -106,13 +101,6 @@ __device__ __forceinline__ f2 window_corr(const f2 (&Kp)[13], const f2 (&W)[25],
     }
     return __builtin_elementwise_fma(-bc_hi(Kp[12]), M, acc0 + acc1);
 }
-// is v within delta of a bin edge that matters: multiples of 8 in [8, 248] ((int)avg clamped to 0..255, >> 3)
-__device__ __forceinline__ bool near_bin_edge(float v, float delta)
-{
-    const float t = v * 0.125f;
-    const float e = __builtin_rintf(t);
-    return fabsf(t - e) * 8.0f < delta && e >= 1.0f && e <= 31.0f;
-}
 // mean of the blended window exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it (LogoScan.hpp:244-251)
 __device__ __forceinline__ float exact_blend_mean(const f2* plane, int woff, int lp, float fade, float omf)
 {
@@ -128,18 +116,6 @@ __device__ __forceinline__ float exact_blend_mean(const f2* plane, int woff, int
         c[i] = ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
     }
     return div25(hsum5(c[0], c[1], c[2], c[3], c[4]));
-}
-
-// a*s + b*maxv for the four pixels a lane stages, given s; LDS layout {s0,bg0,s1,bg1} {s2,bg2,s3,bg3}
-__device__ __forceinline__ void store_pairs(f2* dst, const f4& sv, const f4& av, const f4& bv, float maxv)
-{
-    f4 lo, hi;
-    lo[0] = sv[0]; lo[1] = unblend_bg(av[0], bv[0], maxv, sv[0]);
-    lo[2] = sv[1]; lo[3] = unblend_bg(av[1], bv[1], maxv, sv[1]);
-    hi[0] = sv[2]; hi[1] = unblend_bg(av[2], bv[2], maxv, sv[2]);
-    hi[2] = sv[3]; hi[3] = unblend_bg(av[3], bv[3], maxv, sv[3]);
-    reinterpret_cast<f4*>(dst)[0] = lo;
-    reinterpret_cast<f4*>(dst)[1] = hi;
 }
 
 // Staging of ONE row of an evaluation logo's band for one frame ("unit"), shared by the pair and the linear kernel.  A lane stages
