@@ -16,7 +16,7 @@
 // the rows their windows touch); thread = ONE mask pixel.  LDS holds the band's rows as interleaved {s, bg} pairs, so a
 // window element arrives as one 8-byte read with s in the low and bg in the high half: the window mean and the correlation
 // of BOTH operands are computed by the same packed fp32 instructions (v_pk_*_f32, the 25 taps broadcast to both halves).
-// No ordered sum: per-pixel terms go through an LDS row per fade and a fixed-order tree -- deterministic.
+// No ordered sum: per-pixel terms are summed per wave with DPP adds and the eight wave sums in a fixed order -- deterministic.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>
@@ -26,7 +26,6 @@
 #include "eval_lds_stage.h"
 
 namespace amt {
-
 
 using namespace lin;
 
@@ -45,8 +44,8 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
 // NF > 0: exactly NF fades (11 for AMTAnalyzeLogo: no per-fade branches); NF == 0: nfades <= kLinMaxFades at run time.
 //
 // Software pipeline over the (band, frame) iterations of a workgroup, ONE barrier per iteration: the raw rows of the NEXT
-// iteration are requested before the current window evaluation (4 registers in flight), its logo coefficients after it, and
-// both are converted into the other half of a double-buffered LDS plane after the fade code -- the global-memory latency of
+// iteration are requested before the current window evaluation (buffer_load ... lds: no registers in flight) straight into the
+// other half of a double-buffered LDS plane and converted there, in place, after the fade code -- the global-memory latency of
 // staging sits behind the arithmetic instead of in front of a barrier.
 template <typename pix_t, int NF>
 __global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
