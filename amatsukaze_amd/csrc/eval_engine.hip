@@ -334,7 +334,7 @@ void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitc
     // the interpolated mean is within 19 u v of the exactly evaluated one (7 + 7 roundings of the two means, 3 to combine them, 9 on
     // the exact side... see ensure_linear); a 32 u v window decides when the exact mean is computed for the bin
     const float bin_delta = 32.0f / 16777216.0f * vmax_unit_ * (float)((1 << bits) - 1);
-    int G = (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
+    int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
     for (int f0 = 0; f0 < nf_all; f0 += kLinMaxFades) {
         const int nf = std::min(kLinMaxFades, nf_all - f0);
         G = std::max(1, std::min(G, kLinThreads / nf));
