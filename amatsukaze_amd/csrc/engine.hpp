@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "eval_plan.h"
+#include "eval_tiles.hpp"
 #include "logo_model.hpp"
 
 #define AMT_HIP(expr)                                                                              \
@@ -74,6 +75,16 @@ public:
     size_t size() const { return n_; }
 };
 
+// tile plan of one evaluation logo resident in HBM (eval_tiles.hpp; eval_pair_kernels.hip).  slot = (band * 8 + wave) * 64 + lane
+struct TileLogoDev {
+    const float2* kp;            // [13][nslots]  taps of the slot's mask pixel as pairs {k[2j], k[2j+1]} (k[25] = 0), pair-major
+    const float2* sc;            // [32][nslots]  bin-major {scale, scale2} of the slot's mask pixel
+    const uint32_t* sinfo;       // [nslots]      tile_slot_info
+    const TileDesc* tiles;       // [nbands * 8]
+    const TileBandDesc* bands;   // [nbands]
+    int nbands, nslots;
+};
+
 // one evaluation logo + where its source pixels come from
 struct EvalLogoSpec {
     LogoPlanes planes;       // evaluation logo (deinterlaced, or one field)
@@ -129,7 +140,16 @@ private:
     DevBuf<float> d_fades_;
     // fades {0, 1} (the LogoFrame scan): both evaluations as one packed instruction stream (eval_pair_kernels.hip); decided once
     bool pair_eligible();
+    bool pair_addressable(int pitch_bytes) const;
     int pair_state_ = -1;                          // -1 undecided, 0 generic kernel, 1 pair kernel
+    // tile plans (eval_tiles.hpp), built when the pair kernel is chosen
+    void ensure_tiles();
+    bool tiles_ready_ = false;
+    std::vector<DevBuf<float2>> d_tkp_, d_tsc_;
+    std::vector<DevBuf<uint32_t>> d_tinfo_;
+    std::vector<DevBuf<TileDesc>> d_tiles_;
+    std::vector<DevBuf<TileBandDesc>> d_tbands_;
+    DevBuf<TileLogoDev> d_tls_;
     // linear mode (built on first use)
     void ensure_linear();
     bool linear_ready_ = false;
@@ -154,9 +174,9 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
                                    const int* dframe_map, long long frame_stride_elems, int pitch, int nframes, int G, float* dout,
                                    int out_frame_stride, int take_abs, int plane_cap, float bin_delta);
 // eval_pair_kernels.hip: fades {0, 1} of every logo, bit-exact
-hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const LinLogoDev* dlins, int nlogos,
-                                 const EvalBand* dbands, const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,
-                                 int nframes, int G, float* dout, int out_frame_stride, int take_abs, int plane_cap);
+hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
+                                 const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,
+                                 int nframes, int G, float* dout, int out_frame_stride, int take_abs);
 hipError_t launch_analysis_mark(hipStream_t st, const float* drec, int stride, int nframes, int ngroups, int nfades, const float* eps3,
                                 int* dlist, int* dcount);
 

@@ -179,13 +179,13 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
     const int nl = (int)specs_.size();
     int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
     const int nf_all = (int)fades_.size();
-    if (pair_eligible()) {
+    if (pair_eligible() && pair_addressable(pitch * es)) {
         // fades {0, 1}: the window of s and the window of bg are the two blends themselves
         const size_t dot = prof_name_.find('.');
         const int sp = ctx_->prof_begin(("logo_eval_pair_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
-        AMT_HIP(launch_logo_eval_pair(ctx_->stream, bits, d_logos_.get(), d_lins_.get(), nl, d_lin_bands_.get(), dY, dframe_map,
-                                      frame_stride_bytes / es, pitch, nframes, std::max(2, G & ~1), dout, out_frame_stride_, take_abs_ ? 1 : 0,
-                                      lin_plane_cap_));
+        const int Gp = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min((long long)kTileMaxFrames, (long long)nframes * nl / 2048));
+        AMT_HIP(launch_logo_eval_pair(ctx_->stream, bits, d_logos_.get(), d_tls_.get(), nl, dY, dframe_map,
+                                      frame_stride_bytes / es, pitch, nframes, Gp, dout, out_frame_stride_, take_abs_ ? 1 : 0));
         ctx_->prof_end(sp);
         return;
     }
@@ -201,8 +201,10 @@ void EvalEngine::run(const void* dY, int64_t frame_stride_bytes, int pitch, int 
 }
 
 // The pair kernel evaluates fade 0 on s and fade 1 on bg = a*s + b*maxv directly.  That equals the reference's blend
-// fade*bg + (1-fade)*s bit for bit as long as 0*bg == 0, i.e. bg is finite: every coefficient finite and small enough that
-// a*65535 + b*65535 cannot overflow.  Anything else (and shapes the one-pixel-per-thread tables do not cover) keeps the generic kernel.
+// fade*bg + (1-fade)*s bit for bit as long as 0*bg == 0, i.e. bg is finite; it also takes the score bin from a window mean that
+// it assumes to be below 2^31 (CorrelationScore's (int)avg, LogoScan.hpp:304, is INT_MIN beyond -- exact_math.h score_bin).  Both
+// hold when |a| + |b| < 8192 at every pixel (|bg| < 2^30 for samples up to 65535); logos outside that, field logos and logos
+// without mask pixels keep the generic kernel.
 bool EvalEngine::pair_eligible()
 {
     if (pair_state_ >= 0) return pair_state_ == 1;
@@ -213,16 +215,62 @@ bool EvalEngine::pair_eligible()
     if (fades_.size() != 2 || fades_[0] != 0.0f || fades_[1] != 1.0f || specs_.empty()) return false;
     for (const EvalLogoSpec& S : specs_) {
         const int w = S.planes.w, h = S.planes.h;
-        if (5 * lds_pitch(w) > kLinPlaneCap || w > 256 || w < 4 || S.tables.count <= 0) return false;
-        if ((size_t)S.tables.count + kTablePad >= (1u << 21)) return false;
+        // (tile units are four columns wide and keep 8-byte alignment: even widths >= 6; slot byte offsets stay below 2^32)
+        if (w < 6 || (w & 1) || h < 5 || S.tables.count <= 0 || S.tables.count >= (1 << 20)) return false;     // (24-bit slot byte offsets)
+        if (!S.deint) return false;                             // LogoFrame's logos are deinterlaced ones; field logos keep the generic kernel
         const float* a = S.planes.A(0);
         const float* b = S.planes.B(0);
         for (int p = 0; p < w * h; ++p)
-            if (!(std::fabs(a[p]) < 1e30f) || !(std::fabs(b[p]) < 1e30f)) return false;       // NaN fails both comparisons
+            if (!(std::fabs(a[p]) + std::fabs(b[p]) < 8192.0f)) return false;       // |bg| <= (|a| + |b|) * 65535 < 2^30; NaN fails the comparison
     }
-    ensure_linear();
+    ensure_tiles();
     pair_state_ = 1;
     return true;
+}
+
+// the pair kernel addresses a frame's samples with 32-bit byte offsets
+bool EvalEngine::pair_addressable(int pitch_bytes) const
+{
+    for (const EvalLogoSpec& S : specs_) {
+        const long long last = (long long)(S.imgy + S.row0 + (long long)S.planes.h * S.row_step + 1) * pitch_bytes + (long long)(S.imgx + S.planes.w) * 2;
+        if (last >= (1LL << 31) || pitch_bytes <= 0) return false;
+    }
+    return true;
+}
+
+// tile plans of the pair kernel (eval_tiles.hpp): per logo the bands, the eight wave tiles of every band, and per slot
+// (= lane of a tile) the mask pixel's window offset, taps and scales
+void EvalEngine::ensure_tiles()
+{
+    if (tiles_ready_) return;
+    ctx_->bind();
+    const int nl = (int)specs_.size();
+    std::vector<TileLogoDev> hl(nl);
+    d_tkp_.resize(nl); d_tsc_.resize(nl); d_tinfo_.resize(nl); d_tiles_.resize(nl); d_tbands_.resize(nl);
+    for (int i = 0; i < nl; ++i) {
+        const EvalLogoSpec& S = specs_[i];
+        const MaskTables& T = S.tables;
+        const TilePlan P = build_tile_plan(T.pos, T.count, S.planes.w, S.planes.h);
+        const size_t ns = (size_t)P.nslots();
+        std::vector<float2> kp(13 * ns, float2{0.0f, 0.0f}), sc((size_t)kNumBins * ns, float2{0.0f, 0.0f});
+        for (size_t s = 0; s < ns; ++s) {
+            const int m = P.slot_pixel[s];
+            if (m < 0) continue;
+            const float* k = &T.kernels[(size_t)m * 25];
+            for (int j = 0; j < 13; ++j) kp[(size_t)j * ns + s] = float2{k[2 * j], 2 * j + 1 < 25 ? k[2 * j + 1] : 0.0f};
+            for (int c = 0; c < kNumBins; ++c)
+                sc[(size_t)c * ns + s] = float2{T.scales[((size_t)m * 32 + c) * 2], T.scales[((size_t)m * 32 + c) * 2 + 1]};
+        }
+        d_tkp_[i].upload(kp, ctx_->stream);
+        d_tsc_[i].upload(sc, ctx_->stream);
+        d_tinfo_[i].upload(P.sinfo, ctx_->stream);
+        d_tiles_[i].upload(P.tiles, ctx_->stream);
+        d_tbands_[i].upload(P.bands, ctx_->stream);
+        hl[i] = TileLogoDev{d_tkp_[i].get(), d_tsc_[i].get(), d_tinfo_[i].get(), d_tiles_[i].get(), d_tbands_[i].get(),
+                            (int)P.bands.size(), (int)ns};
+    }
+    d_tls_.upload(hl, ctx_->stream);
+    tiles_ready_ = true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

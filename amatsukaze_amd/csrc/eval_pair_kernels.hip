@@ -2,26 +2,33 @@
 // and corr1 = EvaluateLogo(fade 1) of every logo on every frame, in the reference's fp32 evaluation order (bit-exact records).
 //
 // With fade 0 the blended window  fade*bg + (1-fade)*s  (LogoScan.hpp:244-251) IS s, with fade 1 it IS bg = a*s + b*maxv
-// (0*x + y == y for finite x; the host checks that every logo coefficient is finite and small enough for bg to stay finite,
+// (0*x + y == y for finite x; the host checks that every logo coefficient is finite and small enough for bg to stay below 2^30,
 // and launches the generic kernel of eval_fused_kernels.hip otherwise).  So the two evaluations of a mask pixel are the SAME
-// instruction stream on two operands: LDS holds the band's rows as interleaved {s, bg} pairs, a window element arrives as one
-// 8-byte read, and every add / sub / mul of CalcCorrelation5x5_AVX's order (ComputeKernel.cpp:77-121, exact_math.h) is one
-// packed fp32 instruction whose low half evaluates fade 0 and whose high half evaluates fade 1 -- no blend arithmetic, no
-// FMA contraction (-ffp-contract=off), the 25 taps broadcast to both halves through op_sel.
+// instruction stream on two operands: LDS holds {s, bg} pairs, a window element arrives as one 8-byte read, and every
+// add / sub / mul of CalcCorrelation5x5_AVX's order (ComputeKernel.cpp:77-121, exact_math.h) is one packed fp32 instruction whose
+// low half evaluates fade 0 and whose high half evaluates fade 1 -- no blend arithmetic, no FMA contraction
+// (-ffp-contract=off), the 25 taps broadcast to both halves through op_sel.
 //
-// Shape: workgroup = (logo, G frames), 8 evaluation waves + 1 summing wave, walking the logo's pixel bands (<= 512
-// raster-consecutive mask pixels and the <= 16 rows their windows touch; the tables of the linear kernel); two frames per
-// iteration.  An evaluation thread owns ONE mask pixel.  Pipeline, ONE barrier per (band, frame pair) iteration:
-//   * the raw rows of the next iteration are requested at the top with buffer_load ... lds (no registers held) into the wave's
-//     own rows of the other half of a double-buffered plane, and converted to {s, bg} in place after the evaluation;
-//   * the band's logo coefficients stay in LDS across the frames of the workgroup;
-//   * per-pixel terms go to an LDS row per (frame, fade); the ninth wave adds the PREVIOUS iteration's rows front to back -- one
-//     lane per row, the reference's order (`result += score`, LogoScan.hpp:295-315) -- while the others evaluate the current one.
+// Shape (eval_tiles.hpp): workgroup = (logo, G <= 8 frames) = 8 evaluation waves + 1 summing wave, walking the logo's bands of
+// <= 512 raster-consecutive mask pixels.  Within a band every evaluation wave owns a TILE: 64 of the band's mask pixels (the
+// band sorted by column and dealt out 64 at a time) and the bounding box of their 5x5 windows.  The wave stages its tile for
+// one frame per iteration into LDS nobody else touches -- raw samples prefetched into registers an iteration ahead, converted to
+// {s, bg} with the tile's logo coefficients held in registers for the whole band -- and evaluates its pixels from it.  LDS
+// operations of one wave complete in order, so nothing in an iteration needs a barrier.  The per-pixel terms go to an LDS row
+// per (frame, fade) at the pixel's raster position; the waves meet ONCE PER BAND, and the ninth wave then adds the band's
+// 2 G rows front to back -- one lane per row, the reference's order (`result += score`, LogoScan.hpp:295-315) -- while the
+// others evaluate the next band into the second set of rows.
+//
+// The loop is bound by the NUMBER of vector instructions a wave issues (two to three waves per SIMD sustain one per ~6 cycles
+// whatever their mix: profiles/r03_notes.md), so the code around the 101 packed operations of a window is kept short: raw
+// bytes are blended two samples per instruction (16-bit lanes), a tile of at most 64 units is staged in one pass, every
+// address that does not change within a band is kept in a register.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>
 
-#include "eval_plan.h"
+#include "engine.hpp"
+#include "eval_tiles.hpp"
 #include "exact_math.h"
 #include "eval_lds_stage.h"
 #include "eval_ordered_sum.h"
@@ -30,11 +37,8 @@ namespace amt {
 
 using namespace lin;
 
-constexpr int kPairEvalWaves = kLinThreads / 64;                 // 8: one mask pixel per evaluation thread
-constexpr int kPairThreads = kLinThreads + 64;                   // + the summing wave
-constexpr int kPairFPI = 2;                                      // frames per iteration
-constexpr int kPairRows = 2 * kPairFPI;                          // score rows per iteration: (frame, fade)
-constexpr int kPairRowPitch = kLinBandPix + kEvalScorePad;       // floats; the sum reads ahead of the row's end
+constexpr int kPairThreads = (kTileWaves + 1) * 64;              // the evaluation waves + the summing wave
+constexpr int kPairRowPitch = kTileBandPix + kEvalScorePad;      // floats; the sum reads ahead of the row's end
 
 // {corr(k, s), corr(k, bg)} around the window means M = window_means(W) in the reference's order (exact_math.h corr5x5_strided),
 // both halves at once
@@ -55,269 +59,357 @@ __device__ __forceinline__ f2 window_corr_exact(const f2 (&Kp)[13], const f2 (&W
     return ((p[0] + p[4]) + p[2]) + (p[1] + p[3]);
 }
 
+// The 5x5 window of one pixel: 25 separate 8-byte LDS reads (merged into ds_read2_b64 they would take twice the LDS cycles and
+// fall under a different bank map than the one the tile pitch was chosen for -- MI355X_MICROARCH.md, LDS table), issued in one go,
+// row by row; wrow[r] = LDS byte address of the window's row r.  The compiler does not count these reads, so the waits are placed
+// here: LDS operations of a wave complete in order, and window_rows_ready<N>() returns when at most N of them are outstanding.  Its
+// in/out operands tie the rows it releases to the instructions that consume them.  (No scalar load is in flight at this point of
+// the loop -- their consumers precede the evaluation -- so lgkmcnt counts LDS operations only.)
+__device__ __forceinline__ void window_reads(const unsigned (&wrow)[5], f2 (&W)[25])
+{
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:8\n\tds_read_b64 %2, %5 offset:16\n\t"
+                     "ds_read_b64 %3, %5 offset:24\n\tds_read_b64 %4, %5 offset:32"
+                     : "=&v"(W[5 * r]), "=&v"(W[5 * r + 1]), "=&v"(W[5 * r + 2]), "=&v"(W[5 * r + 3]), "=&v"(W[5 * r + 4])
+                     : "v"(wrow[r]) : "memory");
+}
+template <int OUTSTANDING, int ROW0, int NROWS>
+__device__ __forceinline__ void window_rows_ready(f2 (&W)[25])
+{
+    static_assert(NROWS == 1 || NROWS == 2, "one or two rows per wait");
+    if (NROWS == 2)
+        asm volatile("s_waitcnt lgkmcnt(%10)"
+                     : "+v"(W[5 * ROW0]), "+v"(W[5 * ROW0 + 1]), "+v"(W[5 * ROW0 + 2]), "+v"(W[5 * ROW0 + 3]), "+v"(W[5 * ROW0 + 4]),
+                       "+v"(W[5 * ROW0 + 5]), "+v"(W[5 * ROW0 + 6]), "+v"(W[5 * ROW0 + 7]), "+v"(W[5 * ROW0 + 8]), "+v"(W[5 * ROW0 + 9])
+                     : "n"(OUTSTANDING) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%5)"
+                     : "+v"(W[5 * ROW0]), "+v"(W[5 * ROW0 + 1]), "+v"(W[5 * ROW0 + 2]), "+v"(W[5 * ROW0 + 3]), "+v"(W[5 * ROW0 + 4])
+                     : "n"(OUTSTANDING) : "memory");
+}
+
+// bin of CorrelationScore (LogoScan.hpp:304) for a mean below 2^31 (guaranteed by pair_eligible: |bg| < 2^30)
+__device__ __forceinline__ unsigned score_bin_bounded(float mean) { return (unsigned)((int)__builtin_amdgcn_fmed3f(mean, 0.0f, 255.0f) >> 3); }
+
+// Four adjacent samples of a source row as they come out of memory, and the unit's four s values: the sample itself, or DeintY's
+// (r0 + 2 r1 + r2 + 2) / 4.0f (LogoScan.hpp:763-780) -- an integer sum below 2^24 times 0.25, the reference's value bit for bit.
+template <typename pix_t> struct Quad;
+template <> struct Quad<uint8_t> {
+    unsigned v;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff) { v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0); }
+    __device__ __forceinline__ float get(int k) const { return (float)((v >> (8 * k)) & 0xFFu); }
+    // two samples per instruction: bytes 0, 2 and bytes 1, 3 spread over 16-bit lanes (sums <= 1022).  bias = 2 in both lanes for
+    // a blended row; for a copied row (the logo's first / last, LogoScan.hpp:763-780) r0 = r2 = r1 and bias = 0: 4 r1 / 4 = r1
+    static __device__ __forceinline__ void blend(const Quad& r0, const Quad& r1, const Quad& r2, unsigned bias, float (&s)[4])
+    {
+        const unsigned e0 = __builtin_amdgcn_perm(r0.v, r0.v, 0x0C020C00u), o0 = __builtin_amdgcn_perm(r0.v, r0.v, 0x0C030C01u);
+        const unsigned e1 = __builtin_amdgcn_perm(r1.v, r1.v, 0x0C020C00u), o1 = __builtin_amdgcn_perm(r1.v, r1.v, 0x0C030C01u);
+        const unsigned e2 = __builtin_amdgcn_perm(r2.v, r2.v, 0x0C020C00u), o2 = __builtin_amdgcn_perm(r2.v, r2.v, 0x0C030C01u);
+        const unsigned se = ((e1 << 1) + e0) + (e2 + bias);
+        const unsigned so = ((o1 << 1) + o0) + (o2 + bias);
+        // (ldexp, not a multiply by 0.25: the vectoriser would pair the multiplies and the pairs {s0,s1}, {s2,s3} then need four
+        //  moves into the {s, bg} order of the LDS store)
+        s[0] = __builtin_amdgcn_ldexpf((float)(se & 0xFFFFu), -2);
+        s[1] = __builtin_amdgcn_ldexpf((float)(so & 0xFFFFu), -2);
+        s[2] = __builtin_amdgcn_ldexpf((float)(se >> 16), -2);
+        s[3] = __builtin_amdgcn_ldexpf((float)(so >> 16), -2);
+    }
+    static constexpr unsigned kBias = 0x00020002u;
+};
+template <> struct Quad<uint16_t> {
+    u2 v;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff) { v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0); }
+    __device__ __forceinline__ float get(int k) const { return (float)((v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu); }
+    static __device__ __forceinline__ void blend(const Quad& r0, const Quad& r1, const Quad& r2, unsigned bias, float (&s)[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned a = (r0.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, b = (r1.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu,
+                           c = (r2.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            s[k] = __builtin_amdgcn_ldexpf((float)(((b << 1) + a) + (c + bias)), -2);
+        }
+    }
+    static constexpr unsigned kBias = 2u;
+};
+
+struct PairLaunch {
+    const EvalLogoDev* logos;
+    const TileLogoDev* tls;
+    const void* Y;
+    const int* frame_map;
+    long long frame_stride;      // elements
+    int pitch;                   // elements
+    float maxv;
+    int nframes, G, ngroups;
+    float* out;
+    int out_frame_stride, take_abs;
+};
+
+#ifdef AMT_PAIR_OCC
+#define AMT_PAIR_OCC_ATTR __attribute__((amdgpu_waves_per_eu(AMT_PAIR_OCC, AMT_PAIR_OCC)))
+#else
+#define AMT_PAIR_OCC_ATTR
+#endif
 template <typename pix_t>
-__global__ __launch_bounds__(kPairThreads)
-void logo_eval_pair_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoDev* __restrict__ lins, const EvalBand* __restrict__ bands,
-                           const pix_t* __restrict__ Y, const int* __restrict__ frame_map, long long frame_stride, int pitch, float maxv,
-                           int nframes, int G, int ngroups, float* __restrict__ out, int out_frame_stride, int take_abs, int plane_cap)
+__global__ __launch_bounds__(kPairThreads) AMT_PAIR_OCC_ATTR
+void logo_eval_pair_kernel(const PairLaunch A)
 {
     extern __shared__ float lds[];
-    f2* const planes = reinterpret_cast<f2*>(lds);                       // [2][kPairFPI][plane_cap] {s, bg} of a band's rows
-    f2* const abp = planes + 2 * kPairFPI * plane_cap;                   // [plane_cap] {a, b} of the current band's rows
-    float* const rows = lds + (2 * kPairFPI + 1) * 2 * plane_cap;        // [2][kPairRows][kPairRowPitch] per-pixel terms
-    float* const accs = rows + 2 * kPairRows * kPairRowPitch;            // [G][2] running sums
-
-    const int logo = blockIdx.x / ngroups;
-    const int grp = blockIdx.x - logo * ngroups;
-    const int F0 = grp * G;
-    const int gcount = min(G, nframes - F0);
-    const EvalLogoDev L = logos[logo];
-    const LinLogoDev X = lins[logo];
-    const gptr_t gScales = (gptr_t)L.scales, gK = (gptr_t)X.kpix, gPos = (gptr_t)X.pos;
-    const unsigned cpad = (unsigned)L.count_pad;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = L.w, lp = L.lp;
-    constexpr unsigned ES = sizeof(pix_t);
+    f2* const planes = reinterpret_cast<f2*>(lds);                       // [kTileWaves][kTileCap] {s, bg}: a wave's own tile
+    float* const rows = lds + kTileWaves * kTileCap * 2;                 // [2][2 G][kPairRowPitch] per-pixel terms of a band
 
 #ifdef AMT_PAIR_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
 #define AMT_PTICK(k) do { const long long t_ = clock64(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#define AMT_PDUMP() do { if (lane == 0 && blockIdx.x == gridDim.x / 2) { \
+        long long* tb = reinterpret_cast<long long*>(A.out + (long long)A.nframes * A.out_frame_stride);   /* the host reserves room */ \
+        for (int k = 0; k < 8; ++k) tb[wave * 8 + k] = tacc[k]; \
+        tb[16 * 8 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_REG_HW_ID: SIMD id in bits 5:4 */ } } while (0)
 #else
 #define AMT_PTICK(k) do { } while (0)
+#define AMT_PDUMP() do { } while (0)
 #endif
-    if (tid < 2 * G) accs[tid] = 0.0f;
-    const int npairs = (gcount + kPairFPI - 1) / kPairFPI;
-    const int niter = X.nbands * npairs;
+    const int G = A.G;
+    const int logo = blockIdx.x / A.ngroups;
+    const int grp = blockIdx.x - logo * A.ngroups;
+    const int F0 = grp * G;
+    const int gcount = min(G, A.nframes - F0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const EvalLogoDev* const Lp = A.logos + logo;
+    const TileLogoDev* const Xp = A.tls + logo;
+    const int nbands = Xp->nbands;
+    constexpr int ES = (int)sizeof(pix_t);
 
-    if (wave == kPairEvalWaves) {
-        // ---------------- the summing wave: iteration it adds the rows written during iteration it - 1 ----------------
-        __syncthreads();                                  // the prologue's barrier
-        int bi = 0, pr = 0;
-        int prev_npix = 0, prev_g = 0, prev_rows = 0;
-        for (int it = 0; it < niter; ++it) {
-#ifndef AMT_PAIR_NO_SUM
-            if (it > 0 && lane < prev_rows) {
-#else
-            if (it > 0 && lane < prev_rows && prev_npix > 100000) {
-#endif
-                float* a = accs + prev_g * 2 + lane;      // row fr*2 + fade belongs to frame prev_g + fr
-                *a = ordered_row_sum(rows + (((it - 1) & 1) * kPairRows + lane) * kPairRowPitch, prev_npix, *a);
-            }
-            prev_npix = bands[X.band0 + bi].npix;
-            prev_g = pr * kPairFPI;
-            prev_rows = 2 * min(kPairFPI, gcount - prev_g);
-            if (++pr == npairs) { pr = 0; ++bi; }
-            AMT_PTICK(2);
-            __syncthreads();
-            AMT_PTICK(6);
-        }
-        if (niter > 0 && lane < prev_rows) {
-            float* a = accs + prev_g * 2 + lane;
-            *a = ordered_row_sum(rows + (((niter - 1) & 1) * kPairRows + lane) * kPairRowPitch, prev_npix, *a);
-        }
-        __syncthreads();
-    } else {
-        // ---------------- evaluation waves ----------------
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.a), 0, 0x7FFFFFFF, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.b), 0, 0x7FFFFFFF, 0x00020000);
-        // Staging unit = one row of the band of one of the iteration's frames; the nrows * kPairFPI units of an iteration are dealt
-        // round-robin to the 8 waves (unit u -> wave u % 8: a 10-row band gives every wave 2 or 3 units; whole rows per wave left
-        // three waves idle and the rest with 4).  A lane stages four adjacent columns (w <= 256); a ragged right edge (w % 4 == 2)
-        // is covered by shifting the last lane group left.
-        constexpr int kMaxUnits = (kLinBandRows * kPairFPI + kPairEvalWaves - 1) / kPairEvalWaves;      // 4
-        auto frame_rsrc = [&](int g) {
-            const int frame = F0 + min(g, gcount - 1);            // the second frame of a ragged last pair repeats the first
-            const int srcFrame = frame_map ? frame_map[frame] : frame;
-            const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
-            return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
-        };
-        const RowStager<pix_t> st(L, lane, pitch, maxv);
-        // this thread's mask pixel of a band: window offset, table index, taps
-        auto load_pixel = [&](const EvalBand& Bd, bool& act_, int& woff_, unsigned& m8_, f2 (&K)[13]) {
-            act_ = tid < Bd.npix;
-            const unsigned m = (unsigned)(Bd.m0 + (act_ ? tid : 0));
-            const unsigned pos = gld<unsigned>(gPos, m * 4u);
-            woff_ = ((int)(pos >> 16) - 2 - Bd.y0) * lp + (int)(pos & 0xFFFFu) - 2;
-            m8_ = m * 8u;
-#pragma unroll
-            for (int j = 0; j < 13; ++j) K[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
-        };
-
-        EvalBand B = bands[X.band0];
-        bool act = false;
-        unsigned m8 = 0;
-        int woff = 0;
-        const unsigned cpad8 = cpad * 8u;
-        f2 Kp[13];
-        load_pixel(B, act, woff, m8, Kp);
-        // prologue: the first iteration's rows, straight from memory
-        {
-            const int U = B.nrows * kPairFPI;
-#pragma unroll
-            for (int k = 0; k < kMaxUnits; ++k) {
-                const int u = wave + kPairEvalWaves * k;
-                if (u >= U) break;
-                const int fr = u >= B.nrows ? 1 : 0, r = u - fr * B.nrows;
-                f2* prow = planes + fr * plane_cap + r * lp;
-                st.request(frame_rsrc(fr), B.y0 + r, prow);
-                f4 av, bmv;
-                st.load_ab(rA, rB, B.y0 + r, av, bmv);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (fr == 0) st.ab_to_lds(abp + r * lp, av, bmv);
-                st.convert(prow, B.y0 + r, av, bmv);
-            }
-        }
-        __syncthreads();
-
-        int bi = 0, pr = 0;
-        for (int it = 0; it < niter; ++it) {
-            const int cur = it & 1;
-            f2* const plane = planes + cur * kPairFPI * plane_cap;
-            f2* const nplane = planes + (cur ^ 1) * kPairFPI * plane_cap;
-            const bool has_next = it + 1 < niter;
-            const bool next_band = pr + 1 == npairs;
-            const int npr = next_band ? 0 : pr + 1;
-            EvalBand Bn = B;
-            if (has_next && next_band) {
-                const EvalBand* nb = bands + X.band0 + bi + 1;
-                Bn.m0 = nb->m0; Bn.npix = nb->npix; Bn.y0 = nb->y0; Bn.nrows = nb->nrows;
-            }
-            const int Un = Bn.nrows * kPairFPI;
-            AMT_PTICK(0);
-            // ---- 1. request the next iteration's raw rows ----
-#ifndef AMT_PAIR_NO_STAGE
-            if (has_next) {
-#else
-            if (false) {
-#endif
-                const __amdgpu_buffer_rsrc_t rs0 = frame_rsrc(npr * kPairFPI), rs1 = frame_rsrc(npr * kPairFPI + 1);
-#pragma unroll
-                for (int k = 0; k < kMaxUnits; ++k) {
-                    const int u = wave + kPairEvalWaves * k;
-                    if (u >= Un) break;
-                    const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
-                    st.request(fr ? rs1 : rs0, Bn.y0 + r, nplane + fr * plane_cap + r * lp);
-                }
-            }
-            AMT_PTICK(1);
-            // ---- 2. both fades of both frames: one packed window evaluation per frame ----
-            // (the taps are loop-invariant: LICM would hoist their {k,k} broadcasts and keep 50 registers of copies; the empty asm
-            //  makes them opaque per iteration and the broadcast folds into the multiply's op_sel)
-#pragma unroll
-            for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
-            float* const myrows = rows + cur * kPairRows * kPairRowPitch + tid;
-            f2 R[kPairFPI], sc0[kPairFPI], sc1[kPairFPI];
-#pragma unroll
-            for (int fr = 0; fr < kPairFPI; ++fr) {
-                f2 W[25], M;
-#ifdef AMT_PAIR_NO_EVAL
-                M = plane[fr * plane_cap + woff]; R[fr] = Kp[fr] * M;
-#else
-                load_window(plane + fr * plane_cap, woff, lp, W);        // surplus threads read pixel B.m0's window: never written out
-                M = window_means(W);
-                R[fr] = window_corr_exact(Kp, W, M);
-#endif
-                // (issuing the two scale gathers right after the means, ahead of the correlation's 75 packed ops, measured slower:
-                //  5.30 vs 5.16 ms per 10 000 frames)
-#ifdef AMT_PAIR_NO_GATHER
-                sc0[fr] = f2{1e-4f * (float)score_bin_dev(M.x), 0.5f}; sc1[fr] = f2{1e-4f * (float)score_bin_dev(M.y), 0.5f};
-#else
-                sc0[fr] = gld<f2>(gScales, __umul24((unsigned)score_bin_dev(M.x), cpad8) + m8);
-                sc1[fr] = gld<f2>(gScales, __umul24((unsigned)score_bin_dev(M.y), cpad8) + m8);
-#endif
-            }
-#ifdef AMT_PAIR_TIMING
-            if (R[0].x == 123456.0f && R[1].y == 123456.0f) tacc[7] += 1;
-#endif
-            AMT_PTICK(2);
-            // ---- 3. per-pixel terms (LogoScan.hpp:305-308) -> the score rows ----
-            const bool act_now = act;
-#pragma unroll
-            for (int fr = 0; fr < kPairFPI; ++fr) {
-                if (act_now) {
-                    myrows[(fr * 2 + 0) * kPairRowPitch] = score_term(R[fr].x, sc0[fr].x, sc0[fr].y);
-                    myrows[(fr * 2 + 1) * kPairRowPitch] = score_term(R[fr].y, sc1[fr].x, sc1[fr].y);
-                }
-            }
-            AMT_PTICK(3);
-            // ---- 4. the next iteration's rows: raw -> {s, bg} in place (holding the terms back until after the conversion so that it
-            //      covers the scale gathers' trip was tried: 36 registers spilled, 5.4 -> 8.2 ms per 10 000 frames) ----
-#ifdef AMT_PAIR_NO_STAGE
-            if (false) {
-#else
-            if (has_next) {
-#endif
-                f4 av[kMaxUnits], bmv[kMaxUnits];
-                if (next_band) {
-#pragma unroll
-                    for (int k = 0; k < kMaxUnits; ++k) {
-                        const int u = wave + kPairEvalWaves * k;
-                        if (u >= Un) break;
-                        const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
-                        st.load_ab(rA, rB, Bn.y0 + r, av[k], bmv[k]);     // once per band, from memory
-                    }
-                    // the band's last evaluation is done: the next band's pixel and taps (14 loads, issued after everything the
-                    // conversion needs) travel while the rows are converted
-                    asm volatile("" ::: "memory");
-                    load_pixel(Bn, act, woff, m8, Kp);
-                    asm volatile("" ::: "memory");
-                }
-                // the LDS-direct loads were issued before everything else and vector-memory loads return in order: what may stay
-                // outstanding here are the next band's 14 pixel / tap loads (when one starts), never the raw rows or the coefficients
-                if (next_band) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                AMT_PTICK(4);
-#pragma unroll
-                for (int k = 0; k < kMaxUnits; ++k) {
-                    const int u = wave + kPairEvalWaves * k;
-                    if (u >= Un) break;
-                    const int fr = u >= Bn.nrows ? 1 : 0, r = u - fr * Bn.nrows;
-                    if (next_band) { if (fr == 0) st.ab_to_lds(abp + r * lp, av[k], bmv[k]); }
-                    else st.ab_from_lds(abp + r * lp, av[k], bmv[k]);
-                    st.convert(nplane + fr * plane_cap + r * lp, Bn.y0 + r, av[k], bmv[k]);
-                }
-            }
+    if (wave == kTileWaves) {
+        // ---------------- the summing wave: after the barrier that ends band b it adds band b's rows ----------------
+        // Its chain of dependent adds is short on instructions but long on latency: with the issue priority raised it gets its
+        // slot as soon as an add's operand is ready instead of queueing behind the SIMD's evaluation waves for every element
+        // (measured: 18.7 -> 10 cycles per element), and the band's rows are free again long before the next barrier.
+        __builtin_amdgcn_s_setprio(3);
+        float acc = 0.0f;
+        typedef const __attribute__((address_space(4))) TileBandDesc* const_band_ptr;
+        const const_band_ptr bd = (const_band_ptr)Xp->bands;
+        for (int b = 0; b < nbands; ++b) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             AMT_PTICK(5);
-            __syncthreads();                     // next planes and this iteration's score rows complete; current planes consumed
-            AMT_PTICK(6);
-            if (next_band) { B.m0 = Bn.m0; B.npix = Bn.npix; B.y0 = Bn.y0; B.nrows = Bn.nrows; ++bi; }
-            pr = npr;
-        }
-        __syncthreads();                         // the summing wave's last rows
-    }
+            const int npix = bd[b].npix;
+            if (lane < 2 * gcount) acc = ordered_row_sum(rows + ((b & 1) * 2 * G + lane) * kPairRowPitch, npix, acc);
 #ifdef AMT_PAIR_TIMING
-    if (lane == 0 && blockIdx.x == gridDim.x / 2 && (wave == 0 || wave == 3 || wave == 7 || wave == 8)) {
-        long long* tb = reinterpret_cast<long long*>(out + (long long)nframes * out_frame_stride);   // host reserves room
-        const int slot = wave == 0 ? 0 : (wave == 3 ? 1 : (wave == 7 ? 2 : 3));
-        for (int k = 0; k < 8; ++k) tb[slot * 8 + k] = tacc[k];
-    }
+            asm volatile("" : "+v"(acc));
 #endif
-    if (tid < gcount * 2) {
-        const int gg = tid >> 1, f = tid & 1;
-        float r = accs[tid] / L.blackScore;
-        if (take_abs) r = fabsf(r);
-        out[(long long)(F0 + gg) * out_frame_stride + L.out_off + f] = r;
+            AMT_PTICK(0);
+        }
+        if (lane < 2 * gcount) {
+            float r = acc / Lp->blackScore;
+            if (A.take_abs) r = fabsf(r);
+            A.out[(long long)(F0 + (lane >> 1)) * A.out_frame_stride + Lp->out_off + (lane & 1)] = r;
+        }
+        AMT_PDUMP();
+        return;
     }
+
+    // ---------------- evaluation waves ----------------
+    const int w = Lp->w, h = Lp->h;
+    const int srow0 = Lp->imgy + Lp->row0, srow_step = Lp->row_step, scol0 = Lp->imgx;
+    const gptr_t gA = (gptr_t)Lp->a, gB = (gptr_t)Lp->b;
+    const int pitchB = A.pitch * ES;
+    const float maxv = A.maxv;
+    const gptr_t gK = (gptr_t)Xp->kp, gSc = (gptr_t)Xp->sc, gInfo = (gptr_t)Xp->sinfo;
+    const unsigned nslots8 = (unsigned)Xp->nslots * 8u;
+    typedef const __attribute__((address_space(4))) TileDesc* const_tile_ptr;      // constant address space: scalar loads
+    const const_tile_ptr tiles = (const_tile_ptr)(Xp->tiles + wave);
+    f2* const myplane = planes + wave * kTileCap;
+    const unsigned plane_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) f2*)myplane;
+
+    auto frame_rsrc = [&](int g) {
+        const int frame = F0 + g;
+        typedef const __attribute__((address_space(4))) int* const_int_ptr;        // scalar load
+        const int srcFrame = A.frame_map ? ((const_int_ptr)A.frame_map)[frame] : frame;
+        const pix_t* src = reinterpret_cast<const pix_t*>(A.Y) + (long long)srcFrame * A.frame_stride;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
+    };
+
+    // ---- staging units of this lane in the current tile: unit = one tile row x four columns; a tile has at most 64 * kTileUnits
+    //      of them and is staged in `npass` passes of 64.  Lanes beyond the tile's last unit repeat it (same loads, same values
+    //      stored to the same place), so that a pass runs without a branch ----
+    bool second_pass = false;        // (scalar) the tile has more than 64 units
+    int ulds[kTileUnits];            // pair offset in the tile plane
+    int ug[kTileUnits][3];           // byte offsets in a frame of the rows above / at / below the unit
+    unsigned ubias[kTileUnits];      // DeintY: + 2 for a blended row, 0 for a copied one (the rows above / below then ARE the row)
+    f4 ua[kTileUnits], ubmv[kTileUnits];                        // the unit's logo coefficients: a, b * maxv
+    Quad<pix_t> raw[kTileUnits][3];
+
+    // (no branch defines these registers: a value that is only conditionally loaded gets copied at the join, and the copy waits for
+    //  the load right behind its issue -- the prefetch distance is gone)
+    auto setup_units = [&](const TileDesc& T) {
+        second_pass = T.nrows * T.ncol4 > 64;
+#pragma unroll
+        for (int k = 0; k < kTileUnits; ++k) {
+            const TileUnit U = tile_unit(T, lane + 64 * k, w);
+            const bool blend = U.y > 0 && U.y < h - 1;
+            ulds[k] = U.lds;
+            ubias[k] = blend ? Quad<pix_t>::kBias : 0u;
+            ug[k][1] = (srow0 + U.y * srow_step) * pitchB + (scol0 + U.xs) * ES;
+            ug[k][0] = blend ? ug[k][1] - pitchB : ug[k][1];
+            ug[k][2] = blend ? ug[k][1] + pitchB : ug[k][1];
+            typedef f4 __attribute__((aligned(8))) f4a8;
+            ua[k] = gld<f4a8>(gA, (unsigned)(U.y * w + U.xs) * 4u);
+            ubmv[k] = gld<f4a8>(gB, (unsigned)(U.y * w + U.xs) * 4u) * maxv;      // rounded once, exactly as in a*s + b*maxv
+        }
+    };
+    auto request = [&](int g) {
+        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(g);
+#pragma unroll
+        for (int k = 0; k < kTileUnits; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) raw[k][j].load(rs, ug[k][j]);
+    };
+    // raw samples -> {s, bg = a*s + b*maxv} pairs (LogoScan.hpp:247)
+    auto convert_unit = [&](int k) {
+        float sv[4];
+        Quad<pix_t>::blend(raw[k][0], raw[k][1], raw[k][2], ubias[k], sv);
+        f2* dst = myplane + ulds[k];
+        reinterpret_cast<f4*>(dst)[0] = f4{sv[0], ua[k][0] * sv[0] + ubmv[k][0], sv[1], ua[k][1] * sv[1] + ubmv[k][1]};
+        reinterpret_cast<f4*>(dst)[1] = f4{sv[2], ua[k][2] * sv[2] + ubmv[k][2], sv[3], ua[k][3] * sv[3] + ubmv[k][3]};
+    };
+    auto convert = [&]() {
+        convert_unit(0);
+        if (second_pass) {
+#pragma unroll
+            for (int k = 1; k < kTileUnits; ++k) convert_unit(k);
+        }
+    };
+
+    auto fetch_tile = [&](TileDesc& D, int band) {
+        const const_tile_ptr t = tiles + band * kTileWaves;
+        D.x0 = t->x0; D.y0 = t->y0; D.nrows = t->nrows; D.ncol4 = t->ncol4; D.tp = t->tp; D.npix = t->npix; D.rcp = t->rcp;
+    };
+    // ---- this lane's mask pixel in the current band ----
+    f2 Kp[13];
+    unsigned wrow[5];                // LDS byte addresses of the five rows of the pixel's window in the tile plane
+    int ridx = 0;
+    bool act = false;
+    unsigned slot8 = 0;
+    auto load_pixel = [&](int band, const TileDesc& T) {
+        const unsigned slot = (unsigned)(band * kTileWaves + wave) * 64u + (unsigned)lane;
+        const unsigned si = gld<unsigned>(gInfo, slot * 4u);
+        const int woff = (int)(si & 0xFFFu);                      // idle lanes: the tile's first window, never written out
+#pragma unroll
+        for (int r = 0; r < 5; ++r) wrow[r] = plane_base + (unsigned)(woff + r * T.tp) * 8u;
+        ridx = (int)((si >> 12) & 0xFFFu);
+        act = (si >> 31) != 0;
+        slot8 = slot * 8u;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) Kp[j] = gld<f2>(gK, (unsigned)j * nslots8 + slot8);
+    };
+
+    TileDesc T;
+    fetch_tile(T, 0);
+    setup_units(T);
+    request(0);
+    // (the first raw samples must not be the LAST loads issued before the loop: vector-memory loads return in order, and the wait the
+    //  compiler places at the loop head for them is the merge of this path and the back edge -- with the raw loads sunk below the 14
+    //  pixel / tap loads it became vmcnt(0) in every iteration, which also waits for the scale gathers issued just before)
+    asm volatile("" ::: "memory");
+    load_pixel(0, T);
+
+    // the terms of an evaluation are formed one iteration later, when its two scale gathers have long arrived
+    f2 pR = {0.0f, 0.0f}, psc0 = pR, psc1 = pR;
+    int prow = 0;                    // (scalar) the pending terms' first row: 2 * frame in the band's set of rows
+    bool pact = false;
+    auto flush_terms = [&]() {
+        if (pact) {
+            float* const pdst = rows + prow * kPairRowPitch + ridx;
+            pdst[0] = score_term(pR.x, psc0.x, psc0.y);               // LogoScan.hpp:305-308
+            pdst[kPairRowPitch] = score_term(pR.y, psc1.x, psc1.y);
+        }
+    };
+
+    int b = 0, g = 0;
+    const int niter = nbands * gcount;
+    for (int it = 0; it < niter; ++it) {
+        const bool band_end = g + 1 == gcount;
+        // ---- 1. the iteration's tile: raw -> {s, bg} pairs in this wave's plane ----
+        AMT_PTICK(6);
+#ifdef AMT_PAIR_TIMING
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // (timing build: the wait for the raw samples on its own)
+        AMT_PTICK(7);
+#endif
+        convert();
+        AMT_PTICK(0);
+        // ---- 2. the next iteration's raw samples travel during the evaluation (past the last iteration: a repeat nobody reads) ----
+        if (band_end && b + 1 < nbands) {
+            fetch_tile(T, b + 1);
+            setup_units(T);
+        }
+        request(band_end ? 0 : g + 1);
+        AMT_PTICK(1);
+        // ---- 3. both fades of the frame: one packed window evaluation ----
+        // (the taps are loop-invariant: LICM would hoist their {k,k} broadcasts and keep 50 registers of copies; the empty asm
+        //  makes them opaque per iteration and the broadcast folds into the multiply's op_sel)
+#pragma unroll
+        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
+        f2 W[25];
+        window_reads(wrow, W);
+        // the column sums ((r0+r1)+(r2+r3))+r4 of the window means (ComputeKernel.cpp:88-94) start as the rows arrive
+        f2 c01[5], c[5];
+        window_rows_ready<15, 0, 2>(W);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) c01[i] = W[i] + W[5 + i];
+        window_rows_ready<5, 2, 2>(W);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) c[i] = c01[i] + (W[10 + i] + W[15 + i]);
+        window_rows_ready<0, 4, 1>(W);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) c[i] = c[i] + W[20 + i];
+        const f2 M = div25_pk(((c[0] + c[4]) + c[2]) + (c[1] + c[3]));          // hsum256_ps order, /25 (ComputeKernel.cpp:54-74,98)
+        const f2 R = window_corr_exact(Kp, W, M);
+#ifdef AMT_PAIR_TIMING
+        { f2 Rt = R; asm volatile("" : "+v"(Rt)); }
+#endif
+        AMT_PTICK(2);
+        // ---- 4. the previous iteration's terms -> the band's score rows, at the pixel's raster position; then this iteration's two
+        //      scale gathers go straight into the registers the terms were read from (a copy would wait for them here) ----
+        flush_terms();
+        psc0 = gld<f2>(gSc, __umul24(score_bin_bounded(M.x), nslots8) + slot8);
+        psc1 = gld<f2>(gSc, __umul24(score_bin_bounded(M.y), nslots8) + slot8);
+        pR = R; pact = act;
+        AMT_PTICK(3);
+        prow = (b & 1) * 2 * G + g * 2;
+        if (band_end) {
+            flush_terms();                                           // the band's rows are complete before the waves meet
+            pact = false;
+            // the band's last evaluation is done: the next band's pixel and taps travel across the barrier
+            ++b; g = 0;
+            if (b < nbands) load_pixel(b, T);
+            AMT_PTICK(4);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            AMT_PTICK(5);
+        } else {
+            ++g;
+        }
+    }
+    AMT_PDUMP();
 }
 
-hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const LinLogoDev* dlins, int nlogos,
-                                 const EvalBand* dbands, const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,
-                                 int nframes, int G, float* dout, int out_frame_stride, int take_abs, int plane_cap)
+hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
+                                 const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,
+                                 int nframes, int G, float* dout, int out_frame_stride, int take_abs)
 {
     if (nframes <= 0 || nlogos <= 0) return hipSuccess;
-    if (2 * G > kLinThreads || plane_cap > kLinPlaneCap) return hipErrorInvalidValue;
-    const int ngroups = (nframes + G - 1) / G;
-    const float maxv = (float)((1 << bits) - 1);
-    const size_t lds = ((size_t)(2 * kPairFPI + 1) * 2 * plane_cap + (size_t)2 * kPairRows * kPairRowPitch + (size_t)2 * G) * sizeof(float);
-    dim3 grid((unsigned)((long long)ngroups * nlogos));
-    if (bits <= 8)
-        hipLaunchKernelGGL(logo_eval_pair_kernel<uint8_t>, grid, dim3(kPairThreads), lds, st, dlogos, dlins, dbands, (const uint8_t*)dY, dframe_map,
-                           frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, plane_cap);
-    else
-        hipLaunchKernelGGL(logo_eval_pair_kernel<uint16_t>, grid, dim3(kPairThreads), lds, st, dlogos, dlins, dbands, (const uint16_t*)dY, dframe_map,
-                           frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, plane_cap);
+    PairLaunch A;
+    A.logos = dlogos; A.tls = dtls; A.Y = dY; A.frame_map = dframe_map; A.frame_stride = frame_stride_elems; A.pitch = pitch;
+    A.maxv = (float)((1 << bits) - 1);
+    A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
+    A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs;
+    const size_t lds = ((size_t)kTileWaves * kTileCap * 2 + (size_t)2 * 2 * G * kPairRowPitch) * sizeof(float);
+    if (G < 1 || 2 * G > 64 || lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((long long)A.ngroups * nlogos));
+    if (bits <= 8) hipLaunchKernelGGL(logo_eval_pair_kernel<uint8_t>, grid, dim3(kPairThreads), lds, st, A);
+    else hipLaunchKernelGGL(logo_eval_pair_kernel<uint16_t>, grid, dim3(kPairThreads), lds, st, A);
     return hipGetLastError();
 }
 

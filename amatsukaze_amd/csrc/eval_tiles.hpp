@@ -1,0 +1,175 @@
+// eval_tiles.hpp -- host-side plan of the tile evaluation kernels (eval_pair_kernels.hip): bands of raster-consecutive mask
+// pixels, each split into up to eight wave tiles.  Pure C++ (no HIP) so that tests/cpp/eval_tiles_test.cpp can replay the
+// kernel's addressing on the CPU.
+//
+// Why tiles: CorrelationScore (LogoScan.hpp:288-318) adds the per-pixel terms in raster order, so the terms of a band of <= 512
+// raster-consecutive mask pixels go to an LDS row that one lane adds front to back.  WHICH thread evaluates a mask pixel is
+// free, though: a band's pixels are sorted by column and dealt to the eight evaluation waves 64 at a time, and every wave stages
+// only the bounding box of its own pixels' 5x5 windows -- a tile of ~36 x 10 samples instead of a share of the band's full-width
+// rows -- into LDS that no other wave reads.  Staging, window reads and evaluation of a wave then need no workgroup barrier; the
+// waves meet once per band (eight frames), when the summing wave takes over the band's rows.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+namespace amt {
+
+#ifndef AMT_TILE_WAVES
+#define AMT_TILE_WAVES 11
+#endif
+constexpr int kTileWaves = AMT_TILE_WAVES;            // evaluation waves per workgroup = tiles per band
+#ifndef AMT_TILE_G
+#define AMT_TILE_G 8
+#endif
+constexpr int kTileMaxFrames = AMT_TILE_G;            // frames per workgroup: 2 * kTileMaxFrames score rows per band, twice (double buffer)
+constexpr int kTileLanes = 64;                        // mask pixels per tile
+constexpr int kTileBandPix = kTileWaves * kTileLanes; // 512: mask pixels per band, one LDS score row per (frame, fade)
+constexpr int kTileCap = 512;                         // {s, bg} pairs an LDS tile plane holds (4 KB)
+constexpr int kTileUnits = kTileCap / 4 / kTileLanes; // staging units (one row x four columns) per lane per frame: 2
+
+// one wave's tile of one band; read with scalar loads (32 bytes)
+struct TileDesc {
+    int x0, y0;          // tile origin in logo coordinates (x0 even: the units' 16-byte LDS stores stay aligned)
+    int nrows, ncol4;    // rows, four-column units per row
+    int tp;              // LDS row pitch in pairs (even, >= 4 * ncol4), chosen on the host for the fewest bank conflicts
+    int npix;            // mask pixels of this tile = active lanes (<= 64); 0: the wave idles through this band
+    int rcp;             // unit u -> row u / ncol4 == (u * rcp) >> 16 for every u < 64 * kTileUnits
+    int pad;
+};
+struct TileBandDesc {
+    int m0, npix;        // the band's mask pixels [m0, m0 + npix) in raster order
+};
+#if defined(__HIPCC__)
+#define AMT_TILE_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define AMT_TILE_HD inline
+#endif
+// staging unit u of a tile (one tile row x four columns; units beyond the tile's last repeat it): the logo row and first column
+// it covers and its pair offset in the tile plane.  Shared by the kernel and the CPU replay of its addressing.
+struct TileUnit { int y, xs, lds; };
+AMT_TILE_HD TileUnit tile_unit(const TileDesc& T, int u, int w)
+{
+    const int last = T.nrows * T.ncol4 - 1;
+    u = u < last ? u : (last < 0 ? 0 : last);
+    const int row = (u * T.rcp) >> 16;
+    const int c4 = u - row * T.ncol4;
+    const int x = T.x0 + 4 * c4;
+    const int xs = x < w - 4 ? x : w - 4;             // a ragged right edge: the last unit moves left
+    return TileUnit{T.y0 + row, xs, row * T.tp + (xs - T.x0)};
+}
+
+// per lane of a tile (slot = (band * kTileWaves + wave) * 64 + lane)
+inline uint32_t tile_slot_info(int woff, int ridx, bool valid) { return (uint32_t)woff | ((uint32_t)ridx << 12) | (valid ? 0x80000000u : 0u); }
+
+struct TilePlan {
+    std::vector<TileBandDesc> bands;
+    std::vector<TileDesc> tiles;          // bands.size() * kTileWaves
+    std::vector<uint32_t> sinfo;          // per slot: window offset in the tile (pairs, bits 0-11), index in the band's score row (bits 12-23), valid (bit 31)
+    std::vector<int> slot_pixel;          // per slot: mask pixel m, -1 for an idle lane
+    int nslots() const { return (int)sinfo.size(); }
+};
+
+namespace tiles_detail {
+
+struct Px { int x, y, m; };
+
+// LDS cycles of one 8-byte window read of a wave: lanes 0-31 and 32-63 are served as two groups, a bank pair holds pair index mod 32,
+// distinct addresses on one bank pair serialise (MI355X_MICROARCH.md, LDS: ds_read_b64).  The 25 reads of a window differ by a
+// constant, so one count covers them all.
+inline int window_read_cycles(const std::vector<Px>& g, int x0, int y0, int tp)
+{
+    int cycles = 0;
+    for (int half = 0; half < 2; ++half) {
+        std::vector<int> seen[32];
+        int worst = 1;
+        for (int l = half * 32; l < std::min((int)g.size(), half * 32 + 32); ++l) {
+            const int off = (g[l].y - 2 - y0) * tp + (g[l].x - 2 - x0);
+            std::vector<int>& b = seen[off & 31];
+            if (std::find(b.begin(), b.end(), off) == b.end()) b.push_back(off);
+            worst = std::max(worst, (int)b.size());
+        }
+        cycles += worst;
+    }
+    return cycles;
+}
+
+struct Geometry { int x0, y0, nrows, ncol4; };
+inline Geometry bbox(const std::vector<Px>& g, size_t a, size_t b)
+{
+    int xmin = 1 << 30, xmax = -1, ymin = 1 << 30, ymax = -1;
+    for (size_t i = a; i < b; ++i) {
+        xmin = std::min(xmin, g[i].x); xmax = std::max(xmax, g[i].x);
+        ymin = std::min(ymin, g[i].y); ymax = std::max(ymax, g[i].y);
+    }
+    Geometry G;
+    G.x0 = (xmin - 2) & ~1;
+    G.y0 = ymin - 2;
+    G.nrows = ymax + 2 - G.y0 + 1;
+    G.ncol4 = (xmax + 2 - G.x0 + 1 + 3) / 4;
+    return G;
+}
+inline bool fits(const Geometry& G) { return G.nrows * G.ncol4 * 4 <= kTileCap && G.nrows * G.ncol4 <= kTileLanes * kTileUnits; }
+
+} // namespace tiles_detail
+
+// pos[m] = (y << 16) | x of mask pixel m in raster order (MaskTables::pos); every pixel has 2 <= x < w-2, 2 <= y < h-2, w >= 5
+inline TilePlan build_tile_plan(const std::vector<uint32_t>& pos, int count, int w, int h)
+{
+    using namespace tiles_detail;
+    (void)h;
+    if (w < 5) throw std::runtime_error("logo too narrow for the tile kernel");
+    TilePlan P;
+    for (int m = 0; m < count;) {
+        int n = std::min(kTileBandPix, count - m);
+        std::vector<std::vector<Px>> groups;
+        for (;;) {
+            // the band's pixels by column, then row: a wave's 64 pixels cover few columns and all of the band's rows
+            std::vector<Px> px(n);
+            for (int i = 0; i < n; ++i) px[i] = Px{(int)(pos[m + i] & 0xFFFFu), (int)(pos[m + i] >> 16), m + i};
+            std::stable_sort(px.begin(), px.end(), [](const Px& a, const Px& b) { return a.x < b.x; });
+            groups.clear();
+            for (size_t a = 0; a < px.size();) {
+                size_t b = a + 1;
+                while (b < px.size() && b - a < (size_t)kTileLanes && fits(bbox(px, a, b + 1))) ++b;
+                groups.emplace_back(px.begin() + a, px.begin() + b);
+                a = b;
+            }
+            if ((int)groups.size() <= kTileWaves) break;
+            n = std::max(1, n - std::max(1, n / 8));       // sparse stretch: a shorter band
+        }
+        const int band = (int)P.bands.size();
+        P.bands.push_back(TileBandDesc{m, n});
+        P.tiles.resize((size_t)(band + 1) * kTileWaves, TileDesc{0, 0, 0, 1, 4, 0, 65536, 0});
+        P.sinfo.resize((size_t)(band + 1) * kTileBandPix, tile_slot_info(0, 0, false));
+        P.slot_pixel.resize((size_t)(band + 1) * kTileBandPix, -1);
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const std::vector<Px>& g = groups[gi];
+            const Geometry G = bbox(g, 0, g.size());
+            // pitch: the candidate with the fewest LDS cycles per window read, the narrowest among equals
+            int best_tp = G.ncol4 * 4, best_cyc = 1 << 30;
+            for (int tp = G.ncol4 * 4; tp * G.nrows <= kTileCap && tp < G.ncol4 * 4 + 32; tp += 2) {
+                const int c = window_read_cycles(g, G.x0, G.y0, tp);
+                if (c < best_cyc) { best_cyc = c; best_tp = tp; }
+            }
+            TileDesc& T = P.tiles[(size_t)band * kTileWaves + gi];
+            T.x0 = G.x0; T.y0 = G.y0; T.nrows = G.nrows; T.ncol4 = G.ncol4; T.tp = best_tp; T.npix = (int)g.size();
+            T.rcp = (65536 + G.ncol4 - 1) / G.ncol4;
+            for (int u = 0; u < kTileLanes * kTileUnits; ++u)
+                if (((u * T.rcp) >> 16) != u / G.ncol4) throw std::runtime_error("tile plan: unit row magic");
+            for (size_t l = 0; l < g.size(); ++l) {
+                const size_t slot = ((size_t)band * kTileWaves + gi) * kTileLanes + l;
+                const int woff = (g[l].y - 2 - G.y0) * best_tp + (g[l].x - 2 - G.x0);
+                if (woff < 0 || woff + 4 * best_tp + 4 > G.nrows * best_tp - 1 || G.nrows * best_tp > kTileCap) throw std::runtime_error("tile plan: window outside its tile");
+                P.sinfo[slot] = tile_slot_info(woff, g[l].m - m, true);
+                P.slot_pixel[slot] = g[l].m;
+            }
+        }
+        m += n;
+    }
+    return P;
+}
+
+} // namespace amt

@@ -116,9 +116,9 @@ def test_scan_in_ragged_batches_bit_exact(gpu, group, bits):
 @pytest.mark.parametrize("shape,maskratio", [("w98_ragged", 0.35), ("origin_mod4_2", 0.35), ("tall_narrow", 0.35), ("w322_two_groups", 0.35),
                                              ("w98_ragged", 1.0), ("origin_mod4_2", 0.02)])
 def test_scan_shapes_bit_exact(gpu, shape, maskratio, bits):
-    """LogoFrame scan on the shapes the pair kernel's staging special-cases (ragged last lane group, rectangle origins that are
-    even but not 4-byte aligned, bands of many short rows, dense and sparse masks); the 322-wide logo is outside its one column
-    group and runs on the generic kernel.  Records are the oracle's bytes either way."""
+    """LogoFrame scan on the shapes the pair kernel's tile staging special-cases (a last unit moved left at a ragged right edge,
+    rectangle origins that are even but not 4-byte aligned, bands of many short rows, dense and sparse masks, a logo wider than
+    one wave's lanes).  Records are the oracle's bytes."""
     import ctypes as C
     from amatsukaze_amd import LogoFrame
     W, H, LW, LH, X, Y0, N = SHAPES[shape]
@@ -131,7 +131,7 @@ def test_scan_shapes_bit_exact(gpu, shape, maskratio, bits):
     got = lf.evalResults
     used = [k for k, (calls, _) in ctx.profile_report().items() if calls]
     ctx.profile(False)
-    assert used == ["logo_eval_fused_kernel.scan" if LW > 256 else "logo_eval_pair_kernel.scan"], used
+    assert used == ["logo_eval_pair_kernel.scan"], used
     orc = cs["orc"]
     d = orc.lib.orc_logo_deint(cs["lo"]); orc.lib.orc_logo_create_mask(d, maskratio, 1)
     Y = cs["clip"]["Y"]

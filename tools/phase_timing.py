@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")
 ap.add_argument("--what", default="analyze")
 ap.add_argument("--frames", type=int, default=2048)
+ap.add_argument("--logos", type=int, default=1, help="scan: candidate logos (copies of one)")
 ap.add_argument("--mode", default="exact", help="analysis mode: exact | linear_unguarded")
 a = ap.parse_args()
 if a.build:
@@ -38,13 +39,19 @@ logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
 if a.what == "scan":
     # the kernel dumps its counters past the results of the frames it was given: declare a longer clip, scan its head
     import numpy as np
-    lf = LogoFrame(ctx, [logo], 0.35)
-    lf.begin(W, H, 8, a.frames + 64)
+    lf = LogoFrame(ctx, [logo] * a.logos, 0.35)
+    lf.begin(W, H, 8, a.frames + 128)
     for _ in range(2):
         lf.scan_batch(dclip.Y[: a.frames], 8, 0, a.frames)
     torch.cuda.synchronize()
-    r = np.ascontiguousarray(lf.evalResults.reshape(-1)[a.frames * 2:a.frames * 2 + 64])
-    t = r.view(np.int64).reshape(4, 8)
+    r = np.ascontiguousarray(lf.evalResults.reshape(-1)[a.frames * 2 * a.logos:a.frames * 2 * a.logos + 2 * (16 * 8 + 16)])
+    tall = r.view(np.int64)
+    hwid = tall[16 * 8:16 * 8 + 16]
+    tall = tall[:16 * 8].reshape(16, 8)
+    nw = int((tall.sum(1) > 0).sum())
+    t = tall[[0, min(3, nw - 2), nw - 2, nw - 1]]
+    print("waves of the middle workgroup: SIMD (HW_ID bits 5:4) / evaluation phase cycles / barrier wait:")
+    print("  " + "  ".join(f"w{w}:simd{(int(hwid[w]) >> 4) & 3}/{int(tall[w, 2])}/{int(tall[w, 5])}" for w in range(nw)))
 else:
     out = torch.zeros((a.frames + 8, 33), dtype=torch.float32, device=dev)     # the kernel dumps its counters past the results
     an = AMTAnalyzeLogo(ctx, logo, 0.35, mode=a.mode)
@@ -53,13 +60,13 @@ else:
     torch.cuda.synchronize()
     t = out[a.frames:].reshape(-1)[:64].contiguous().view(torch.int64).cpu().numpy().reshape(4, 8)
 if a.what == "scan":
-    pn = ["band start (pixel, taps)", "request raw rows (LDS-direct)", "windows + evaluation / ordered sum", "gathers landed, terms, row writes",
-          "wait for the raw rows", "convert -> {s,bg}", "wait at the barrier", "-"]
-    tot = t[:, :7].sum(1)
-    print("pair kernel: cycles (s_memtime ticks) of the middle workgroup; waves 0, 3, 7 evaluate, wave 8 sums:")
-    for k in range(7):
-        print(f"  {pn[k]:36s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
-    print("  total                                " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
+    pn = ["convert raw -> {s,bg} / ordered sum", "next tile + request raw samples", "window reads + evaluation", "previous terms, scale gathers",
+          "band end: last terms, next pixel + taps", "wait at the barrier", "loop bookkeeping", "wait for the raw samples"]
+    tot = t.sum(1)
+    print("pair kernel: cycles (s_memtime ticks) of the middle workgroup; three evaluation waves (first, fourth, last) and the summing wave:")
+    for k in range(8):
+        print(f"  {pn[k]:40s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
+    print("  total                                    " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
     sys.exit(0)
 if a.what != "scan" and a.mode != "exact":
     ln = ["band start (pixel, taps)", "request raw rows (LDS-direct)", "fold sums, window evaluation", "fades (gathers, terms, fix-up)",
