@@ -82,7 +82,8 @@ struct TileLogoDev {
     const uint32_t* sinfo;       // [nslots]      tile_slot_info
     const TileDesc* tiles;       // [nbands * 8]
     const TileBandDesc* bands;   // [nbands]
-    int nbands, nslots;
+    const int* tlist;            // [ntlist]  indices of the tiles that hold pixels (kernels that need no band order walk these)
+    int nbands, nslots, ntlist;
 };
 
 // one evaluation logo + where its source pixels come from
@@ -141,6 +142,7 @@ private:
     // fades {0, 1} (the LogoFrame scan): both evaluations as one packed instruction stream (eval_pair_kernels.hip); decided once
     bool pair_eligible();
     bool pair_addressable(int pitch_bytes) const;
+    bool tiles_usable(int pitch_bytes) const;
     int pair_state_ = -1;                          // -1 undecided, 0 generic kernel, 1 pair kernel
     // tile plans (eval_tiles.hpp), built when the pair kernel is chosen
     void ensure_tiles();
@@ -149,17 +151,13 @@ private:
     std::vector<DevBuf<uint32_t>> d_tinfo_;
     std::vector<DevBuf<TileDesc>> d_tiles_;
     std::vector<DevBuf<TileBandDesc>> d_tbands_;
+    std::vector<DevBuf<int>> d_tlist_;
     DevBuf<TileLogoDev> d_tls_;
     // linear mode (built on first use)
     void ensure_linear();
     bool linear_ready_ = false;
-    int lin_plane_cap_ = 0;
     float vmax_unit_ = 1.0f;                       // max over logos / pixels of max(1, |a| + |b|): window values are <= this * maxv
     std::vector<double> lin_err_corr_, lin_err_sum_;   // per logo: the two parts of the error bound, in units of (u * vmax) and u
-    std::vector<DevBuf<float2>> d_kpix_;
-    std::vector<DevBuf<uint32_t>> d_pos_;
-    DevBuf<LinLogoDev> d_lins_;
-    DevBuf<EvalBand> d_lin_bands_;
 };
 
 // kernel launcher (eval_fused_kernels.hip).  dnframes (device, optional): the number of frames actually present (<= nframes,
@@ -169,10 +167,10 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
                                   long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
                                   int take_abs, int plane_cap, const int* dnframes = nullptr, int scatter = 0);
 // eval_linear_kernels.hip
-hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const LinLogoDev* dlins, int nlogos,
-                                   const EvalBand* dbands, const float* dfades, int nfades, int fade0, const void* dY,
-                                   const int* dframe_map, long long frame_stride_elems, int pitch, int nframes, int G, float* dout,
-                                   int out_frame_stride, int take_abs, int plane_cap, float bin_delta);
+hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
+                                   const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
+                                   long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
+                                   int take_abs, float bin_delta);
 // eval_pair_kernels.hip: fades {0, 1} of every logo, bit-exact
 hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                  const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,

@@ -215,8 +215,8 @@ bool EvalEngine::pair_eligible()
     if (fades_.size() != 2 || fades_[0] != 0.0f || fades_[1] != 1.0f || specs_.empty()) return false;
     for (const EvalLogoSpec& S : specs_) {
         const int w = S.planes.w, h = S.planes.h;
-        // (tile units are four columns wide and keep 8-byte alignment: even widths >= 6; slot byte offsets stay below 2^32)
-        if (w < 6 || (w & 1) || h < 5 || S.tables.count <= 0 || S.tables.count >= (1 << 20)) return false;     // (24-bit slot byte offsets)
+        // (tile units are four columns wide and keep 8-byte alignment: even widths >= 6; 24-bit slot byte offsets)
+        if (w < 6 || (w & 1) || h < 5 || S.tables.count <= 0 || S.tables.count >= (1 << 20)) return false;
         if (!S.deint) return false;                             // LogoFrame's logos are deinterlaced ones; field logos keep the generic kernel
         const float* a = S.planes.A(0);
         const float* b = S.planes.B(0);
@@ -246,7 +246,7 @@ void EvalEngine::ensure_tiles()
     ctx_->bind();
     const int nl = (int)specs_.size();
     std::vector<TileLogoDev> hl(nl);
-    d_tkp_.resize(nl); d_tsc_.resize(nl); d_tinfo_.resize(nl); d_tiles_.resize(nl); d_tbands_.resize(nl);
+    d_tkp_.resize(nl); d_tsc_.resize(nl); d_tinfo_.resize(nl); d_tiles_.resize(nl); d_tbands_.resize(nl); d_tlist_.resize(nl);
     for (int i = 0; i < nl; ++i) {
         const EvalLogoSpec& S = specs_[i];
         const MaskTables& T = S.tables;
@@ -257,7 +257,9 @@ void EvalEngine::ensure_tiles()
             const int m = P.slot_pixel[s];
             if (m < 0) continue;
             const float* k = &T.kernels[(size_t)m * 25];
-            for (int j = 0; j < 13; ++j) kp[(size_t)j * ns + s] = float2{k[2 * j], 2 * j + 1 < 25 ? k[2 * j + 1] : 0.0f};
+            float ksum = 0.0f;
+            for (int t = 0; t < 25; ++t) ksum += k[t];
+            for (int j = 0; j < 13; ++j) kp[(size_t)j * ns + s] = float2{k[2 * j], 2 * j + 1 < 25 ? k[2 * j + 1] : ksum};    // [12].y = sum of the taps (linear kernel)
             for (int c = 0; c < kNumBins; ++c)
                 sc[(size_t)c * ns + s] = float2{T.scales[((size_t)m * 32 + c) * 2], T.scales[((size_t)m * 32 + c) * 2 + 1]};
         }
@@ -266,8 +268,11 @@ void EvalEngine::ensure_tiles()
         d_tinfo_[i].upload(P.sinfo, ctx_->stream);
         d_tiles_[i].upload(P.tiles, ctx_->stream);
         d_tbands_[i].upload(P.bands, ctx_->stream);
-        hl[i] = TileLogoDev{d_tkp_[i].get(), d_tsc_[i].get(), d_tinfo_[i].get(), d_tiles_[i].get(), d_tbands_[i].get(),
-                            (int)P.bands.size(), (int)ns};
+        std::vector<int> tlist;
+        for (size_t t = 0; t < P.tiles.size(); ++t) if (P.tiles[t].npix > 0) tlist.push_back((int)t);
+        d_tlist_[i].upload(tlist, ctx_->stream);
+        hl[i] = TileLogoDev{d_tkp_[i].get(), d_tsc_[i].get(), d_tinfo_[i].get(), d_tiles_[i].get(), d_tbands_[i].get(), d_tlist_[i].get(),
+                            (int)P.bands.size(), (int)ns, (int)tlist.size()};
     }
     d_tls_.upload(hl, ctx_->stream);
     tiles_ready_ = true;
@@ -279,52 +284,13 @@ void EvalEngine::ensure_tiles()
 void EvalEngine::ensure_linear()
 {
     if (linear_ready_) return;
-    ctx_->bind();
     const int nl = (int)specs_.size();
-    std::vector<LinLogoDev> hl(nl);
-    std::vector<EvalBand> bands;
-    d_kpix_.resize(nl); d_pos_.resize(nl);
     lin_err_corr_.assign(nl, 0.0); lin_err_sum_.assign(nl, 0.0);
-    lin_plane_cap_ = 0;
     double vunit = 1.0;
     for (int i = 0; i < nl; ++i) {
         const EvalLogoSpec& S = specs_[i];
         const MaskTables& T = S.tables;
         const int w = S.planes.w, h = S.planes.h;
-        const int lp = lds_pitch(w);
-        if (5 * lp > kLinPlaneCap || w > 256 || w < 4) throw std::runtime_error("logo too wide for the linear evaluation kernel");
-        if ((size_t)T.count + kTablePad >= (1u << 21)) throw std::runtime_error("logo too large for the linear evaluation kernel");   // 24-bit byte offsets
-        const int cpad = std::max(kTablePad, (T.count + kTablePad - 1) / kTablePad * kTablePad);       // == EvalLogoDev::count_pad
-        // pixel bands: up to kLinBandPix raster-consecutive mask pixels whose 5x5 windows fit the LDS plane
-        const int band0 = (int)bands.size();
-        auto py = [&](int m) { return (int)(T.pos[m] >> 16); };
-        for (int m = 0; m < T.count;) {
-            EvalBand B{};
-            B.logo = i; B.m0 = m;
-            const int ytop = py(m) - 2;
-            int e = m;
-            while (e < T.count && e - m < kLinBandPix && (py(e) + 2 - ytop + 1) * lp <= kLinPlaneCap && py(e) + 2 - ytop + 1 <= kLinBandRows) ++e;
-            B.npix = e - m; B.s0 = m; B.nslots = e - m;
-            B.y0 = ytop; B.nrows = py(e - 1) + 2 - ytop + 1;
-            lin_plane_cap_ = std::max(lin_plane_cap_, B.nrows * lp);
-            bands.push_back(B);
-            m = e;
-        }
-        std::vector<float2> kpix((size_t)13 * cpad, float2{0.0f, 0.0f});
-        std::vector<uint32_t> pos(cpad, 0u);
-        for (int m = 0; m < T.count; ++m) {
-            const float* k = &T.kernels[(size_t)m * 25];
-            float ksum = 0.0f;
-            for (int t = 0; t < 25; ++t) ksum += k[t];
-            for (int j = 0; j < 13; ++j) kpix[(size_t)j * cpad + m] = float2{k[2 * j], 2 * j + 1 < 25 ? k[2 * j + 1] : ksum};   // [12].y = sum of the taps
-            pos[m] = T.pos[m];
-        }
-        for (int m = T.count; m < cpad; ++m) pos[m] = T.count ? T.pos[T.count - 1] : 0u;
-        d_kpix_[i].upload(kpix, ctx_->stream);
-        d_pos_[i].upload(pos, ctx_->stream);
-        hl[i].kpix = d_kpix_[i].get(); hl[i].pos = d_pos_[i].get();
-        hl[i].band0 = band0; hl[i].nbands = (int)bands.size() - band0;
-
         // ---- error bound of the linear evaluation against the reference's evaluation order (u = 2^-24, v = bound on window values) ----
         // every window value (s, bg, any blend with fade in [0,1] ... fades up to 2 are covered by the factor below) is <= v = vunit*maxv;
         // exact path:  W_i carries 3 roundings, the mean 6 + 1, (W_i - m), the product, the 6-deep sum:   |d corr| <= 27 u v sum|k|
@@ -332,7 +298,8 @@ void EvalEngine::ensure_linear()
         //              mean term, whose own error 7 u v is multiplied by |sum k_i| <= sum|k_i|): 23 u v sum|k|, for s and for bg with
         //              weights 1-f and f; 3 roundings to combine:  26
         //  => |corr_lin - corr_exact| <= 53 u v sum|k_i| (58 below); the clamp is 1-Lipschitz, so a term moves by <= scale*scale2 times that (+ 2u|t|);
-        // the two summation orders (sequential vs tree) differ by <= (count + 32) u sum|t|, and |t| <= scale2.
+        // two summation orders of the count terms (the reference's sequential one, this kernel's lanes / tiles / waves) differ by
+        // <= (count + 32) u sum|t|, and |t| <= scale2.
         const float* a = S.planes.A(0);
         const float* b = S.planes.B(0);
         for (int p = 0; p < w * h; ++p) vunit = std::max(vunit, (double)std::fabs(a[p]) + std::fabs(b[p]));
@@ -354,9 +321,17 @@ void EvalEngine::ensure_linear()
         lin_err_sum_[i] = ((double)T.count + 40.0) * tsum / black + 8.0;        // x u  (+ the final division / abs, results are O(1))
     }
     vmax_unit_ = (float)(vunit * 2.0);          // fades of ReMakeLogo reach 1.9: |f| + |1-f| <= 3; analysis fades are in [0,1]; 2x margin
-    d_lins_.upload(hl, ctx_->stream);
-    d_lin_bands_.upload(bands, ctx_->stream);
     linear_ready_ = true;
+}
+
+// the tile kernels address a frame's samples with 32-bit byte offsets and the slot tables with 24-bit ones
+bool EvalEngine::tiles_usable(int pitch_bytes) const
+{
+    for (const EvalLogoSpec& S : specs_) {
+        const int w = S.planes.w, h = S.planes.h;
+        if (w < 6 || (w & 1) || h < 5 || S.tables.count <= 0 || S.tables.count >= (1 << 20)) return false;
+    }
+    return pair_addressable(pitch_bytes);
 }
 
 float EvalEngine::linear_error_bound(int logo, int bits) const
@@ -369,30 +344,24 @@ float EvalEngine::linear_error_bound(int logo, int bits) const
 void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout, const int* dframe_map)
 {
     if (nframes <= 0 || specs_.empty()) return;
-    // a logo without mask pixels (maskratio 0) has no bands for the one-pixel-per-thread kernels to walk: the generic kernel
-    // handles it (its results are 0 / blackScore = 0 / 0, as the reference's)
-    for (const EvalLogoSpec& S : specs_)
-        if (S.tables.count <= 0) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }
-    ensure_linear();
-    ctx_->bind();
     const int es = bits <= 8 ? 1 : 2;
+    // The linear kernel evaluates AMTAnalyzeLogo's 11 fades on tile plans.  A logo without mask pixels (maskratio 0: results are
+    // 0 / blackScore = 0 / 0, as the reference's), odd or tiny shapes and any other fade list keep the exact kernel.
+    if ((int)fades_.size() != 11 || !tiles_usable(pitch * es)) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }
+    ensure_linear();
+    ensure_tiles();
+    ctx_->bind();
     if (frame_stride_bytes % es) throw std::runtime_error("frame stride not a multiple of the sample size");
     const int nl = (int)specs_.size();
-    const int nf_all = (int)fades_.size();
     // the interpolated mean is within 19 u v of the exactly evaluated one (7 + 7 roundings of the two means, 3 to combine them, 9 on
     // the exact side... see ensure_linear); a 32 u v window decides when the exact mean is computed for the bin
     const float bin_delta = 32.0f / 16777216.0f * vmax_unit_ * (float)((1 << bits) - 1);
-    int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
-    for (int f0 = 0; f0 < nf_all; f0 += kLinMaxFades) {
-        const int nf = std::min(kLinMaxFades, nf_all - f0);
-        G = std::max(1, std::min(G, kLinThreads / nf));
-        const size_t dot = prof_name_.find('.');
-        const int sp = ctx_->prof_begin(("logo_eval_linear_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
-        AMT_HIP(launch_logo_eval_linear(ctx_->stream, bits, d_logos_.get(), d_lins_.get(), nl, d_lin_bands_.get(), d_fades_.get(), nf, f0, dY,
-                                        dframe_map, frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0,
-                                        lin_plane_cap_, bin_delta));
-        ctx_->prof_end(sp);
-    }
+    const int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
+    const size_t dot = prof_name_.find('.');
+    const int sp = ctx_->prof_begin(("logo_eval_linear_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
+    AMT_HIP(launch_logo_eval_linear(ctx_->stream, bits, d_logos_.get(), d_tls_.get(), nl, d_fades_.get(), 11, 0, dY, dframe_map,
+                                    frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0, bin_delta));
+    ctx_->prof_end(sp);
 }
 
 void EvalEngine::run_listed(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int max_frames, const int* dlist,

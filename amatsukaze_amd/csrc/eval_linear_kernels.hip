@@ -12,22 +12,29 @@
 //   * argmin over fades (CalcFade2, :1288-1314): analysis_mark_kernel lists every frame whose best / second-best margin is
 //     below twice the error bound, and the exact kernel (eval_fused_kernels.hip) re-evaluates just those frames.
 //
-// Shape: workgroup (512 threads) = (logo, G frames) walking the logo's pixel bands (<= 512 raster-consecutive mask pixels and
-// the rows their windows touch); thread = ONE mask pixel.  LDS holds the band's rows as interleaved {s, bg} pairs, so a
-// window element arrives as one 8-byte read with s in the low and bg in the high half: the window mean and the correlation
-// of BOTH operands are computed by the same packed fp32 instructions (v_pk_*_f32, the 25 taps broadcast to both halves).
-// No ordered sum: per-pixel terms are summed per wave with DPP adds and the eight wave sums in a fixed order -- deterministic.
+// Shape (eval_tiles.hpp, eval_tile_stage.h): workgroup (256 threads) = (logo, G frames); its four waves share out the logo's
+// TILES (64 mask pixels and the bounding box of their windows) round-robin and never meet before the end: a wave stages its
+// tile for one frame into its own LDS plane as {s, bg} pairs -- raw samples prefetched into registers an iteration ahead --
+// evaluates the window mean and the correlation of BOTH operands with the same packed fp32 instructions (the 25 taps broadcast
+// to both halves), forms the fades, adds the terms over its lanes with DPP adds and keeps the sums per (frame, fade) in LDS
+// cells that only it touches.  The summation order of this mode is free (it is not the reference's; the error bound covers any
+// order) but fixed: lanes by DPP tree, tiles in turn, the four waves in order at the end -- deterministic.  No barrier in the loop.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>
 
-#include "eval_plan.h"
-#include "exact_math.h"
-#include "eval_lds_stage.h"
+#include "eval_tile_stage.h"
 
 namespace amt {
 
 using namespace lin;
+using namespace tile;
+
+#ifndef AMT_LIN_WAVES
+#define AMT_LIN_WAVES 4
+#endif
+constexpr int kLinWaves = AMT_LIN_WAVES;     // waves per workgroup: one per SIMD, so that three workgroups always fit a CU at <= 168 registers
+constexpr int kLinWgThreads = kLinWaves * 64;
 
 // sum over the 64 lanes of a wave in a fixed order (DPP: every step is one v_add_f32); the total lands in lane 63
 __device__ __forceinline__ float wave_sum_dpp(float v)
@@ -41,41 +48,78 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
     return v;
 }
 
-// NF > 0: exactly NF fades (11 for AMTAnalyzeLogo: no per-fade branches); NF == 0: nfades <= kLinMaxFades at run time.
-//
-// Software pipeline over the (band, frame) iterations of a workgroup, ONE barrier per iteration: the raw rows of the NEXT
-// iteration are requested before the current window evaluation (buffer_load ... lds: no registers in flight) straight into the
-// other half of a double-buffered LDS plane and converted there, in place, after the fade code -- the global-memory latency of
-// staging sits behind the arithmetic instead of in front of a barrier.
+__device__ __forceinline__ int clamp_bin(int b) { return min(max(b, 0), 31); }      // (v_med3_i32)
+
+// mean of the blended window exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it (LogoScan.hpp:244-251, ComputeKernel.cpp:88-98),
+// one column at a time (the rare path of the bin select: few registers matter more than speed)
+__device__ __forceinline__ float exact_blend_mean_rolled(const unsigned (&wrow)[5], float fade)
+{
+    typedef const __attribute__((address_space(3))) f2* lds_pair;
+    const float omf = 1 - fade;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < 5; ++i) {
+        float v[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const f2 e = ((lds_pair)(unsigned long long)wrow[r])[i];
+            v[r] = fade_mix(fade, e.y, e.x);
+        }
+        (void)omf;
+        const float c = ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
+        c0 = i == 0 ? c : c0; c1 = i == 1 ? c : c1; c2 = i == 2 ? c : c2; c3 = i == 3 ? c : c3; c4 = i == 4 ? c : c4;
+    }
+    return div25(hsum5(c0, c1, c2, c3, c4));
+}
+
+struct LinLaunch {
+    const EvalLogoDev* logos;
+    const TileLogoDev* tls;
+    const float* fades;
+    const void* Y;
+    const int* frame_map;
+    long long frame_stride;      // elements
+    int pitch;                   // elements
+    float maxv;
+    int nfades, fade0;
+    int nframes, G, ngroups;
+    float* out;
+    int out_frame_stride, take_abs;
+    float bin_delta;
+};
+
+#ifndef AMT_LIN_OCC
+#define AMT_LIN_OCC 3
+#endif
+#define AMT_LIN_OCC_ATTR __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC, AMT_LIN_OCC)))
+// NF fades (11 for AMTAnalyzeLogo, the only caller of this mode: no per-fade branches; NF == 0 would take nfades <= kLinMaxFades
+// at run time -- kept in the source for the record, not instantiated: it spills scalar registers).
 template <typename pix_t, int NF>
-__global__ __launch_bounds__(kLinThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLogoDev* __restrict__ lins, const EvalBand* __restrict__ bands,
-                             const float* __restrict__ fades, int nfades_rt, int fade0, const pix_t* __restrict__ Y,
-                             const int* __restrict__ frame_map, long long frame_stride, int pitch, float maxv, int nframes, int G,
-                             int ngroups, float* __restrict__ out, int out_frame_stride, int take_abs, int plane_cap, float bin_delta)
+__device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 {
     constexpr int NFMAX = NF > 0 ? NF : kLinMaxFades;
-    const int nfades = NF > 0 ? NF : nfades_rt;
+    const int nfades = NF > 0 ? NF : A.nfades;
     extern __shared__ float lds[];
-    f2* const planes = reinterpret_cast<f2*>(lds);                 // [2][plane_cap] {s, bg = a*s + b*maxv} of a band's rows, one frame each
-    f2* const abp = planes + 2 * plane_cap;                        // [plane_cap] {a, b} of the current band's rows (frame-independent)
-    float* const wpart = lds + 6 * plane_cap;                      // [2][kWaves][NFMAX] per-wave sums of the terms of an iteration
-    float* const accs = wpart + 2 * kWaves * NFMAX;                // [G][nfades] running sums
+    f2* const planes = reinterpret_cast<f2*>(lds);                 // [kLinWaves][2][kTileCap] a wave's own tile: {s, bg} and the logo's {a, b*maxv}
+    float* const wacc = lds + kLinWaves * 2 * kTileCap * 2;        // [kLinWaves][G][NFMAX] a wave's running sums
 
-    const int logo = blockIdx.x / ngroups;
-    const int grp = blockIdx.x - logo * ngroups;
+    const int G = A.G;
+    const int logo = blockIdx.x / A.ngroups;
+    const int grp = blockIdx.x - logo * A.ngroups;
     const int F0 = grp * G;
-    const int gcount = min(G, nframes - F0);
-    const EvalLogoDev L = logos[logo];
-    const LinLogoDev X = lins[logo];
-    const gptr_t gScales = (gptr_t)L.scales, gK = (gptr_t)X.kpix, gPos = (gptr_t)X.pos;
-    const unsigned cpad = (unsigned)L.count_pad;
+    const int gcount = min(G, A.nframes - F0);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the staging rows' address math stays scalar
-    const int w = L.w, lp = L.lp;
-    constexpr unsigned ES = sizeof(pix_t);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const EvalLogoDev* const Lp = A.logos + logo;
+    const TileLogoDev* const Xp = A.tls + logo;
+    const int ntl = Xp->ntlist;                                    // tiles that hold pixels
+    const const_int_ptr tlist = (const_int_ptr)Xp->tlist;
+    const gptr_t gSc = (gptr_t)Xp->sc;
+    const unsigned nslots8 = (unsigned)Xp->nslots * 8u;
+    const const_tile_ptr tiles = (const_tile_ptr)Xp->tiles;
     // bin edges in 1/4096 fixed point: a mean within dq of a multiple of 8 takes the exact path
-    const int dq = (int)(bin_delta * 4096.0f) + 2;
+    const int dq = (int)(A.bin_delta * 4096.0f) + 3;
+    const float dqf = (float)dq;
 
 #ifdef AMT_LIN_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -84,269 +128,210 @@ void logo_eval_linear_kernel(const EvalLogoDev* __restrict__ logos, const LinLog
 #else
 #define AMT_LTICK(k) do { } while (0)
 #endif
-    if (tid < G * nfades) accs[tid] = 0.0f;
-    const int fade_bits = __builtin_bit_cast(int, fades[fade0 + min(lane, nfades - 1)]);     // lane f holds fade f
-    // buffer descriptors: loads below are (descriptor, per-lane column offset, wave-uniform row offset) -- no per-load address math
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.a), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.b), 0, 0x7FFFFFFF, 0x00020000);
-
-    // ---- staging: unit = one row of the band (RowStager, eval_lds_stage.h); row r belongs to wave r % 8 -- rows 2w, 2w+1 per wave put
-    //      twice the conversion work on the SIMD that hosts waves 0 and 4 of a typical 10-row band.  The raw rows of the next iteration
-    //      are requested at the top of an iteration with buffer_load ... lds (no registers held) into the plane row they are
-    //      converted into after the fade code; the row's logo coefficients {a, b*maxv} stay in LDS across the frames of the
-    //      workgroup, written and read by the wave that owns the row (no barrier involved) ----
-    constexpr int kMaxUnits = kLinBandRows / kWaves;               // 2
-    const RowStager<pix_t> st(L, lane, pitch, maxv);
-    auto frame_rsrc = [&](int g) {
-        const int frame = F0 + g;
-        const int srcFrame = frame_map ? frame_map[frame] : frame;
-        const pix_t* src = Y + (long long)srcFrame * frame_stride + (long long)(L.imgy + L.row0) * pitch + L.imgx;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
-    };
-
-    const int niter = X.nbands * gcount;
-    EvalBand B = bands[X.band0];
-    // prologue: the first iteration's rows
+    // the fades, wave-uniform (scalar registers)
+    float fd[NFMAX];
     {
-        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(0);
+        typedef const __attribute__((address_space(4))) float* const_float_ptr;
+        const const_float_ptr fp = (const_float_ptr)(A.fades + A.fade0);
 #pragma unroll
-        for (int k = 0; k < kMaxUnits; ++k) {
-            const int r = wave + kWaves * k;
-            if (r >= B.nrows) break;
-            f4 av, bmv;
-            st.request(rs, B.y0 + r, planes + r * lp);
-            st.load_ab(rA, rB, B.y0 + r, av, bmv);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            st.ab_to_lds(abp + r * lp, av, bmv);
-            st.convert(planes + r * lp, B.y0 + r, av, bmv);
+        for (int f = 0; f < NFMAX; ++f) fd[f] = fp[min(f, nfades - 1)];
+    }
+    float* const myacc = wacc + wave * G * NFMAX;
+    for (int i = lane; i < G * NFMAX; i += 64) myacc[i] = 0.0f;
+
+    f2* const myplane = planes + wave * 2 * kTileCap;
+    const unsigned plane_base = lds_address(myplane);
+    TileStager<pix_t, true, true> st;
+    st.init(Lp, A.pitch, A.maxv, myplane, myplane + kTileCap);
+    TilePixel px;
+    TileDesc T;
+
+    // this wave's tiles: entries wave, wave + 4, ... of the logo's list of tiles.  (i, g) = (list position, frame) of an iteration
+    auto advance = [&](int& i, int& g) {
+        const bool last = g + 1 == gcount;
+        g = last ? 0 : g + 1;
+        i = last ? i + kLinWaves : i;
+    };
+    // Pipeline: while iteration i is evaluated, the raw samples of i + 1 sit in registers, those of i + 2 travel, and so do the
+    // scale gathers of i - 1.
+    //   A. window reads of i from the plane, means and correlations of s and bg
+    //   D. the 11 terms of iteration i - 1 (its gathers have had a whole iteration to arrive), their sums over the wave, added to
+    //      the wave's running sums
+    //   B. the fades' bins (a mean next to a bin edge: the reference's exact mean decides, rare)
+    //   E. the 11 gathers of i go straight into the registers the terms of i - 1 were read from
+    //   C. raw(i + 1) -> plane; request raw(i + 2)   (the pixel / taps of i + 1, if its tile is a new one, are requested before D)
+    int i0 = wave, g0 = 0;                                       // iteration i
+    int i1 = i0, g1 = 0;                                         // iteration i + 1 (its raw samples are in the registers)
+    int iu = -1;                                                 // the list position whose tile the staging units describe
+    if (i0 < ntl) {
+        const int t0 = tlist[i0];
+        fetch_tile(T, tiles + t0);
+        st.setup_units(T, lane);
+        iu = i0;
+        st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0));
+        asm volatile("" ::: "memory");                             // (see eval_pair_kernels.hip: the raw loads stay ahead of the tap loads)
+        px.load(Xp, (unsigned)t0 * 64u + (unsigned)lane, T, plane_base);
+        st.convert();
+        // (the first taps have arrived before the loop: the wait the compiler places at the loop head is the merge of this path and
+        //  the back edge, and on the back edge the taps of a new tile are the OLDEST loads in flight -- see step B')
+#pragma unroll
+        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(px.Kp[j]));
+        advance(i1, g1);
+        if (i1 < ntl) {
+            if (i1 != iu) { fetch_tile(T, tiles + tlist[i1]); st.setup_units(T, lane); iu = i1; }
+            st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + g1));
         }
     }
-    bool act = false;
-    unsigned m = 0, m8 = 0;
-    int woff = 0;
-    const unsigned cpad8 = cpad * 8u;
-    f2 Kp[13];
-    // a band's mask pixel of this thread: window offset, table index, taps (a surplus thread gets zero taps: it evaluates to exactly 0,
-    // no branches in the fade code)
-    auto load_pixel = [&](const EvalBand& Bd) {
-        act = tid < Bd.npix;
-        m = (unsigned)(Bd.m0 + (act ? tid : 0));
-        const unsigned pos = gld<unsigned>(gPos, m * 4u);
-        woff = ((int)(pos >> 16) - 2 - Bd.y0) * lp + (int)(pos & 0xFFFFu) - 2;          // plane offset of the window's top-left element
-        m8 = m * 8u;
+    // the pending iteration: scales (in flight), correlation of s and its slope over the fades, frame.  (Before the first one: zero
+    // scales, i.e. zero terms, added to frame 0 -- no branch around the flush, whose registers the gathers are issued into.)
+    f2 psc[NFMAX];
+    float pR0 = 0.0f, pdR = 0.0f;
+    int pg = 0;                                                  // (scalar)
 #pragma unroll
-        for (int j = 0; j < 13; ++j) {
-            Kp[j] = gld<f2>(gK, ((unsigned)j * cpad + m) * 8u);
-            if (!act) Kp[j] = f2{0.0f, 0.0f};
+    for (int f = 0; f < NFMAX; ++f) psc[f] = f2{0.0f, 0.0f};
+    auto flush_terms = [&]() {
+        float term[NFMAX];
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f)                            // per-pixel terms (LogoScan.hpp:305-308)
+            term[f] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;
+        // the wave's sums (in lane 63 after the DPP steps) -> the wave's running sums: eleven reads, eleven adds, eleven writes by
+        // that lane, in two batches (two LDS round trips, not eleven)
+#pragma unroll
+        for (int f = 0; f < NFMAX; ++f) term[f] = wave_sum_dpp(term[f]);
+        if (lane == 63) {
+            float* const acc = myacc + pg * NFMAX;
+            constexpr int H = (NFMAX + 1) / 2;
+            float old[H];
+#pragma unroll
+            for (int f = 0; f < H; ++f) old[f] = acc[f];
+#pragma unroll
+            for (int f = 0; f < H; ++f) acc[f] = old[f] + term[f];
+#pragma unroll
+            for (int f = H; f < NFMAX; ++f) old[f - H] = acc[f];
+#pragma unroll
+            for (int f = H; f < NFMAX; ++f) acc[f] = old[f - H] + term[f];
         }
     };
-    load_pixel(B);
-    __syncthreads();
-
-    int bi = 0, g = 0;
-    for (int it = 0; it < niter; ++it) {
-        const int cur = it & 1;
-        f2* const plane = planes + cur * plane_cap;
-        // (a band's pixel and taps are requested behind the previous band's last evaluation, see load_pixel below)
+    while (i0 < ntl) {
         AMT_LTICK(0);
-        // the next iteration: same band / next frame, or the next band / first frame
-        const bool has_next = it + 1 < niter;
-        const bool next_band = g + 1 == gcount;
-        const int ng = next_band ? 0 : g + 1;
-        EvalBand Bn = B;
-        if (has_next && next_band) {
-            const EvalBand* nb = bands + X.band0 + bi + 1;
-            Bn.m0 = nb->m0; Bn.npix = nb->npix; Bn.y0 = nb->y0; Bn.nrows = nb->nrows;
-        }
-        // ---- 1. request the next iteration's raw rows (LDS-direct: no registers held) ----
-        if (has_next) {
-            const __amdgpu_buffer_rsrc_t rs = frame_rsrc(ng);
-#pragma unroll
-            for (int k = 0; k < kMaxUnits; ++k) {
-                const int r = wave + kWaves * k;
-                if (r >= Bn.nrows) break;
-                st.request(rs, Bn.y0 + r, planes + (cur ^ 1) * plane_cap + r * lp);
-            }
-        }
-        AMT_LTICK(1);
-        // ---- 2. fold the previous iteration's per-wave sums into the running sums (fixed order: deterministic) ----
-        if (it > 0 && tid < nfades) {
-            const float* wp = wpart + (cur ^ 1) * kWaves * NFMAX + tid;
-            float s = 0.0f;
-#pragma unroll
-            for (int q = 0; q < kWaves; ++q) s += wp[q * NFMAX];
-            const int pg = g == 0 ? gcount - 1 : g - 1;        // the previous iteration's frame
-            accs[pg * nfades + tid] += s;
-        }
-        // ---- 3. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
+        // ---- A. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
         // The taps are loop-invariant, so LICM would hoist their {k,k} broadcasts out of the loop and keep 50 registers of
         // copies; an empty asm makes them opaque per iteration and the broadcast folds into the multiply's op_sel instead.
 #pragma unroll
-        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
+        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(px.Kp[j]));
         f2 R, M;
-#ifdef AMT_LIN_NO_EVAL
-        M = plane[woff]; R = Kp[0] * M;
-#else
         {
-            f2 W[25];
-            load_window(plane, woff, lp, W);     // surplus threads read pixel B.m0's window: finite values, zero taps
-            M = window_means(W);
-            R = window_corr(Kp, W, M);
+            unsigned wrow[5];
+            px.rows(wrow);
+            window_eval_streamed(wrow, px.Kp, M, R);         // idle lanes read the tile's first window: finite values, zero taps
         }
-#endif
-#ifdef AMT_LIN_TIMING
-        if (R.x == 123456.0f && M.y == 123456.0f) tacc[7] += 1;
-#endif
         AMT_LTICK(2);
-        f4 av[kMaxUnits], bmv[kMaxUnits];
-        // ---- 5. all fades from the two pairs: interpolated mean -> bin -> scale gather, all in flight together; while they travel
-        //      the next iteration's rows are converted into the other plane (loads return in order: raw rows and coefficients
-        //      were requested earlier); then correlation and per-pixel term (LogoScan.hpp:305-308), summed over the wave.
-        //      The bin select is discontinuous: a mean within dq of a bin edge is noted, and those (pixel, fade) pairs -- about
-        //      1e-4 of all -- are redone below with the mean evaluated exactly as the reference does ----
-        const float m0q = M.x * 4096.0f, dMq = (M.y - M.x) * 4096.0f, dR = R.y - R.x;     // mean in 1/4096 units: m0q + fade * dMq
-        unsigned emin = 0x7FFFu;                                                          // smallest distance (+dq) to a bin edge
-        float term[NFMAX];
-#ifdef AMT_LIN_NO_FADES
+        // ---- D. the previous iteration's terms (their scales arrived long ago) leave their registers to this iteration's gathers ----
+        flush_terms();
+        AMT_LTICK(4);
+        // ---- B. bins.  qd = interpolated mean in 1/4096 units + dq: its low 15 bits are the distance (+ dq) from the bin edge below,
+        //      qd >> 15 the bin.  The bin select is discontinuous (LogoScan.hpp:304): for a mean within dq of an edge -- about 1e-4
+        //      of all (pixel, fade) pairs -- the mean is evaluated exactly as the reference does and ITS bin is taken ----
+        const float m0qd = __builtin_fmaf(M.x, 4096.0f, dqf), dMq = (M.y - M.x) * 4096.0f;
+        unsigned emin = 0x7FFFu;
+        unsigned goff[NFMAX];                                      // byte offset of the fade's {scale, scale2} in the slot table
 #pragma unroll
-        for (int f = 0; f < NFMAX; ++f) term[f] = R.x + dR * (float)f + m0q + dMq;
-#else
-        // every fade's scale gather is in flight before the first term is formed: one exposed round trip to L2 per iteration
-        constexpr int NA = (NFMAX + 1) / 2;
-        auto issue = [&](int f, f2& dst) {
-            const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
-            const int q = (int)__builtin_fmaf(fade, dMq, m0q);
-            emin = min(emin, (unsigned)(q + dq) & 0x7FFFu);
-#ifdef AMT_LIN_NO_GATHER
-            dst = f2{1e-4f * (float)(q >> 15), 0.5f};
-#elif defined(AMT_LIN_GATHER_BIN0)
-            dst = gld<f2>(gScales, __umul24((unsigned)min(max(q >> 25, 0), 31), cpad8) + m8);     // every lane reads bin 0: fully coalesced
-#else
-            dst = gld<f2>(gScales, __umul24((unsigned)min(max(q >> 15, 0), 31), cpad8) + m8);
-#endif
-        };
-        auto finish = [&](int f, const f2& sc) {
-            const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
-            term[f] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fade, dR, R.x) * sc.x, -1.0f, 1.0f) * sc.y;
-        };
-        f2 scA[NA], scB[NFMAX - NA];
+        for (int f = 0; f < NFMAX; ++f) {
+            const int qd = (int)__builtin_fmaf(fd[f], dMq, m0qd);
+            emin = min(emin, (unsigned)qd & 0x7FFFu);
+            goff[f] = __umul24((unsigned)clamp_bin(qd >> 15), nslots8) + px.slot8;
+        }
+        // (rare, and kept small in code and registers: rolled loops -- unrolled, the eleven inlined window re-reads cost the whole
+        //  kernel 70 registers)
+        if (px.act && emin <= (unsigned)(2 * dq)) {
+            typedef const __attribute__((address_space(4))) float* const_float_ptr;
+            const const_float_ptr fp = (const_float_ptr)(A.fades + A.fade0);
+            unsigned wrow[5];
+            px.rows(wrow);
+#pragma unroll 1
+            for (int f = 0; f < nfades; ++f) {
+                const float fade = fp[f];
+                const int qd = (int)__builtin_fmaf(fade, dMq, m0qd);
+                if (((unsigned)qd & 0x7FFFu) <= (unsigned)(2 * dq)) {
+                    const unsigned go = __umul24((unsigned)score_bin_dev(exact_blend_mean_rolled(wrow, fade)), nslots8) + px.slot8;
 #pragma unroll
-        for (int f = 0; f < NA; ++f) if (NF > 0 || f < nfades) issue(f, scA[f]);
-#pragma unroll
-        for (int f = NA; f < NFMAX; ++f) if (NF > 0 || f < nfades) issue(f, scB[f - NA]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < NA; ++f) if (NF > 0 || f < nfades) finish(f, scA[f]);
-#pragma unroll
-        for (int f = NA; f < NFMAX; ++f) if (NF > 0 || f < nfades) finish(f, scB[f - NA]);
-        // a mean near an edge: exact mean -> the reference's bin; when it differs from the interpolated mean's, replace the term
-        if (act && emin <= (unsigned)(2 * dq)) {
-#pragma unroll
-            for (int f = 0; f < NFMAX; ++f) {
-                if (NF > 0 || f < nfades) {
-                    const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));
-                    const int q = (int)__builtin_fmaf(fade, dMq, m0q);
-                    if (((unsigned)(q + dq) & 0x7FFFu) <= (unsigned)(2 * dq)) {
-                        const int bin_ref = score_bin_dev(exact_blend_mean(plane, woff, lp, fade, 1 - fade));
-                        if (bin_ref != min(max(q >> 15, 0), 31)) {
-                            const f2 s2 = gld<f2>(gScales, __umul24((unsigned)bin_ref, cpad8) + m8);
-                            term[f] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fade, dR, R.x) * s2.x, -1.0f, 1.0f) * s2.y;
-                        }
-                    }
+                    for (int ff = 0; ff < NFMAX; ++ff) goff[ff] = ff == f ? go : goff[ff];
                 }
             }
         }
-#endif
-#ifdef AMT_LIN_TIMING
-        if (term[0] == 123456.0f && term[NFMAX - 1] == 123456.0f) tacc[7] += 1;
-#endif
         AMT_LTICK(3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next && next_band) {                           // once per band: from memory (the wave sums below cover the trip)
+        // ---- B'. a new tile next: its pixel and taps are requested BEFORE the gathers and the raw samples -- vector-memory loads
+        //      return in order, and the taps are what the next iteration needs first ----
+        if (i1 < ntl && i1 != i0) {
+            const int t1 = tlist[i1];
+            TileDesc Tn;
+            fetch_tile(Tn, tiles + t1);
+            px.load(Xp, (unsigned)t1 * 64u + (unsigned)lane, Tn, plane_base);
+        }
+        // ---- E. this iteration's gathers, into the registers the previous terms were read from ----
 #pragma unroll
-            for (int k = 0; k < kMaxUnits; ++k) {
-                const int r = wave + kWaves * k;
-                if (r >= Bn.nrows) break;
-                st.load_ab(rA, rB, Bn.y0 + r, av[k], bmv[k]);
+        for (int f = 0; f < NFMAX; ++f) psc[f] = gld<f2>(gSc, goff[f]);
+        pR0 = R.x; pdR = R.y - R.x; pg = g0;
+        AMT_LTICK(5);
+        // ---- C. the next iteration's tile into the plane, its pixel if the tile changes, the raw samples of the one after ----
+        if (i1 < ntl) {
+            st.convert();
+            int i2 = i1, g2 = g1;
+            advance(i2, g2);
+            if (i2 < ntl) {
+                if (i2 != iu) { fetch_tile(T, tiles + tlist[i2]); st.setup_units(T, lane); iu = i2; }
+                st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + g2));
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef AMT_LIN_NO_REDUCE
-        if (lane == 63) wpart[(cur * kWaves + wave) * NFMAX] = term[0] + term[NFMAX - 1];
-#else
-#pragma unroll
-        for (int f = 0; f < NFMAX; ++f) {
-            if (NF > 0 || f < nfades) {
-                const float s = wave_sum_dpp(term[f]);
-                if (lane == 63) wpart[(cur * kWaves + wave) * NFMAX + f] = s;
-            }
-        }
-#endif
-        AMT_LTICK(4);
-#ifndef AMT_LIN_NO_STAGE
-        if (has_next) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the LDS-direct loads are counted with the vector-memory loads
-            AMT_LTICK(5);
-            // the band's last evaluation is long done: the next band's pixel and taps travel while the rows are converted
-            if (next_band) load_pixel(Bn);
-#pragma unroll
-            for (int k = 0; k < kMaxUnits; ++k) {
-                const int r = wave + kWaves * k;
-                if (r >= Bn.nrows) break;
-                if (next_band) st.ab_to_lds(abp + r * lp, av[k], bmv[k]); else st.ab_from_lds(abp + r * lp, av[k], bmv[k]);
-                st.convert(planes + (cur ^ 1) * plane_cap + r * lp, Bn.y0 + r, av[k], bmv[k]);
-            }
-        }
-#endif
-        AMT_LTICK(6);
-        __syncthreads();                         // next plane and this iteration's wave sums complete; current plane consumed
-        AMT_LTICK(7);
-        if (next_band) { B.m0 = Bn.m0; B.npix = Bn.npix; B.y0 = Bn.y0; B.nrows = Bn.nrows; ++bi; }
-        g = ng;
+        AMT_LTICK(1);
+        i0 = i1; g0 = g1;
+        advance(i1, g1);
     }
-    // the last iteration's wave sums
-    if (niter > 0 && tid < nfades) {
-        const float* wp = wpart + ((niter - 1) & 1) * kWaves * NFMAX + tid;
-        float s = 0.0f;
-#pragma unroll
-        for (int q = 0; q < kWaves; ++q) s += wp[q * NFMAX];
-        accs[(gcount - 1) * nfades + tid] += s;
-    }
+    flush_terms();
     __syncthreads();
 #ifdef AMT_LIN_TIMING
-    if (lane == 0 && blockIdx.x == gridDim.x / 6 && (wave == 0 || wave == 3 || wave == 5 || wave == 7)) {      // a workgroup of logo 0 (the deint logo)
-        long long* tb = reinterpret_cast<long long*>(out + (long long)nframes * out_frame_stride);            // host reserves room
-        const int slot = wave == 0 ? 0 : (wave == 3 ? 1 : (wave == 5 ? 2 : 3));
+    if (lane == 0 && blockIdx.x == gridDim.x / 6 && (wave == 0 || wave == 2 || wave == 4 || wave == 5)) {      // a workgroup of logo 0 (the deint logo)
+        long long* tb = reinterpret_cast<long long*>(A.out + (long long)A.nframes * A.out_frame_stride);      // host reserves room
+        const int slot = wave == 0 ? 0 : (wave == 2 ? 1 : (wave == 4 ? 2 : 3));
         for (int k = 0; k < 8; ++k) tb[slot * 8 + k] = tacc[k];
     }
 #endif
+    // the waves' sums, in order
     if (tid < gcount * nfades) {
         const int gg = tid / nfades, f = tid - gg * nfades;
-        float r = accs[tid] / L.blackScore;
-        if (take_abs) r = fabsf(r);
-        out[(long long)(F0 + gg) * out_frame_stride + L.out_off + fade0 + f] = r;
+        float r = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kLinWaves; ++q) r += wacc[(q * G + gg) * NFMAX + f];
+        r = r / Lp->blackScore;
+        if (A.take_abs) r = fabsf(r);
+        A.out[(long long)(F0 + gg) * A.out_frame_stride + Lp->out_off + A.fade0 + f] = r;
     }
 }
 
-hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const LinLogoDev* dlins, int nlogos,
-                                   const EvalBand* dbands, const float* dfades, int nfades, int fade0, const void* dY,
+// 8-bit samples: three waves per SIMD (<= 168 registers); 16-bit containers carry twice the raw samples in flight and get two
+// (a spilled register would be reloaded with a wait for EVERY load in flight -- the pipeline's whole point)
+__global__ __launch_bounds__(kLinWgThreads) AMT_LIN_OCC_ATTR
+void logo_eval_linear_kernel(const LinLaunch A) { logo_eval_linear_body<uint8_t, 11>(A); }
+__global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void logo_eval_linear_kernel16(const LinLaunch A) { logo_eval_linear_body<uint16_t, 11>(A); }
+
+hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
+                                   const float* dfades, int nfades, int fade0, const void* dY,
                                    const int* dframe_map, long long frame_stride_elems, int pitch, int nframes, int G, float* dout,
-                                   int out_frame_stride, int take_abs, int plane_cap, float bin_delta)
+                                   int out_frame_stride, int take_abs, float bin_delta)
 {
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
-    if (nfades > kLinMaxFades || G * nfades > kLinThreads || plane_cap > kLinPlaneCap) return hipErrorInvalidValue;
-    const int ngroups = (nframes + G - 1) / G;
-    const float maxv = (float)((1 << bits) - 1);
-    const int nfmax = nfades == 11 ? 11 : kLinMaxFades;
-    const size_t lds = ((size_t)6 * plane_cap + (size_t)2 * (kLinThreads / 64) * nfmax + (size_t)G * nfades) * sizeof(float);
-    dim3 grid((unsigned)((long long)ngroups * nlogos));
-#define AMT_LAUNCH(T, N)                                                                                                              \
-    hipLaunchKernelGGL((logo_eval_linear_kernel<T, N>), grid, dim3(kLinThreads), lds, st, dlogos, dlins, dbands, dfades, nfades, fade0,   \
-                       (const T*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, \
-                       plane_cap, bin_delta)
-    if (nfades == 11) { if (bits <= 8) AMT_LAUNCH(uint8_t, 11); else AMT_LAUNCH(uint16_t, 11); }
-    else { if (bits <= 8) AMT_LAUNCH(uint8_t, 0); else AMT_LAUNCH(uint16_t, 0); }
-#undef AMT_LAUNCH
+    if (nfades != 11 || G * nfades > kLinWgThreads) return hipErrorInvalidValue;       // (AMTAnalyzeLogo's fades; anything else keeps the exact kernel)
+    LinLaunch A;
+    A.logos = dlogos; A.tls = dtls; A.fades = dfades; A.Y = dY; A.frame_map = dframe_map; A.frame_stride = frame_stride_elems; A.pitch = pitch;
+    A.maxv = (float)((1 << bits) - 1);
+    A.nfades = nfades; A.fade0 = fade0;
+    A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
+    A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs; A.bin_delta = bin_delta;
+    const size_t lds = ((size_t)kLinWaves * 2 * kTileCap * 2 + (size_t)kLinWaves * G * nfades) * sizeof(float);
+    dim3 grid((unsigned)((long long)A.ngroups * nlogos));
+    if (bits <= 8) hipLaunchKernelGGL(logo_eval_linear_kernel, grid, dim3(kLinWgThreads), lds, st, A);
+    else hipLaunchKernelGGL(logo_eval_linear_kernel16, grid, dim3(kLinWgThreads), lds, st, A);
     return hipGetLastError();
 }
 

@@ -30,12 +30,13 @@
 #include "engine.hpp"
 #include "eval_tiles.hpp"
 #include "exact_math.h"
-#include "eval_lds_stage.h"
+#include "eval_tile_stage.h"
 #include "eval_ordered_sum.h"
 
 namespace amt {
 
 using namespace lin;
+using namespace tile;
 
 constexpr int kPairThreads = (kTileWaves + 1) * 64;              // the evaluation waves + the summing wave
 constexpr int kPairRowPitch = kTileBandPix + kEvalScorePad;      // floats; the sum reads ahead of the row's end
@@ -59,79 +60,8 @@ __device__ __forceinline__ f2 window_corr_exact(const f2 (&Kp)[13], const f2 (&W
     return ((p[0] + p[4]) + p[2]) + (p[1] + p[3]);
 }
 
-// The 5x5 window of one pixel: 25 separate 8-byte LDS reads (merged into ds_read2_b64 they would take twice the LDS cycles and
-// fall under a different bank map than the one the tile pitch was chosen for -- MI355X_MICROARCH.md, LDS table), issued in one go,
-// row by row; wrow[r] = LDS byte address of the window's row r.  The compiler does not count these reads, so the waits are placed
-// here: LDS operations of a wave complete in order, and window_rows_ready<N>() returns when at most N of them are outstanding.  Its
-// in/out operands tie the rows it releases to the instructions that consume them.  (No scalar load is in flight at this point of
-// the loop -- their consumers precede the evaluation -- so lgkmcnt counts LDS operations only.)
-__device__ __forceinline__ void window_reads(const unsigned (&wrow)[5], f2 (&W)[25])
-{
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-        asm volatile("ds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:8\n\tds_read_b64 %2, %5 offset:16\n\t"
-                     "ds_read_b64 %3, %5 offset:24\n\tds_read_b64 %4, %5 offset:32"
-                     : "=&v"(W[5 * r]), "=&v"(W[5 * r + 1]), "=&v"(W[5 * r + 2]), "=&v"(W[5 * r + 3]), "=&v"(W[5 * r + 4])
-                     : "v"(wrow[r]) : "memory");
-}
-template <int OUTSTANDING, int ROW0, int NROWS>
-__device__ __forceinline__ void window_rows_ready(f2 (&W)[25])
-{
-    static_assert(NROWS == 1 || NROWS == 2, "one or two rows per wait");
-    if (NROWS == 2)
-        asm volatile("s_waitcnt lgkmcnt(%10)"
-                     : "+v"(W[5 * ROW0]), "+v"(W[5 * ROW0 + 1]), "+v"(W[5 * ROW0 + 2]), "+v"(W[5 * ROW0 + 3]), "+v"(W[5 * ROW0 + 4]),
-                       "+v"(W[5 * ROW0 + 5]), "+v"(W[5 * ROW0 + 6]), "+v"(W[5 * ROW0 + 7]), "+v"(W[5 * ROW0 + 8]), "+v"(W[5 * ROW0 + 9])
-                     : "n"(OUTSTANDING) : "memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(%5)"
-                     : "+v"(W[5 * ROW0]), "+v"(W[5 * ROW0 + 1]), "+v"(W[5 * ROW0 + 2]), "+v"(W[5 * ROW0 + 3]), "+v"(W[5 * ROW0 + 4])
-                     : "n"(OUTSTANDING) : "memory");
-}
-
 // bin of CorrelationScore (LogoScan.hpp:304) for a mean below 2^31 (guaranteed by pair_eligible: |bg| < 2^30)
 __device__ __forceinline__ unsigned score_bin_bounded(float mean) { return (unsigned)((int)__builtin_amdgcn_fmed3f(mean, 0.0f, 255.0f) >> 3); }
-
-// Four adjacent samples of a source row as they come out of memory, and the unit's four s values: the sample itself, or DeintY's
-// (r0 + 2 r1 + r2 + 2) / 4.0f (LogoScan.hpp:763-780) -- an integer sum below 2^24 times 0.25, the reference's value bit for bit.
-template <typename pix_t> struct Quad;
-template <> struct Quad<uint8_t> {
-    unsigned v;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff) { v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0); }
-    __device__ __forceinline__ float get(int k) const { return (float)((v >> (8 * k)) & 0xFFu); }
-    // two samples per instruction: bytes 0, 2 and bytes 1, 3 spread over 16-bit lanes (sums <= 1022).  bias = 2 in both lanes for
-    // a blended row; for a copied row (the logo's first / last, LogoScan.hpp:763-780) r0 = r2 = r1 and bias = 0: 4 r1 / 4 = r1
-    static __device__ __forceinline__ void blend(const Quad& r0, const Quad& r1, const Quad& r2, unsigned bias, float (&s)[4])
-    {
-        const unsigned e0 = __builtin_amdgcn_perm(r0.v, r0.v, 0x0C020C00u), o0 = __builtin_amdgcn_perm(r0.v, r0.v, 0x0C030C01u);
-        const unsigned e1 = __builtin_amdgcn_perm(r1.v, r1.v, 0x0C020C00u), o1 = __builtin_amdgcn_perm(r1.v, r1.v, 0x0C030C01u);
-        const unsigned e2 = __builtin_amdgcn_perm(r2.v, r2.v, 0x0C020C00u), o2 = __builtin_amdgcn_perm(r2.v, r2.v, 0x0C030C01u);
-        const unsigned se = ((e1 << 1) + e0) + (e2 + bias);
-        const unsigned so = ((o1 << 1) + o0) + (o2 + bias);
-        // (ldexp, not a multiply by 0.25: the vectoriser would pair the multiplies and the pairs {s0,s1}, {s2,s3} then need four
-        //  moves into the {s, bg} order of the LDS store)
-        s[0] = __builtin_amdgcn_ldexpf((float)(se & 0xFFFFu), -2);
-        s[1] = __builtin_amdgcn_ldexpf((float)(so & 0xFFFFu), -2);
-        s[2] = __builtin_amdgcn_ldexpf((float)(se >> 16), -2);
-        s[3] = __builtin_amdgcn_ldexpf((float)(so >> 16), -2);
-    }
-    static constexpr unsigned kBias = 0x00020002u;
-};
-template <> struct Quad<uint16_t> {
-    u2 v;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff) { v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0); }
-    __device__ __forceinline__ float get(int k) const { return (float)((v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu); }
-    static __device__ __forceinline__ void blend(const Quad& r0, const Quad& r1, const Quad& r2, unsigned bias, float (&s)[4])
-    {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned a = (r0.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, b = (r1.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu,
-                           c = (r2.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-            s[k] = __builtin_amdgcn_ldexpf((float)(((b << 1) + a) + (c + bias)), -2);
-        }
-    }
-    static constexpr unsigned kBias = 2u;
-};
 
 struct PairLaunch {
     const EvalLogoDev* logos;
@@ -212,109 +142,24 @@ void logo_eval_pair_kernel(const PairLaunch A)
     }
 
     // ---------------- evaluation waves ----------------
-    const int w = Lp->w, h = Lp->h;
-    const int srow0 = Lp->imgy + Lp->row0, srow_step = Lp->row_step, scol0 = Lp->imgx;
-    const gptr_t gA = (gptr_t)Lp->a, gB = (gptr_t)Lp->b;
-    const int pitchB = A.pitch * ES;
-    const float maxv = A.maxv;
-    const gptr_t gK = (gptr_t)Xp->kp, gSc = (gptr_t)Xp->sc, gInfo = (gptr_t)Xp->sinfo;
+    const gptr_t gSc = (gptr_t)Xp->sc;
     const unsigned nslots8 = (unsigned)Xp->nslots * 8u;
-    typedef const __attribute__((address_space(4))) TileDesc* const_tile_ptr;      // constant address space: scalar loads
     const const_tile_ptr tiles = (const_tile_ptr)(Xp->tiles + wave);
     f2* const myplane = planes + wave * kTileCap;
-    const unsigned plane_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) f2*)myplane;
-
-    auto frame_rsrc = [&](int g) {
-        const int frame = F0 + g;
-        typedef const __attribute__((address_space(4))) int* const_int_ptr;        // scalar load
-        const int srcFrame = A.frame_map ? ((const_int_ptr)A.frame_map)[frame] : frame;
-        const pix_t* src = reinterpret_cast<const pix_t*>(A.Y) + (long long)srcFrame * A.frame_stride;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<pix_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
-    };
-
-    // ---- staging units of this lane in the current tile: unit = one tile row x four columns; a tile has at most 64 * kTileUnits
-    //      of them and is staged in `npass` passes of 64.  Lanes beyond the tile's last unit repeat it (same loads, same values
-    //      stored to the same place), so that a pass runs without a branch ----
-    bool second_pass = false;        // (scalar) the tile has more than 64 units
-    int ulds[kTileUnits];            // pair offset in the tile plane
-    int ug[kTileUnits][3];           // byte offsets in a frame of the rows above / at / below the unit
-    unsigned ubias[kTileUnits];      // DeintY: + 2 for a blended row, 0 for a copied one (the rows above / below then ARE the row)
-    f4 ua[kTileUnits], ubmv[kTileUnits];                        // the unit's logo coefficients: a, b * maxv
-    Quad<pix_t> raw[kTileUnits][3];
-
-    // (no branch defines these registers: a value that is only conditionally loaded gets copied at the join, and the copy waits for
-    //  the load right behind its issue -- the prefetch distance is gone)
-    auto setup_units = [&](const TileDesc& T) {
-        second_pass = T.nrows * T.ncol4 > 64;
-#pragma unroll
-        for (int k = 0; k < kTileUnits; ++k) {
-            const TileUnit U = tile_unit(T, lane + 64 * k, w);
-            const bool blend = U.y > 0 && U.y < h - 1;
-            ulds[k] = U.lds;
-            ubias[k] = blend ? Quad<pix_t>::kBias : 0u;
-            ug[k][1] = (srow0 + U.y * srow_step) * pitchB + (scol0 + U.xs) * ES;
-            ug[k][0] = blend ? ug[k][1] - pitchB : ug[k][1];
-            ug[k][2] = blend ? ug[k][1] + pitchB : ug[k][1];
-            typedef f4 __attribute__((aligned(8))) f4a8;
-            ua[k] = gld<f4a8>(gA, (unsigned)(U.y * w + U.xs) * 4u);
-            ubmv[k] = gld<f4a8>(gB, (unsigned)(U.y * w + U.xs) * 4u) * maxv;      // rounded once, exactly as in a*s + b*maxv
-        }
-    };
-    auto request = [&](int g) {
-        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(g);
-#pragma unroll
-        for (int k = 0; k < kTileUnits; ++k)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) raw[k][j].load(rs, ug[k][j]);
-    };
-    // raw samples -> {s, bg = a*s + b*maxv} pairs (LogoScan.hpp:247)
-    auto convert_unit = [&](int k) {
-        float sv[4];
-        Quad<pix_t>::blend(raw[k][0], raw[k][1], raw[k][2], ubias[k], sv);
-        f2* dst = myplane + ulds[k];
-        reinterpret_cast<f4*>(dst)[0] = f4{sv[0], ua[k][0] * sv[0] + ubmv[k][0], sv[1], ua[k][1] * sv[1] + ubmv[k][1]};
-        reinterpret_cast<f4*>(dst)[1] = f4{sv[2], ua[k][2] * sv[2] + ubmv[k][2], sv[3], ua[k][3] * sv[3] + ubmv[k][3]};
-    };
-    auto convert = [&]() {
-        convert_unit(0);
-        if (second_pass) {
-#pragma unroll
-            for (int k = 1; k < kTileUnits; ++k) convert_unit(k);
-        }
-    };
-
-    auto fetch_tile = [&](TileDesc& D, int band) {
-        const const_tile_ptr t = tiles + band * kTileWaves;
-        D.x0 = t->x0; D.y0 = t->y0; D.nrows = t->nrows; D.ncol4 = t->ncol4; D.tp = t->tp; D.npix = t->npix; D.rcp = t->rcp;
-    };
-    // ---- this lane's mask pixel in the current band ----
-    f2 Kp[13];
-    unsigned wrow[5];                // LDS byte addresses of the five rows of the pixel's window in the tile plane
-    int ridx = 0;
-    bool act = false;
-    unsigned slot8 = 0;
-    auto load_pixel = [&](int band, const TileDesc& T) {
-        const unsigned slot = (unsigned)(band * kTileWaves + wave) * 64u + (unsigned)lane;
-        const unsigned si = gld<unsigned>(gInfo, slot * 4u);
-        const int woff = (int)(si & 0xFFFu);                      // idle lanes: the tile's first window, never written out
-#pragma unroll
-        for (int r = 0; r < 5; ++r) wrow[r] = plane_base + (unsigned)(woff + r * T.tp) * 8u;
-        ridx = (int)((si >> 12) & 0xFFFu);
-        act = (si >> 31) != 0;
-        slot8 = slot * 8u;
-#pragma unroll
-        for (int j = 0; j < 13; ++j) Kp[j] = gld<f2>(gK, (unsigned)j * nslots8 + slot8);
-    };
+    const unsigned plane_base = lds_address(myplane);
+    TileStager<pix_t> st;
+    st.init(Lp, A.pitch, A.maxv, myplane);
+    TilePixel px;
 
     TileDesc T;
-    fetch_tile(T, 0);
-    setup_units(T);
-    request(0);
+    fetch_tile(T, tiles);
+    st.setup_units(T, lane);
+    st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0));
     // (the first raw samples must not be the LAST loads issued before the loop: vector-memory loads return in order, and the wait the
     //  compiler places at the loop head for them is the merge of this path and the back edge -- with the raw loads sunk below the 14
     //  pixel / tap loads it became vmcnt(0) in every iteration, which also waits for the scale gathers issued just before)
     asm volatile("" ::: "memory");
-    load_pixel(0, T);
+    px.load(Xp, (unsigned)wave * 64u + (unsigned)lane, T, plane_base);
 
     // the terms of an evaluation are formed one iteration later, when its two scale gathers have long arrived
     f2 pR = {0.0f, 0.0f}, psc0 = pR, psc1 = pR;
@@ -322,7 +167,7 @@ void logo_eval_pair_kernel(const PairLaunch A)
     bool pact = false;
     auto flush_terms = [&]() {
         if (pact) {
-            float* const pdst = rows + prow * kPairRowPitch + ridx;
+            float* const pdst = rows + prow * kPairRowPitch + px.ridx;
             pdst[0] = score_term(pR.x, psc0.x, psc0.y);               // LogoScan.hpp:305-308
             pdst[kPairRowPitch] = score_term(pR.y, psc1.x, psc1.y);
         }
@@ -338,35 +183,25 @@ void logo_eval_pair_kernel(const PairLaunch A)
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // (timing build: the wait for the raw samples on its own)
         AMT_PTICK(7);
 #endif
-        convert();
+        st.convert();
         AMT_PTICK(0);
         // ---- 2. the next iteration's raw samples travel during the evaluation (past the last iteration: a repeat nobody reads) ----
         if (band_end && b + 1 < nbands) {
-            fetch_tile(T, b + 1);
-            setup_units(T);
+            fetch_tile(T, tiles + (b + 1) * kTileWaves);
+            st.setup_units(T, lane);
         }
-        request(band_end ? 0 : g + 1);
+        st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + (band_end ? 0 : g + 1)));
         AMT_PTICK(1);
         // ---- 3. both fades of the frame: one packed window evaluation ----
         // (the taps are loop-invariant: LICM would hoist their {k,k} broadcasts and keep 50 registers of copies; the empty asm
         //  makes them opaque per iteration and the broadcast folds into the multiply's op_sel)
 #pragma unroll
-        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
+        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(px.Kp[j]));
         f2 W[25];
-        window_reads(wrow, W);
-        // the column sums ((r0+r1)+(r2+r3))+r4 of the window means (ComputeKernel.cpp:88-94) start as the rows arrive
-        f2 c01[5], c[5];
-        window_rows_ready<15, 0, 2>(W);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) c01[i] = W[i] + W[5 + i];
-        window_rows_ready<5, 2, 2>(W);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) c[i] = c01[i] + (W[10 + i] + W[15 + i]);
-        window_rows_ready<0, 4, 1>(W);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) c[i] = c[i] + W[20 + i];
-        const f2 M = div25_pk(((c[0] + c[4]) + c[2]) + (c[1] + c[3]));          // hsum256_ps order, /25 (ComputeKernel.cpp:54-74,98)
-        const f2 R = window_corr_exact(Kp, W, M);
+        unsigned wrow[5];
+        px.rows(wrow);
+        const f2 M = window_load_means(wrow, W);
+        const f2 R = window_corr_exact(px.Kp, W, M);
 #ifdef AMT_PAIR_TIMING
         { f2 Rt = R; asm volatile("" : "+v"(Rt)); }
 #endif
@@ -374,9 +209,9 @@ void logo_eval_pair_kernel(const PairLaunch A)
         // ---- 4. the previous iteration's terms -> the band's score rows, at the pixel's raster position; then this iteration's two
         //      scale gathers go straight into the registers the terms were read from (a copy would wait for them here) ----
         flush_terms();
-        psc0 = gld<f2>(gSc, __umul24(score_bin_bounded(M.x), nslots8) + slot8);
-        psc1 = gld<f2>(gSc, __umul24(score_bin_bounded(M.y), nslots8) + slot8);
-        pR = R; pact = act;
+        psc0 = gld<f2>(gSc, __umul24(score_bin_bounded(M.x), nslots8) + px.slot8);
+        psc1 = gld<f2>(gSc, __umul24(score_bin_bounded(M.y), nslots8) + px.slot8);
+        pR = R; pact = px.act;
         AMT_PTICK(3);
         prow = (b & 1) * 2 * G + g * 2;
         if (band_end) {
@@ -384,7 +219,7 @@ void logo_eval_pair_kernel(const PairLaunch A)
             pact = false;
             // the band's last evaluation is done: the next band's pixel and taps travel across the barrier
             ++b; g = 0;
-            if (b < nbands) load_pixel(b, T);
+            if (b < nbands) px.load(Xp, (unsigned)(b * kTileWaves + wave) * 64u + (unsigned)lane, T, plane_base);
             AMT_PTICK(4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             AMT_PTICK(5);

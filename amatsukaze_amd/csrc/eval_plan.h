@@ -34,18 +34,7 @@ struct EvalLogoDev {
     int lp;                  // LDS row pitch in floats: ((w+31)&~31)+8
 };
 
-// ---- linear (decision-guarded) evaluation, eval_linear_kernels.hip: one mask pixel per thread ----
-constexpr int kLinThreads = 512;    // threads per workgroup = mask pixels per band
-constexpr int kLinBandPix = kLinThreads;
-constexpr int kLinBandRows = 2 * (kLinThreads / 64);   // rows a band may touch: each wave stages two rows per iteration
-constexpr int kLinMaxFades = 12;    // fades per launch (11 for AMTAnalyzeLogo)
-constexpr int kLinPlaneCap = 3200;  // pairs an LDS plane holds (8 B each; 12 rows of a 256-wide logo): two {s,bg} planes + one {a,b}
-                                    // plane + the sums = 78 KB per workgroup, two workgroups per CU
-struct LinLogoDev {
-    const float2* kpix;      // [13][count_pad]  taps of mask pixel m as pairs {k[2j], k[2j+1]} (k[25] = 0), pair-major
-    const uint32_t* pos;     // [count_pad]  (y << 16) | x of mask pixel m
-    int band0, nbands;       // this logo's PIXEL bands in the linear band table (EvalBand: m0 / npix / y0 / nrows; s0, nslots unused)
-};
+constexpr int kLinMaxFades = 12;    // fades the linear kernel's source is written for (11 for AMTAnalyzeLogo, the instantiated case)
 
 // a band = up to kEvalThreads consecutive run slots (one per thread) and the logo rows their windows touch
 struct EvalBand {

@@ -69,10 +69,10 @@ if a.what == "scan":
     print("  total                                    " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
     sys.exit(0)
 if a.what != "scan" and a.mode != "exact":
-    ln = ["band start (pixel, taps)", "request raw rows (LDS-direct)", "fold sums, window evaluation", "fades (gathers, terms, fix-up)",
-          "coefficients, DPP wave sums", "wait for / pick up the raw rows", "convert -> {s,bg}", "wait at the barrier"]
+    ln = ["loop bookkeeping", "next tile + request raw samples", "window reads + evaluation of s and bg", "fades (gathers, terms, fix-up)",
+          "DPP wave sums -> running sums", "tile end: next pixel + taps", "convert raw -> {s,bg}", "-"]
     tot = t.sum(1)
-    print("linear kernel: cycles (s_memtime ticks) of a workgroup of the deint logo; waves 0, 3, 5, 7:")
+    print("linear kernel: cycles (s_memtime ticks) of a workgroup of the deint logo; waves 0, 2, 4, 5:")
     for k in range(8):
         print(f"  {ln[k]:36s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
     print("  total                                " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
