@@ -137,5 +137,10 @@ def test_bench_multi_rank_control_flow_dry_run():
         assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
         ss = line["strong_scan"]
         assert ss["n_gpus"] == 2 and ss["verified"]["sharded_equals_single_launch"] and ss["verified"]["equals_cpu_oracle"]
+        sl = ss["scanlogo"]                              # the sharded "full LogoScan" of the same stream: quota hand-out + 3 all-reduces
+        assert sl["n_gpus"] == 2 and len(sl["lgd_sha256"]) == 64
+        lgd_hashes = locals().setdefault("lgd_hashes", set())
+        lgd_hashes.add(sl["lgd_sha256"])
         if scaling == "weak":
-            assert line["verified"]["ok"]
+            assert line["verified"]["ok"] and line["verified"]["tolerance_ok"] and line["verified"]["fades_equal_all"]
+    assert len(lgd_hashes) == 1          # the weak line's attached strong scan and the strong line scanned the same stream

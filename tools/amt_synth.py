@@ -203,18 +203,29 @@ def make_clip_np(N: int, W: int, H: int, seed: int, alpha=None, alphaUV=None, im
 # ------------------------------------------------------------------------------------------------
 def make_clip_torch(N: int, W: int, H: int, seed: int, alpha, alphaUV, imgx: int, imgy: int, device,
                     bits: int = 8, period: int = 900, fade: int = 12, pitchY: int | None = None,
-                    pitchUV: int | None = None, start: int = 0, chunk: int = 64, cadence: str = "30i", chroma: bool = True):
-    """chroma=False: Y plane only (the all-frames LogoFrame scan reads nothing else); U/V come back as None."""
+                    pitchUV: int | None = None, start: int = 0, chunk: int = 64, cadence: str = "30i", chroma: bool = True,
+                    rows: tuple | None = None, flat_every: int = 0, noise: str = "white"):
+    """chroma=False: Y plane only (the all-frames LogoFrame scan reads nothing else); U/V come back as None.
+    rows=(y0, y1) (both even): only those luma rows (and chroma rows y0/2 .. y1/2) are generated and stored -- the same samples the
+    full frames hold there; for passes that read nothing but the logo rectangle's rows.
+    flat_every=k: one frame in k (by a hash of its index) gets a flat background over the logo rectangle with a flat 2-px ring just
+    inside its border, so that LogoScan::AddFrame accepts it (LogoScan.hpp:616-649) -- as make_clip_np does.
+    noise="white": every sample of every field time gets its own +-22 noise value (the logo passes' default: nothing in them looks at
+    neighbouring rows of the whole frame); noise="soft": band-limited grain -- 4x4 blocks, +-7, plus +-1 per sample -- as SURVEY.md 8d
+    specifies for the clips the field-difference / combing detectors are run on (white noise of that size buries the combing signal)."""
     import torch
     dt = torch.uint8 if bits <= 8 else torch.int16
     maxv = (1 << bits) - 1
     pitchY = pitchY or W
     pitchUV = pitchUV or W // 2
-    Ys = torch.zeros((N, H, pitchY), dtype=dt, device=device)
-    Us = torch.zeros((N, H // 2, pitchUV), dtype=dt, device=device) if chroma else None
-    Vs = torch.zeros((N, H // 2, pitchUV), dtype=dt, device=device) if chroma else None
-    yy = torch.arange(H, device=device, dtype=torch.int64)[:, None]
+    ry0, ry1 = rows if rows is not None else (0, H)
+    assert ry0 % 2 == 0 and ry1 % 2 == 0 and 0 <= ry0 < ry1 <= H
+    Ys = torch.zeros((N, ry1 - ry0, pitchY), dtype=dt, device=device)
+    Us = torch.zeros((N, (ry1 - ry0) // 2, pitchUV), dtype=dt, device=device) if chroma else None
+    Vs = torch.zeros((N, (ry1 - ry0) // 2, pitchUV), dtype=dt, device=device) if chroma else None
+    yy = torch.arange(ry0, ry1, device=device, dtype=torch.int64)[:, None]
     xx = torch.arange(W, device=device, dtype=torch.int64)[None, :]
+    imgy = imgy - ry0                       # the rectangle's first row within the generated rows
     al = torch.as_tensor(alpha, dtype=torch.float32, device=device) if alpha is not None else None
     alc = torch.as_tensor(alphaUV, dtype=torch.float32, device=device) if alphaUV is not None else None
     par = (yy % 2)
@@ -231,7 +242,10 @@ def make_clip_torch(N: int, W: int, H: int, seed: int, alpha, alphaUV, imgx: int
         else:
             t = 2 * n + par
         sv = (scene * 2654435761 + seed) & 0x7FFFFFFF
-        base = 40 + (120 * ((xx * 3 + yy * 2 + (sv & 0xFF)) % (W + H))) // (W + H)
+        if noise == "soft":     # the detectors' clip: a scene change replaces the picture (slope and phase of the ramp), not just shifts it
+            base = 40 + (120 * ((xx * (1 + sv % 5) + yy * (1 + (sv >> 3) % 4) + (sv & 0xFFF)) % (W + H))) // (W + H)
+        else:
+            base = 40 + (120 * ((xx * 3 + yy * 2 + (sv & 0xFF)) % (W + H))) // (W + H)
         bx = ((sv & 0x3FF) + 7 * t) % max(1, W - 160)
         by = (((sv >> 10) & 0x1FF) + 3 * t) % max(1, H - 120)
         box = (xx >= bx) & (xx < bx + 160) & (yy >= by) & (yy < by + 120)
@@ -239,14 +253,37 @@ def make_clip_torch(N: int, W: int, H: int, seed: int, alpha, alphaUV, imgx: int
         hsh = (yy * W + xx + t * 40503 + sv * 69069)
         hsh = (hsh ^ (hsh >> 13)) * 1274126177
         hsh = (hsh ^ (hsh >> 16)) & 0xFFFFFFFF
-        noise = (hsh & 0xF) + ((hsh >> 4) & 0xF) + ((hsh >> 8) & 0xF) - 22
-        Y = (base + noise).clamp(0, 255).to(torch.float32) * (maxv / 255.0)
+        if noise == "soft":
+            hb = ((yy >> 2) * ((W >> 2) + 1) + (xx >> 2) + t * 40503 + sv * 69069)
+            hb = (hb ^ (hb >> 13)) * 1274126177
+            hb = (hb ^ (hb >> 16)) & 0xFFFFFFFF
+            nz = (hb & 7) + ((hb >> 4) & 7) - 7 + (hsh & 3) - 1
+        else:
+            nz = (hsh & 0xF) + ((hsh >> 4) & 0xF) + ((hsh >> 8) & 0xF) - 22
+        Y = (base + nz).clamp(0, 255).to(torch.float32) * (maxv / 255.0)
         if chroma:
             hc = hsh[:, 0::2, 0::2]
             cxx = xx[:, 0::2] // 2
             cyy = yy[0::2] // 2
             U = (128 + ((cxx + scene * 13) % 41) - 20 + ((hc >> 12) & 7) - 3).to(torch.float32) * (maxv / 255.0)
             V = (128 + ((cyy + scene * 7) % 37) - 18 + ((hc >> 16) & 7) - 3).to(torch.float32) * (maxv / 255.0)
+        if al is not None and flat_every:
+            h, w = al.shape
+            hv = ((n * 2654435761 + seed) ^ ((n >> 3) * 40503)) & 0x7FFFFFFF
+            flat = (hv % flat_every) == 0
+            lvl = (16 + (hv >> 8) % 180).to(torch.float32) * (maxv / 255.0)
+            r = Y[:, imgy:imgy + h, imgx:imgx + w]
+            fr = (lvl.round() + ((r.long() % 5) - 2).to(torch.float32)).clamp(0, maxv)
+            ring = torch.zeros((1, h, w), dtype=torch.bool, device=device)
+            ring[:, :2, :] = True; ring[:, -2:, :] = True; ring[:, :, :2] = True; ring[:, :, -2:] = True
+            fr = torch.where(ring, lvl.round().expand_as(fr), fr)
+            Y[:, imgy:imgy + h, imgx:imgx + w] = torch.where(flat, fr, r)
+            if chroma:
+                cu = ((112 + (hv >> 20) % 32).to(torch.float32) * (maxv / 255.0)).round()
+                cv = ((112 + (hv >> 28) % 8 * 4).to(torch.float32) * (maxv / 255.0)).round()
+                for P, cval in ((U, cu), (V, cv)):
+                    r = P[:, imgy // 2:imgy // 2 + h // 2, imgx // 2:imgx // 2 + w // 2]
+                    P[:, imgy // 2:imgy // 2 + h // 2, imgx // 2:imgx // 2 + w // 2] = torch.where(flat, cval.expand_as(r), r)
         if al is not None:
             h, w = al.shape
             vis = torch.as_tensor(logo_presence(np.arange(start + c0, start + c1), period, fade),
