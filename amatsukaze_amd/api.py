@@ -151,8 +151,14 @@ class AmtsFile:
         self.lib.amtgpu_amts_get_info(self.h, _p(info), C.byref(nf), C.byref(na))
         self.info = dict(zip(self.INFO, map(int, info)))
         self.num_frames, self.num_audio_frames = nf.value, na.value
-        b1, b2 = C.create_string_buffer(4096), C.create_string_buffer(4096)
-        self.lib.amtgpu_amts_get_paths(self.h, b1, 4096, b2, 4096)
+        cap = 4096
+        while True:                                    # (a path is at most 3 UTF-8 bytes per UTF-16 unit: 32 767 units -> < 128 KiB)
+            b1, b2 = C.create_string_buffer(cap), C.create_string_buffer(cap)
+            if self.lib.amtgpu_amts_get_paths(self.h, b1, cap, b2, cap):
+                break
+            if cap >= (1 << 20):
+                raise AmtError(f"{path}: source / audio path does not fit {cap} bytes")
+            cap *= 4
         self.srcpath, self.audiopath = b1.value.decode("utf-8"), b2.value.decode("utf-8")
 
     def frames(self):
@@ -449,7 +455,7 @@ class FrameStats:
 
     def __init__(self, ctx: Context, width, height, bits=8):
         self.ctx, self.width, self.height, self.bits = ctx, width, height, bits
-        self.h = ctx.lib.amtgpu_framestats_create(ctx.h, width, height, bits, 0, 0)
+        self.h = ctx.lib.amtgpu_framestats_create(ctx.h, width, height, bits)
         ctx.check(self.h, "FrameStats")
 
     def run_device(self, Y, out, prevY=None):

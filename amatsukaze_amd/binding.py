@@ -40,6 +40,15 @@ SIGNATURES = {
     "amtgpu_frames_upload_wait": (c_i, [c_p]),
     "amtgpu_download": (c_i, [c_p, c_p, c_p, c_u64]),
     "amtgpu_download_strided": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_u64, c_i]),
+    "amtgpu_frames_upload_gather": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_u64, c_i, c_i]),
+    "amtgpu_download_pinned": (c_i, [c_p, c_p, c_u64, c_p]),
+    "amtgpu_marker_record": (c_i, [c_p, c_i]),
+    "amtgpu_marker_wait": (c_i, [c_p, c_i]),
+    "amtgpu_logo_loadW": (c_p, [c_p, c_p]),
+    "amtgpu_logo_saveW": (c_i, [c_p, c_p, c_p, c_s, c_i]),
+    "amtgpu_logo_get_header": (c_i, [c_p, c_p, c_i, c_p]),
+    "amtgpu_logo_set_header": (c_i, [c_p, c_s, c_i]),
+    "amtgpu_scanlogo_fileW": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
     "amtgpu_weave_fields_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
                                         c_i64, c_i64, c_i, c_i, c_i]),
     "amtgpu_amts_load": (c_p, [c_p, c_s]),
@@ -83,6 +92,7 @@ SIGNATURES = {
     "amtgpu_erase_get_rect": (c_i, [c_p, c_p]),
     "amtgpu_analyze_get_rect": (c_i, [c_p, c_p]),
     "amtgpu_logoframe_get_rows": (c_i, [c_p, c_p]),
+    "amtgpu_logoframe_get_columns": (c_i, [c_p, c_p]),
     "amtgpu_logoscan_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
     "amtgpu_logoscan_destroy": (None, [c_p]),
     "amtgpu_logoscan_add_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
@@ -94,7 +104,7 @@ SIGNATURES = {
     "amtgpu_scanlogo_file": (c_i, [c_p, c_s, c_i, c_s, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
     "amtgpu_logoframe_allgather_results": (c_i, [c_p, c_p, c_i, c_i]),
     "amtgpu_scanlogo_sharded": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_s, c_i, c_i, c_i, c_i, c_i, c_i, CB]),
-    "amtgpu_framestats_create": (c_p, [c_p, c_i, c_i, c_i, c_i, c_i]),
+    "amtgpu_framestats_create": (c_p, [c_p, c_i, c_i, c_i]),
     "amtgpu_framestats_destroy": (None, [c_p]),
     "amtgpu_framestats_batch": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_i, c_p]),
     "amtgpu_cm_scene_changes": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),

@@ -45,6 +45,8 @@ void amtgpu_context_destroy(AmtGpuContext* c)
     for (auto& sp : c->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_down) (void)hipHostFree(c->pinned_down);
+    for (auto& e : c->markers) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->slot_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -62,7 +64,8 @@ int amtgpu_context_set_stream(AmtGpuContext* c, void* s)
     else c->stream = s ? (hipStream_t)s : c->own_stream;
     return 1;
 }
-void* amtgpu_context_get_stream(AmtGpuContext* c) { return c ? (void*)c->stream : nullptr; }
+// (the legacy default stream is reported by its sentinel, so that set_stream(get_stream()) is an identity)
+void* amtgpu_context_get_stream(AmtGpuContext* c) { return !c ? nullptr : (c->stream ? (void*)c->stream : AMTGPU_STREAM_LEGACY_DEFAULT); }
 int amtgpu_context_synchronize(AmtGpuContext* c)
 {
     return guard(c, [&] { c->bind(); AMT_HIP(hipStreamSynchronize(c->stream)); });
@@ -114,25 +117,39 @@ void amtgpu_device_free(AmtGpuContext* c, void* p)
 
 // host -> pinned slot (memcpy) -> device (hipMemcpyAsync on the side stream); two slots so that the CPU
 // fills one while the DMA engine drains the other
+namespace {
+constexpr size_t kSlotBytes = 32u << 20;
+// `n` bytes (<= kSlotBytes) of the slot being filled.  A slot that cannot take them is closed -- an event behind its last copy -- and
+// the other one, once ITS copies have drained, becomes the slot being filled.  Small uploads (one frame's logo rows) thus share a
+// slot and cost a memcpy and a copy launch each, no event wait.
+uint8_t* stage_acquire(AmtGpuContext* c, size_t n)
+{
+    if (!c->pinned) {
+        AMT_HIP(hipHostMalloc(&c->pinned, kSlotBytes * 2, hipHostMallocDefault));
+        c->pinned_bytes = kSlotBytes;
+    }
+    if (c->slot_fill + n > kSlotBytes) {
+        AMT_HIP(hipEventRecord(c->slot_free[c->next_slot], c->copy_stream));
+        c->next_slot ^= 1;
+        AMT_HIP(hipEventSynchronize(c->slot_free[c->next_slot]));
+        c->slot_fill = 0;
+    }
+    uint8_t* p = (uint8_t*)c->pinned + (size_t)c->next_slot * kSlotBytes + c->slot_fill;
+    c->slot_fill += (n + 255) & ~(size_t)255;
+    return p;
+}
+} // namespace
+
 int amtgpu_frames_upload(AmtGpuContext* c, void* ddst, const void* hsrc, uint64_t bytes)
 {
     return guard(c, [&] {
         c->bind();
-        const size_t slot_bytes = 32u << 20;
-        if (!c->pinned) {
-            AMT_HIP(hipHostMalloc(&c->pinned, slot_bytes * 2, hipHostMallocDefault));
-            c->pinned_bytes = slot_bytes;
-        }
         uint64_t done = 0;
         while (done < bytes) {
-            const size_t n = (size_t)std::min<uint64_t>(slot_bytes, bytes - done);
-            const int s = c->next_slot;
-            AMT_HIP(hipEventSynchronize(c->slot_free[s]));
-            uint8_t* stage = (uint8_t*)c->pinned + (size_t)s * slot_bytes;
+            const size_t n = (size_t)std::min<uint64_t>(kSlotBytes, bytes - done);
+            uint8_t* stage = stage_acquire(c, n);
             std::memcpy(stage, (const uint8_t*)hsrc + done, n);
             AMT_HIP(hipMemcpyAsync((uint8_t*)ddst + done, stage, n, hipMemcpyHostToDevice, c->copy_stream));
-            AMT_HIP(hipEventRecord(c->slot_free[s], c->copy_stream));
-            c->next_slot ^= 1;
             done += n;
         }
         AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
@@ -148,26 +165,47 @@ int amtgpu_frames_upload_strided(AmtGpuContext* c, void* ddst, int64_t dst_strid
 {
     return guard(c, [&] {
         c->bind();
-        const size_t slot_bytes = 32u << 20;
         if (chunk_bytes == 0 || nchunks <= 0) return;
-        if (chunk_bytes > slot_bytes) throw std::runtime_error("chunk larger than a staging slot");
+        if (chunk_bytes > kSlotBytes) throw std::runtime_error("chunk larger than a staging slot");
         if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
-        if (!c->pinned) {
-            AMT_HIP(hipHostMalloc(&c->pinned, slot_bytes * 2, hipHostMallocDefault));
-            c->pinned_bytes = slot_bytes;
-        }
-        const int per_slot = (int)(slot_bytes / chunk_bytes);
+        const int per_slot = (int)(kSlotBytes / chunk_bytes);
         for (int i0 = 0; i0 < nchunks; i0 += per_slot) {
             const int n = std::min(per_slot, nchunks - i0);
-            const int s = c->next_slot;
-            AMT_HIP(hipEventSynchronize(c->slot_free[s]));
-            uint8_t* stage = (uint8_t*)c->pinned + (size_t)s * slot_bytes;
+            uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
             for (int i = 0; i < n; ++i)
                 std::memcpy(stage + (size_t)i * chunk_bytes, (const uint8_t*)hsrc + (size_t)(i0 + i) * src_stride, chunk_bytes);
             AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
                                      hipMemcpyHostToDevice, c->copy_stream));
-            AMT_HIP(hipEventRecord(c->slot_free[s], c->copy_stream));
-            c->next_slot ^= 1;
+        }
+        AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
+        c->copies_pending = true;
+    });
+}
+
+// `nsrc` sources of `chunks_per_src` pieces each (e.g. the logo rectangle's rows of nsrc separately allocated host frames) to
+// destinations that continue one another: piece j of source i lands at ddst + (i * chunks_per_src + j) * dst_stride.  Packed into
+// the pinned ring and sent as one 2-D copy per slot -- one call and one copy launch for a whole group of frames
+int amtgpu_frames_upload_gather(AmtGpuContext* c, void* ddst, int64_t dst_stride, const void* const* hsrc, int64_t src_stride,
+                                uint64_t chunk_bytes, int chunks_per_src, int nsrc)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (chunk_bytes == 0 || chunks_per_src <= 0 || nsrc <= 0) return;
+        if (!hsrc) throw std::runtime_error("null source list");
+        if (chunk_bytes > kSlotBytes) throw std::runtime_error("chunk larger than a staging slot");
+        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
+        const int64_t total = (int64_t)chunks_per_src * nsrc;
+        const int64_t per_slot = (int64_t)(kSlotBytes / chunk_bytes);
+        for (int64_t i0 = 0; i0 < total; i0 += per_slot) {
+            const int64_t n = std::min(per_slot, total - i0);
+            uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t q = i0 + i;
+                std::memcpy(stage + (size_t)i * chunk_bytes, (const uint8_t*)hsrc[q / chunks_per_src] + (size_t)(q % chunks_per_src) * src_stride,
+                            chunk_bytes);
+            }
+            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
+                                     hipMemcpyHostToDevice, c->copy_stream));
         }
         AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
         c->copies_pending = true;
@@ -204,6 +242,46 @@ int amtgpu_download_strided(AmtGpuContext* c, void* hdst, int64_t dst_stride, co
     });
 }
 
+// device -> a pinned landing buffer of the context in ONE asynchronous copy + one wait; *hptr stays valid until the next call.  For
+// callers that scatter the bytes into several host frames themselves (AMTEraseLogo's block of erased rectangles)
+int amtgpu_download_pinned(AmtGpuContext* c, const void* dsrc, uint64_t bytes, const void** hptr)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (!hptr) throw std::runtime_error("null result pointer");
+        if (bytes > c->pinned_down_bytes) {
+            if (c->pinned_down) { (void)hipHostFree(c->pinned_down); c->pinned_down = nullptr; c->pinned_down_bytes = 0; }
+            AMT_HIP(hipHostMalloc(&c->pinned_down, (size_t)bytes, hipHostMallocDefault));
+            c->pinned_down_bytes = (size_t)bytes;
+        }
+        if (bytes) {
+            AMT_HIP(hipMemcpyAsync(c->pinned_down, dsrc, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+            AMT_HIP(hipStreamSynchronize(c->stream));
+        }
+        *hptr = c->pinned_down;
+    });
+}
+
+// markers on the compute stream: record(id) after a batch's launches, wait(id) on the host before the batch's device buffer is
+// written again -- what a double-buffered caller needs instead of amtgpu_context_synchronize (which also waits for the NEXT batch)
+int amtgpu_marker_record(AmtGpuContext* c, int id)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (id < 0 || id >= 16) throw std::runtime_error("marker id out of range (0..15)");
+        if (!c->markers[id]) AMT_HIP(hipEventCreateWithFlags(&c->markers[id], hipEventDisableTiming));
+        AMT_HIP(hipEventRecord(c->markers[id], c->stream));
+    });
+}
+int amtgpu_marker_wait(AmtGpuContext* c, int id)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (id < 0 || id >= 16) throw std::runtime_error("marker id out of range (0..15)");
+        if (c->markers[id]) AMT_HIP(hipEventSynchronize(c->markers[id]));          // never recorded: nothing to wait for
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 // logo model
 // ---------------------------------------------------------------------------------------------
@@ -212,6 +290,24 @@ AmtGpuLogo* amtgpu_logo_load(AmtGpuContext* c, const char* path)
     AmtGpuLogo* l = nullptr;
     guard(c, [&] { l = new AmtGpuLogo{load_lgd(path)}; });
     return l;
+}
+AmtGpuLogo* amtgpu_logo_loadW(AmtGpuContext* c, const uint16_t* path) { return amtgpu_logo_load(c, amt_utf8_from_utf16z(path).c_str()); }
+int amtgpu_logo_get_header(const AmtGpuLogo* l, char* name, int name_cap, int* serviceId)
+{
+    if (!l) return 0;
+    if (name) {
+        if ((int)l->planes.name.size() + 1 > name_cap) return 0;
+        std::memcpy(name, l->planes.name.c_str(), l->planes.name.size() + 1);
+    }
+    if (serviceId) *serviceId = l->planes.serviceId;
+    return 1;
+}
+int amtgpu_logo_set_header(AmtGpuLogo* l, const char* name, int serviceId)
+{
+    if (!l) return 0;
+    if (name) l->planes.name = std::string(name).substr(0, 254);          // char name[255] (AMTLogo.hpp:26)
+    l->planes.serviceId = serviceId;
+    return 1;
 }
 
 AmtGpuLogo* amtgpu_logo_from_planes(AmtGpuContext* c, int w, int h, int logUVx, int logUVy, int imgw, int imgh,
@@ -233,6 +329,10 @@ AmtGpuLogo* amtgpu_logo_from_planes(AmtGpuContext* c, int w, int h, int logUVx, 
 int amtgpu_logo_save(AmtGpuContext* c, const AmtGpuLogo* l, const char* path, const char* name, int serviceId)
 {
     return guard(c, [&] { save_lgd(l->planes, path, name ? name : "", serviceId); });
+}
+int amtgpu_logo_saveW(AmtGpuContext* c, const AmtGpuLogo* l, const uint16_t* path, const char* name, int serviceId)
+{
+    return amtgpu_logo_save(c, l, amt_utf8_from_utf16z(path).c_str(), name, serviceId);
 }
 void amtgpu_logo_destroy(AmtGpuLogo* l) { delete l; }
 
@@ -390,6 +490,17 @@ int amtgpu_logoframe_get_rows(const AmtGpuLogoFrame* lf, int* out2)
     return 1;
 }
 
+int amtgpu_logoframe_get_columns(const AmtGpuLogoFrame* lf, int* out2)
+{
+    if (!lf || !out2) return 0;
+    int lo = 0x7FFFFFFF, hi = 0;
+    for (const auto& l : lf->logos)
+        if (l) { lo = std::min(lo, l->imgx); hi = std::max(hi, l->imgx + l->w); }
+    if (lo >= hi) { lo = 0; hi = 0; }
+    out2[0] = lo; out2[1] = hi;
+    return 1;
+}
+
 int amtgpu_logoframe_get_results(AmtGpuLogoFrame* lf, float* out)
 {
     return guard(lf->ctx, [&] {
@@ -417,24 +528,40 @@ int amtgpu_logoframe_set_results(AmtGpuLogoFrame* lf, int first, int nframes, co
 int amtgpu_logoframe_allgather_results(AmtGpuLogoFrame* lf, const AmtGpuCollectives* coll, int first, int nlocal)
 {
     return guard(lf->ctx, [&] {
-        if (first < 0 || nlocal < 0 || first + nlocal > lf->numFrames) throw std::runtime_error("frame range outside the clip");
-        if (!coll || coll->world <= 1) return;
+        if (!coll || coll->world <= 1) {
+            if (first < 0 || nlocal < 0 || first + nlocal > lf->numFrames) throw std::runtime_error("frame range outside the clip");
+            return;
+        }
         if (!coll->allgather) throw std::runtime_error("AmtGpuCollectives incomplete");
-        logoframe_sync_results(lf);
+        // A rank whose own work failed must still enter every collective (the others would block in it for ever): what is wrong
+        // here travels as a status word next to the rank's range, and every rank throws after the exchange.
+        std::string local_error;
+        try {
+            if (first < 0 || nlocal < 0 || first + nlocal > lf->numFrames) throw std::runtime_error("frame range outside the clip");
+            logoframe_sync_results(lf);
+        } catch (const std::exception& e) { local_error = e.what(); }
         const size_t rec = lf->logos.size() * 2;                               // floats per frame
-        // ragged shards: gather {first, nlocal}, then records padded to the largest shard
-        const int64_t mine[2] = {first, nlocal};
-        std::vector<int64_t> ranges((size_t)coll->world * 2);
+        // ragged shards: gather {first, nlocal, ok}, then records padded to the largest shard
+        const int64_t mine[3] = {local_error.empty() ? first : 0, local_error.empty() ? nlocal : 0, local_error.empty() ? 1 : 0};
+        std::vector<int64_t> ranges((size_t)coll->world * 3);
         if (!coll->allgather(coll->user, mine, ranges.data(), sizeof mine)) throw std::runtime_error("allgather failed");
         int64_t nmax = 0;
-        for (int r = 0; r < coll->world; ++r) nmax = std::max(nmax, ranges[2 * r + 1]);
+        bool all_ok = true, ranges_ok = true;
+        for (int r = 0; r < coll->world; ++r) {
+            const int64_t f = ranges[3 * r], n = ranges[3 * r + 1];
+            all_ok = all_ok && ranges[3 * r + 2] == 1;
+            ranges_ok = ranges_ok && f >= 0 && n >= 0 && f + n <= lf->numFrames;
+            nmax = std::max(nmax, n);
+        }
+        if (!local_error.empty()) throw std::runtime_error(local_error);
+        if (!all_ok) throw std::runtime_error("another rank failed before the exchange of the scan records");
+        if (!ranges_ok) throw std::runtime_error("a rank reported a frame range outside the clip");
         if (nmax == 0 || rec == 0) return;
         std::vector<float> send((size_t)nmax * rec, 0.0f), recv((size_t)nmax * rec * coll->world);
         std::memcpy(send.data(), lf->results.data() + (size_t)first * rec, (size_t)nlocal * rec * sizeof(float));
         if (!coll->allgather(coll->user, send.data(), recv.data(), (int64_t)(send.size() * sizeof(float)))) throw std::runtime_error("allgather failed");
         for (int r = 0; r < coll->world; ++r) {
-            const int64_t f = ranges[2 * r], n = ranges[2 * r + 1];
-            if (f < 0 || n < 0 || f + n > lf->numFrames) throw std::runtime_error("a rank reported a frame range outside the clip");
+            const int64_t f = ranges[3 * r], n = ranges[3 * r + 1];
             std::memcpy(lf->results.data() + (size_t)f * rec, recv.data() + (size_t)r * nmax * rec, (size_t)n * rec * sizeof(float));
         }
         lf->ctx->bind();

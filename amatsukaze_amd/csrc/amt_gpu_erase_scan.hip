@@ -157,8 +157,12 @@ static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t 
     g.cx = rect_only ? 0 : P.imgx >> P.logUVx; g.cy = rect_only ? 0 : P.imgy >> P.logUVy;
     g.uvparity = (P.imgy / 2) % 2;
     const int sp = er->ctx->prof_begin("delogo_kernel");
+    // fade 0 returns a sample unchanged only while the sample is <= maxv: min(tmp + 0.5, maxv) (LogoScan.hpp:1258) clamps a 10- or
+    // 12-bit clip's out-of-range container values.  At 8 and 16 bits every container value is in range: only there are fade-0
+    // frames skipped.
+    const bool skip_fade0 = er->zeroIdentity && (bits == 8 || bits == 16);
     AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
-                          nframes, er->dFades[slot].get(), er->zeroIdentity ? 1 : 0));
+                          nframes, er->dFades[slot].get(), skip_fade0 ? 1 : 0));
     er->ctx->prof_end(sp);
 }
 
@@ -350,29 +354,60 @@ AmtGpuLogo* amtgpu_logoscan_get_logo(AmtGpuLogoScan* s, int maxv, int clean, int
 
 namespace {
 
-// sums of all ranks -> every rank (px sums, plane sums, frame count, and a cancel flag riding along)
-void reduce_scan(AmtGpuLogoScan* s, const AmtGpuCollectives* coll, int64_t& cancel)
+// A sharded run must never leave ranks behind in a collective: a rank whose own work threw (a HIP error, a bad argument, a
+// cancelled callback) keeps entering every exchange with neutral data, its status rides along, and ALL ranks throw right after
+// the exchange in which the status becomes known.
+struct ShardGuard {
+    const AmtGpuCollectives* coll = nullptr;     // nullptr / world 1: plain exceptions
+    std::string error;                           // this rank's failure, if any
+    int64_t cancel = 0;
+    bool sharded() const { return coll && coll->world > 1; }
+    template <typename F> void attempt(F&& fn)
+    {
+        if (!sharded()) { fn(); return; }
+        if (!error.empty()) return;
+        try { fn(); } catch (const std::exception& e) { error = e.what(); } catch (...) { error = "unknown error"; }
+    }
+    int64_t status() const { return (cancel ? 1 : 0) + (error.empty() ? 0 : (int64_t)1 << 32); }
+    // `summed` = sum over ranks of status(): everyone leaves together
+    void agree(int64_t summed) const
+    {
+        if (!error.empty()) throw std::runtime_error(error);
+        if (summed >> 32) throw std::runtime_error("another rank failed; the sharded run was abandoned on every rank");
+        if (summed & 0xFFFFFFFF) throw std::runtime_error("Cancel requested");
+    }
+};
+
+// sums of all ranks -> every rank (px sums, plane sums, frame count, and the ranks' status riding along); npx = 3 * samples of the
+// scan rectangle (known even when this rank has no scan object to contribute)
+void reduce_scan(AmtGpuLogoScan* s, ShardGuard& sg, size_t npx)
 {
-    if (!coll || coll->world <= 1) return;
-    logoscan_pull(s);
-    std::vector<int64_t> buf(s->sums.px.begin(), s->sums.px.end());
-    for (int k = 0; k < 6; ++k) buf.push_back(s->sums.plane[k]);
-    buf.push_back(s->sums.nframes);
-    buf.push_back(cancel);
-    if (!coll->allreduce_sum_i64(coll->user, buf.data(), (int64_t)buf.size())) throw std::runtime_error("allreduce_sum_i64 failed");
-    const size_t npx = s->sums.px.size();
-    cancel = buf[npx + 7];
+    if (!sg.sharded()) return;
+    std::vector<int64_t> buf(npx + 8, 0);
+    sg.attempt([&] {
+        if (!s) throw std::runtime_error("no scan to reduce");
+        logoscan_pull(s);
+        if (s->sums.px.size() != npx) throw std::runtime_error("scan size mismatch");
+        std::copy(s->sums.px.begin(), s->sums.px.end(), buf.begin());
+        for (int k = 0; k < 6; ++k) buf[npx + k] = s->sums.plane[k];
+        buf[npx + 6] = s->sums.nframes;
+    });
+    if (!sg.error.empty()) std::fill(buf.begin(), buf.end(), 0);
+    buf[npx + 7] = sg.status();
+    if (!sg.coll->allreduce_sum_i64(sg.coll->user, buf.data(), (int64_t)buf.size())) throw std::runtime_error("allreduce_sum_i64 failed");
+    sg.agree(buf[npx + 7]);
     if (!amtgpu_logoscan_set_sums(s, buf.data(), buf.data() + npx, (int)buf[npx + 6])) throw std::runtime_error(s->ctx->err);
 }
 
 // ReMakeLogo twice (LogoScan.hpp:923-1036, 1065-1071) over a device-resident clip: `kept` lists the frames round 0 accepted (indices into
 // the clip), whose rectangle sits at (cx, cy); the finished logo's header gets (himgw, himgh, himgx, himgy).
 template <typename Progress>
-std::unique_ptr<AmtGpuLogo> remake_rounds(AmtGpuContext* c, const AmtGpuCollectives* coll, AmtGpuLogoScan* scan0, const void* dY, const void* dU,
+std::unique_ptr<AmtGpuLogo> remake_rounds(AmtGpuContext* c, ShardGuard& sg, AmtGpuLogoScan* scan0, const void* dY, const void* dU,
                                           const void* dV, int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int cx, int cy, int w, int h,
                                           int thy, const std::vector<int>& kept, const std::vector<int4>& keptVerdict, int himgw, int himgh,
-                                          int himgx, int himgy, Progress&& progress, int64_t& cancel)
+                                          int himgx, int himgy, Progress&& progress)
 {
+    const size_t npx = (size_t)3 * ((size_t)w * h + 2 * (size_t)(w / 2) * (h / 2));
     const int bits = 8;
     const int numFrames = (int)kept.size();
     std::unique_ptr<AmtGpuLogo> logo(amtgpu_logoscan_get_logo(scan0, 255, 0, himgw, himgh, himgx, himgy));
@@ -384,33 +419,36 @@ std::unique_ptr<AmtGpuLogo> remake_rounds(AmtGpuContext* c, const AmtGpuCollecti
     DevBuf<float> dEval((size_t)std::max(1, numFrames) * 20);
     std::vector<float> hEval((size_t)numFrames * 20);
     for (int round = 0; round < 2; ++round) {
-        EvalLogoSpec S;
-        S.planes = deinterlaced_logo(logo->planes);
-        S.tables = build_mask_tables(S.planes, 0.1f);
-        S.imgx = cx; S.imgy = cy; S.row0 = 0; S.row_step = 1; S.deint = 1; S.out_off = 0;
-        std::vector<EvalLogoSpec> specs;
-        specs.push_back(std::move(S));
-        EvalEngine eng(c, std::move(specs), fades, true, 20, "logo_eval_fused_kernel.remake");
-        std::vector<uint8_t> use(numFrames, 0);
-        if (numFrames) {
-            eng.run(dY, strideY, pitchY, bits, numFrames, dEval.get(), dMap.get());
-            AMT_HIP(hipMemcpyAsync(hEval.data(), dEval.get(), hEval.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            AMT_HIP(hipStreamSynchronize(c->stream));
-        }
-        for (int i = 0; i < numFrames; ++i) {
-            float best = FLT_MAX;
-            int bestIdx = 0;
-            for (int fi = 0; fi < 20; ++fi)
-                if (hEval[(size_t)i * 20 + fi] < best) { best = hEval[(size_t)i * 20 + fi]; bestIdx = fi; }
-            use[i] = bestIdx > 8;                       // logo clearly present in this frame
-        }
-        progress(50.0f + 25.0f * round + 12.5f, numFrames, numFrames, numFrames);
-        std::unique_ptr<AmtGpuLogoScan> rescan(logoscan_new(c, w, h, 1, 1, thy));
-        if (numFrames)
-            logoscan_add(rescan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, cx, cy, numFrames, numFrames, use.data(), nullptr,
-                         kept.data(), keptVerdict.data());
-        reduce_scan(rescan.get(), coll, cancel);
-        if (cancel) throw std::runtime_error("Cancel requested");
+        std::unique_ptr<AmtGpuLogoScan> rescan;
+        // (the regression that produced `logo` ran on the same reduced sums on every rank: all ranks are here, or none)
+        sg.attempt([&] {
+            EvalLogoSpec S;
+            S.planes = deinterlaced_logo(logo->planes);
+            S.tables = build_mask_tables(S.planes, 0.1f);
+            S.imgx = cx; S.imgy = cy; S.row0 = 0; S.row_step = 1; S.deint = 1; S.out_off = 0;
+            std::vector<EvalLogoSpec> specs;
+            specs.push_back(std::move(S));
+            EvalEngine eng(c, std::move(specs), fades, true, 20, "logo_eval_fused_kernel.remake");
+            std::vector<uint8_t> use(numFrames, 0);
+            if (numFrames) {
+                eng.run(dY, strideY, pitchY, bits, numFrames, dEval.get(), dMap.get());
+                AMT_HIP(hipMemcpyAsync(hEval.data(), dEval.get(), hEval.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                AMT_HIP(hipStreamSynchronize(c->stream));
+            }
+            for (int i = 0; i < numFrames; ++i) {
+                float best = FLT_MAX;
+                int bestIdx = 0;
+                for (int fi = 0; fi < 20; ++fi)
+                    if (hEval[(size_t)i * 20 + fi] < best) { best = hEval[(size_t)i * 20 + fi]; bestIdx = fi; }
+                use[i] = bestIdx > 8;                       // logo clearly present in this frame
+            }
+            progress(50.0f + 25.0f * round + 12.5f, numFrames, numFrames, numFrames);
+            rescan.reset(logoscan_new(c, w, h, 1, 1, thy));
+            if (numFrames)
+                logoscan_add(rescan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, cx, cy, numFrames, numFrames, use.data(), nullptr,
+                             kept.data(), keptVerdict.data());
+        });
+        reduce_scan(rescan.get(), sg, npx);
         logo.reset(amtgpu_logoscan_get_logo(rescan.get(), 255, 1, himgw, himgh, himgx, himgy));
         if (!logo) throw std::runtime_error(c->err);
     }
@@ -425,21 +463,24 @@ int scanlogo_impl(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* d
         const bool sharded = coll && coll->world > 1;
         if (sharded && (!coll->allgather || !coll->allreduce_sum_i64 || coll->rank < 0 || coll->rank >= coll->world))
             throw std::runtime_error("AmtGpuCollectives incomplete");
-        int64_t cancel = 0;
+        ShardGuard sg;
+        sg.coll = sharded ? coll : nullptr;
         auto progress = [&](float p, int nread, int total, int ngather) {
             if (cb && !cb(p, nread, total, ngather)) {
                 if (!sharded) throw std::runtime_error("Cancel requested");
-                cancel = 1;                                     // the other ranks learn about it with the next reduction
+                sg.cancel = 1;                                  // the other ranks learn about it with the next exchange
             }
         };
-        if (imgx < 0 || imgy < 0 || imgx + w > imgw || imgy + h > imgh) throw std::runtime_error("scan rectangle outside the frame");
         const int bits = 8;                                   // the reference's scan path is 8-bit only (:813)
-        std::unique_ptr<AmtGpuLogoScan> scan(logoscan_new(c, w, h, 1, 1, thy));
+        const size_t npx = (size_t)3 * ((size_t)std::max(0, w) * std::max(0, h) + 2 * (size_t)(std::max(0, w) / 2) * (std::max(0, h) / 2));
+        std::unique_ptr<AmtGpuLogoScan> scan;
         std::vector<int> kept;              // frame index (within this rank's frames) of every kept frame
         std::vector<int4> keptVerdict;      // its {1,bgY,bgU,bgV}
         const int chunk = 4096;
         auto at = [&](const void* base, int64_t stride, int f0) { return (const void*)((const uint8_t*)base + (int64_t)f0 * stride); };
         if (!sharded) {
+            if (imgx < 0 || imgy < 0 || imgx + w > imgw || imgy + h > imgh) throw std::runtime_error("scan rectangle outside the frame");
+            scan.reset(logoscan_new(c, w, h, 1, 1, thy));
             // round 0: every frame in stream order until numMaxFrames are kept
             for (int f0 = 0; f0 < nframes && (int)kept.size() < numMaxFrames; f0 += chunk) {
                 const int n = std::min(chunk, nframes - f0);
@@ -452,33 +493,40 @@ int scanlogo_impl(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* d
             }
         } else {
             // round 0, sharded: border verdicts of every local frame (nothing accepted yet: max_valid = 0) ...
-            for (int f0 = 0; f0 < nframes; f0 += chunk) {
-                const int n = std::min(chunk, nframes - f0);
-                logoscan_add(scan.get(), at(dY, strideY, f0), at(dU, strideUV, f0), at(dV, strideUV, f0), strideY, strideUV, pitchY, pitchUV,
-                             bits, imgx, imgy, n, 0, nullptr, nullptr, nullptr, nullptr);
-                for (int i = 0; i < n; ++i)
-                    if (scan->lastVerdicts[i].x) { kept.push_back(f0 + i); keptVerdict.push_back(scan->lastVerdicts[i]); }
-                progress(50.0f * (f0 + n) / std::max(1, nframes), f0 + n, 0, (int)kept.size());
-            }
-            // ... this rank's share of "the first numMaxFrames valid frames of the stream" ...
-            std::vector<int64_t> counts(coll->world, 0);
-            const int64_t mine = (int64_t)kept.size();
-            if (!coll->allgather(coll->user, &mine, counts.data(), sizeof(int64_t))) throw std::runtime_error("allgather failed");
-            int64_t before = 0;
-            for (int r = 0; r < coll->rank; ++r) before += counts[r];
-            const int quota = (int)std::max<int64_t>(0, std::min<int64_t>(mine, (int64_t)numMaxFrames - before));
+            sg.attempt([&] {
+                if (imgx < 0 || imgy < 0 || imgx + w > imgw || imgy + h > imgh) throw std::runtime_error("scan rectangle outside the frame");
+                scan.reset(logoscan_new(c, w, h, 1, 1, thy));
+                for (int f0 = 0; f0 < nframes; f0 += chunk) {
+                    const int n = std::min(chunk, nframes - f0);
+                    logoscan_add(scan.get(), at(dY, strideY, f0), at(dU, strideUV, f0), at(dV, strideUV, f0), strideY, strideUV, pitchY, pitchUV,
+                                 bits, imgx, imgy, n, 0, nullptr, nullptr, nullptr, nullptr);
+                    for (int i = 0; i < n; ++i)
+                        if (scan->lastVerdicts[i].x) { kept.push_back(f0 + i); keptVerdict.push_back(scan->lastVerdicts[i]); }
+                    progress(50.0f * (f0 + n) / std::max(1, nframes), f0 + n, 0, (int)kept.size());
+                }
+            });
+            // ... this rank's share of "the first numMaxFrames valid frames of the stream" (and how every rank is doing) ...
+            std::vector<int64_t> counts((size_t)coll->world * 2, 0);
+            const int64_t mine[2] = {sg.error.empty() ? (int64_t)kept.size() : 0, sg.status()};
+            if (!coll->allgather(coll->user, mine, counts.data(), sizeof mine)) throw std::runtime_error("allgather failed");
+            int64_t before = 0, summed = 0;
+            for (int r = 0; r < coll->world; ++r) summed += counts[2 * r + 1];
+            for (int r = 0; r < coll->rank; ++r) before += counts[2 * r];
+            sg.agree(summed);
+            const int quota = (int)std::max<int64_t>(0, std::min<int64_t>(mine[0], (int64_t)numMaxFrames - before));
             kept.resize(quota);
             keptVerdict.resize(quota);
             // ... accumulated locally, summed over ranks
-            if (quota)
-                logoscan_add(scan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, quota, quota, nullptr, nullptr,
-                             kept.data(), keptVerdict.data());
-            reduce_scan(scan.get(), coll, cancel);
-            if (cancel) throw std::runtime_error("Cancel requested");
+            sg.attempt([&] {
+                if (quota)
+                    logoscan_add(scan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, imgx, imgy, quota, quota, nullptr, nullptr,
+                                 kept.data(), keptVerdict.data());
+            });
+            reduce_scan(scan.get(), sg, npx);
         }
         const int numFrames = (int)kept.size();
-        std::unique_ptr<AmtGpuLogo> logo = remake_rounds(c, coll, scan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, w, h,
-                                                         thy, kept, keptVerdict, imgw, imgh, imgx, imgy, progress, cancel);
+        std::unique_ptr<AmtGpuLogo> logo = remake_rounds(c, sg, scan.get(), dY, dU, dV, strideY, strideUV, pitchY, pitchUV, imgx, imgy, w, h,
+                                                         thy, kept, keptVerdict, imgw, imgh, imgx, imgy, progress);
         progress(1, numFrames, numFrames, numFrames);
         if (dstpath && (!sharded || coll->rank == 0)) save_lgd(logo->planes, dstpath, "No Name", serviceid);
     });
@@ -561,13 +609,19 @@ int amtgpu_scanlogo_file(AmtGpuContext* c, const char* srcpath, int serviceid, c
         }
         std::vector<int> kept(nkept);
         for (int i = 0; i < nkept; ++i) kept[i] = i;
-        int64_t cancel = 0;
-        std::unique_ptr<AmtGpuLogo> logo = remake_rounds(c, nullptr, scan.get(), cropY.get(), cropU.get(), cropV.get(), (int64_t)w * h,
-                                                         (int64_t)wUV * hUV, w, wUV, 0, 0, w, h, thy, kept, keptVerdict, W, H, imgx, imgy, progress,
-                                                         cancel);
+        ShardGuard unsharded;
+        std::unique_ptr<AmtGpuLogo> logo = remake_rounds(c, unsharded, scan.get(), cropY.get(), cropU.get(), cropV.get(), (int64_t)w * h,
+                                                         (int64_t)wUV * hUV, w, wUV, 0, 0, w, h, thy, kept, keptVerdict, W, H, imgx, imgy, progress);
         progress(1, nkept, nkept, nkept);
         save_lgd(logo->planes, dstpath, "No Name", serviceid);
     });
+}
+
+int amtgpu_scanlogo_fileW(AmtGpuContext* c, const uint16_t* srcpath, int serviceid, const uint16_t* workfile, const uint16_t* dstpath, int imgx,
+                          int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb)
+{
+    const std::string src = amt_utf8_from_utf16z(srcpath), work = amt_utf8_from_utf16z(workfile), dst = amt_utf8_from_utf16z(dstpath);
+    return amtgpu_scanlogo_file(c, src.c_str(), serviceid, work.c_str(), dst.c_str(), imgx, imgy, w, h, thy, numMaxFrames, cb);
 }
 
 int amtgpu_scanlogo_sharded(AmtGpuContext* c, const AmtGpuCollectives* coll, const void* dY, const void* dU, const void* dV,

@@ -20,11 +20,10 @@ struct AmtGpuFrameStats {
 
 extern "C" {
 
-AmtGpuFrameStats* amtgpu_framestats_create(AmtGpuContext* c, int width, int height, int bits, int t1, int t2)
+AmtGpuFrameStats* amtgpu_framestats_create(AmtGpuContext* c, int width, int height, int bits)
 {
     AmtGpuFrameStats* fs = nullptr;
     guard(c, [&] {
-        (void)t1; (void)t2;     // reserved for thresholded variants of the metrics
         if (width <= 0 || height < 4 || bits < 8 || bits > 15) throw std::runtime_error("[FrameStats] unsupported frame format");
         fs = new AmtGpuFrameStats{c, width, height, bits};
     });

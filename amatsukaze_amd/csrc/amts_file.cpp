@@ -65,22 +65,7 @@ struct Reader {
 
 template <typename T> T at(const uint8_t* base, size_t off) { T v; std::memcpy(&v, base + off, sizeof(T)); return v; }
 
-std::string utf8(const std::u16string& s)
-{
-    std::string o;
-    for (size_t i = 0; i < s.size(); ++i) {
-        uint32_t c = s[i];
-        if (c >= 0xD800 && c < 0xDC00 && i + 1 < s.size() && s[i + 1] >= 0xDC00 && s[i + 1] < 0xE000) {
-            c = 0x10000 + ((c - 0xD800) << 10) + (s[i + 1] - 0xDC00);
-            ++i;
-        }
-        if (c < 0x80) o += (char)c;
-        else if (c < 0x800) { o += (char)(0xC0 | (c >> 6)); o += (char)(0x80 | (c & 0x3F)); }
-        else if (c < 0x10000) { o += (char)(0xE0 | (c >> 12)); o += (char)(0x80 | ((c >> 6) & 0x3F)); o += (char)(0x80 | (c & 0x3F)); }
-        else { o += (char)(0xF0 | (c >> 18)); o += (char)(0x80 | ((c >> 12) & 0x3F)); o += (char)(0x80 | ((c >> 6) & 0x3F)); o += (char)(0x80 | (c & 0x3F)); }
-    }
-    return o;
-}
+std::string utf8(const std::u16string& s) { return amt_utf8_from_utf16(reinterpret_cast<const uint16_t*>(s.data()), s.size()); }
 
 } // namespace
 

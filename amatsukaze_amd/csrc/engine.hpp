@@ -30,7 +30,11 @@ struct AmtGpuContext {
     void* pinned = nullptr;             // pinned staging ring (2 slots)
     size_t pinned_bytes = 0;
     hipEvent_t slot_free[2] = {nullptr, nullptr};
-    int next_slot = 0;
+    int next_slot = 0;                  // the slot being filled
+    size_t slot_fill = 0;               // bytes of it handed out (small uploads share a slot: no event wait per call)
+    void* pinned_down = nullptr;        // pinned landing buffer of amtgpu_download_pinned
+    size_t pinned_down_bytes = 0;
+    hipEvent_t markers[16] = {};        // amtgpu_marker_record / _wait
     std::string err;
     // One context may be shared by several filter instances whose GetFrame runs on different AviSynth threads
     // (MT_NICE_FILTER): the staging ring, the error string and the timing spans are guarded by this lock.

@@ -671,6 +671,13 @@ def main():
                 configs[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
 
+    boundary = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            boundary = measure_boundary(ctx, logos, local_rank)
+        except Exception as e:
+            boundary = {"error": f"{type(e).__name__}: {e}"}
+
     ingest = None
     if rank == 0 and world == 1 and not args.no_ingest:
         try:
@@ -767,7 +774,7 @@ def main():
             "gpu_over_cpu": (fps / cpu["value"]) if cpu else None,
             "gpu_over_cpu_all_cores": (fps / cpu["all_cores"]["value"]) if cpu else None,
             "exact_mode": exact_mode,
-            "verified": verified, "configs": configs, "strong_scan": strong, "ingest": ingest,
+            "verified": verified, "configs": configs, "boundary": boundary, "strong_scan": strong, "ingest": ingest,
             "kernels": out_kern,
         }
         print(json.dumps(line), flush=True)
@@ -1090,6 +1097,30 @@ def config_scanlogo(ctx, dev, logos_np, alpha, alphaUV, args, NT=STRONG_FRAMES, 
             "kernels_ms_per_call": kern, "algorithmic_bytes": {"border_test_and_accumulate": rect_bytes * NT},
             "lgd_sha256": hashlib.sha256(lgd).hexdigest(), "lgd_bytes": len(lgd), "verified": verified, "clip_generation_s": gen_s,
             "note": "only the rectangle's rows of every frame are resident (30 GB instead of 251 GB): ScanLogo reads nothing else of a frame"}
+
+# --------------------------------------------------------------------------------------------------------------------
+# throughput through the drop-in surface itself: the C++ filter classes of include/amt_filters.hpp (the reference's AMTAnalyzeLogo /
+# AMTEraseLogo / LogoFrame over the C ABI), frames pulled one GetFrame at a time by a C++ host (tests/cpp/filters_host_test --bench)
+# --------------------------------------------------------------------------------------------------------------------
+def measure_boundary(ctx, logos, device, frames=6144):
+    import tempfile
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp, "filters_host_test"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tmp = tempfile.mkdtemp()
+    paths = []
+    for i, l in enumerate(logos):
+        p = os.path.join(tmp, f"logo{i}.lgd")
+        l.save(p, f"bench{i}", 1)
+        paths.append(p)
+    r = subprocess.run([os.path.join(cpp, "filters_host_test"), "--bench", str(W), str(H), str(frames)] + paths + [str(device)],
+                       capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("filters_host_test --bench: " + (r.stderr or r.stdout)[-400:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out["note"] = ("a second process on the same GPU, after the timed region; source frames are handed out by reference (no decoder), so "
+                   "these are the filter layer's own rates: host copies (MakeWritable, pinned staging), PCIe, launches")
+    return out
+
 
 # --------------------------------------------------------------------------------------------------------------------
 # frames that are NOT resident: pageable host -> pinned ring -> hipMemcpyAsync on the side stream, overlapped with the

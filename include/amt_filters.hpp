@@ -11,9 +11,14 @@
  * Host types: AviSynth's, from the real avisynth.h when AMT_FILTERS_USE_AVISYNTH_H is defined before inclusion, else
  * the stand-ins of amt_avs_min.h (namespace amtavs).
  *
- * What differs from the reference's filters, by design: AMTAnalyzeLogo evaluates a block of analysis frames per GPU
- * launch and serves GetFrame from that block (the reference computes 8 source frames per call); the frames returned
- * are byte-identical.  AMTEraseLogo mode != 0 (debug text overlay, :1402-1418) is not provided.
+ * What differs from the reference's filters, by design: both filters work a BLOCK of frames per GPU launch and serve GetFrame
+ * from it -- AMTAnalyzeLogo a block of analysis frames (the reference computes 8 source frames per call), AMTEraseLogo a block
+ * of child frames whose logo rectangles go up in one batch, through ONE erase launch and back in one copy (the reference
+ * erases the frame it was asked for); LogoFrame::scanFrames uploads the next batch of frames while the GPU scans the current
+ * one.  What they return is byte-identical to the reference's.  AMTAnalyzeLogo can also run the linear decision-guarded
+ * evaluation (AMTGPU_ANALYZE_LINEAR_GUARDED: ~2x faster, every fade AMTEraseLogo derives from the clip identical, the clip's
+ * floats within 1e-4) -- opt-in, since the analysis clip then is no longer the reference's bit for bit.
+ * AMTEraseLogo mode != 0 (debug text overlay, :1402-1418) is not provided.
  */
 #ifndef AMT_FILTERS_HPP
 #define AMT_FILTERS_HPP
@@ -50,6 +55,7 @@ using AMT_AVS_NS PLANAR_V;
 using AMT_AVS_NS PLANAR_Y;
 
 inline int nblocks(int n, int block) { return (n + block - 1) / block; }      /* StreamUtils.hpp:35 */
+constexpr int kUploadGroup = 64;   /* host frames whose logo rectangles share one upload call */
 
 /* one context (device, stream, pinned ring) shared by the filters of a script */
 class Context {
@@ -103,7 +109,7 @@ class AMTAnalyzeLogo : public GenericVideoFilter {
     std::mutex mu_;
     int cache_first_ = -1;
     std::vector<float> cache_;                    /* [block_][8][33] */
-    int row0_ = 0, row1_ = 0;                     /* Y rows the analysis reads: the logo rectangle's */
+    int row0_ = 0, row1_ = 0, col0_ = 0, col1_ = 0;   /* the Y samples the analysis reads: the logo rectangle */
 
     void fill(int first, IScriptEnvironment* env)
     {
@@ -112,41 +118,60 @@ class AMTAnalyzeLogo : public GenericVideoFilter {
         const int es = srcvi_.ComponentSize();
         uint64_t plane = 0;
         int pitch = 0;
+        std::vector<PVideoFrame> held;
+        std::vector<const void*> srcs;
+        int group_first = 0;
+        /* only the logo rectangle travels, to its place in the device frame: the analysis reads nothing else (LogoScan.hpp:1132-1141)
+         * -- w * h samples per frame instead of the whole plane; kUploadGroup frames per upload call */
+        auto flush = [&]() {
+            if (srcs.empty()) return;
+            if (row1_ > row0_ && col1_ > col0_ &&
+                !amtgpu_frames_upload_gather(ctx_->get(), dY_.at(plane * group_first) + (uint64_t)col0_ * es, pitch, srcs.data(), pitch,
+                                             (uint64_t)(col1_ - col0_) * es, row1_ - row0_, (int)srcs.size()))
+                env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
+            held.clear();
+            srcs.clear();
+        };
         for (int k = 0; k < nsrc; ++k) {
             const int n = std::max(0, std::min(srcvi_.num_frames - 1, first * 8 + k));
             PVideoFrame f = child->GetFrame(n, env);
             if (k == 0) {
                 pitch = f->GetPitch(PLANAR_Y);
-                plane = (uint64_t)pitch * srcvi_.height;
-                dY_.reserve(plane * nsrc);
+                plane = (uint64_t)pitch * (row1_ - row0_);        /* resident part of a frame: the rectangle's rows */
+                dY_.reserve(plane * nsrc + 64);
             } else if (f->GetPitch(PLANAR_Y) != pitch) {
                 env->ThrowError("[AMTAnalyzeLogo] frames of one clip must share a pitch");
             }
-            /* only the rows of the logo rectangle travel, to their place in the device frame: the analysis reads nothing else
-             * (LogoScan.hpp:1132-1141) -- h * pitch bytes per frame instead of the whole plane */
-            const uint64_t off = (uint64_t)row0_ * pitch;
-            if (!amtgpu_frames_upload(ctx_->get(), dY_.at(plane * k + off), f->GetReadPtr(PLANAR_Y) + off, (uint64_t)(row1_ - row0_) * pitch))
-                env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
+            if (srcs.empty()) group_first = k;
+            srcs.push_back(f->GetReadPtr(PLANAR_Y) + (uint64_t)row0_ * pitch + (uint64_t)col0_ * es);
+            held.push_back(std::move(f));
+            if ((int)srcs.size() == kUploadGroup) flush();
         }
+        flush();
         if (!amtgpu_frames_upload_wait(ctx_->get())) env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
         cache_.assign((size_t)block_ * 8 * AMTGPU_ANALYZE_FLOATS, 0.0f);
-        if (!amtgpu_analyze_batch_host(an_, dY_.at(0), (int64_t)plane, pitch / es, srcvi_.BitsPerComponent(), nsrc, cache_.data()))
+        /* a device "frame" is the rectangle's rows, addressed as if the rows above were there */
+        if (!amtgpu_analyze_batch_host(an_, dY_.at(0) - (uint64_t)row0_ * pitch, (int64_t)plane, pitch / es, srcvi_.BitsPerComponent(), nsrc, cache_.data()))
             env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
         cache_first_ = first;
     }
 
 public:
+    /* analysisMode: AMTGPU_ANALYZE_EXACT (the reference's records bit for bit) or AMTGPU_ANALYZE_LINEAR_GUARDED */
     AMTAnalyzeLogo(PClip clip, const std::string& logoPath, float maskratio, IScriptEnvironment* env, PContext ctx = PContext(),
-                   int framesPerLaunch = 32)
+                   int framesPerLaunch = 32, int analysisMode = AMTGPU_ANALYZE_EXACT)
         : GenericVideoFilter(clip), ctx_(ctx ? ctx : std::make_shared<Context>()), srcvi_(vi), block_(std::max(1, framesPerLaunch)),
           dY_(ctx_)
     {
         an_ = amtgpu_analyze_create(ctx_->get(), logoPath.c_str(), maskratio);
         if (!an_) env->ThrowError("Failed to read logo file (%s)", logoPath.c_str());          /* LogoScan.hpp:1174 */
+        if (analysisMode != AMTGPU_ANALYZE_EXACT && !amtgpu_analyze_set_mode(an_, analysisMode)) env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
         int rc[4] = {0, 0, 0, 0};
         if (!amtgpu_analyze_get_rect(an_, rc)) env->ThrowError("[AMTAnalyzeLogo] %s", ctx_->error());
         row0_ = std::max(0, std::min(srcvi_.height, rc[1]));
         row1_ = std::max(row0_, std::min(srcvi_.height, rc[1] + rc[3]));
+        col0_ = std::max(0, std::min(srcvi_.width, rc[0]));
+        col1_ = std::max(col0_, std::min(srcvi_.width, rc[0] + rc[2]));
         const int out_bytes = (int)sizeof(float) * AMTGPU_ANALYZE_FLOATS * 8;                  /* sizeof(LogoAnalyzeFrame) * 8 */
         vi.pixel_type = VideoInfo::CS_BGR32;
         vi.width = 64;
@@ -178,10 +203,13 @@ class AMTEraseLogo : public GenericVideoFilter {
     AmtGpuErase* er_ = nullptr;
     PClip analyzeclip_;
     int mode_, maxFadeLength_;
+    int block_;                                   /* child frames erased per GPU launch */
     DeviceBuffer dbuf_;
     std::mutex mu_;
     std::vector<float> analysis_;                 /* [num_frames][33], filled on demand from analyzeclip */
     std::vector<char> have_;                      /* per analysis frame */
+    int cache_first_ = -1;
+    std::vector<PVideoFrame> cache_;              /* the erased frames of the current block */
 
     void need_analysis(int lo, int hi, IScriptEnvironment* env)
     {
@@ -197,11 +225,84 @@ class AMTEraseLogo : public GenericVideoFilter {
         }
     }
 
+    /* frames [first, first + nb): fetched, their logo rectangles uploaded together, ONE Delogo launch (LogoScan.hpp:1248-1261,
+     * 1374-1397), one copy back.  Delogo rewrites the rectangle and nothing else: w*h luma and 2 * w/2*h/2 chroma samples per frame
+     * cross PCIe each way, and a frame whose fades are both 0 does not travel at all when the reference's arithmetic is the
+     * identity there (amtgpu_erase_get_rect). */
+    void fill(int first, IScriptEnvironment* env)
+    {
+        const int es = vi.ComponentSize();
+        const int nb = std::min(block_, vi.num_frames - first);
+        /* CalcFade2 reads the analysis of source frames n-8 .. n+8; a logoframe transition can widen that by maxfade/2 */
+        const int reach = 8 + (maxFadeLength_ >> 1) + 1;
+        need_analysis(first - reach, first + nb - 1 + reach, env);
+        std::vector<float> fades((size_t)nb * 2);
+        if (!amtgpu_erase_calc_fades(er_, analysis_.data(), vi.num_frames, first, nb, fades.data())) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+        int rc[5];
+        if (!amtgpu_erase_get_rect(er_, rc)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+        const int imgx = rc[0], imgy = rc[1], w = rc[2], h = rc[3];
+        if (imgx < 0 || imgy < 0 || imgx + w > vi.width || imgy + h > vi.height) env->ThrowError("[AMTEraseLogo] logo rectangle outside the frame");
+        const int wUV = w >> 1, hUV = h >> 1, cx = imgx >> 1, cy = imgy >> 1;
+        const uint64_t by = (uint64_t)w * h * es, buv = (uint64_t)wUV * hUV * es, per = by + 2 * buv;
+        std::vector<PVideoFrame> frames(nb);
+        std::vector<int> slot(nb, -1);                /* position of the frame's rectangle in the device batch, -1: untouched */
+        std::vector<float> bf;
+        AmtGpuContext* g = ctx_->get();
+        int m = 0;
+        for (int i = 0; i < nb; ++i) {
+            frames[i] = child->GetFrame(first + i, env);
+            /* both fades 0: the reference's arithmetic is the identity -- for samples <= maxv, i.e. at 8 and 16 bits (at 10 / 12 bits
+             * its clamp still rewrites out-of-range container values, LogoScan.hpp:1258): the frame is returned as it came */
+            const int bpc = vi.BitsPerComponent();
+            if (rc[4] && (bpc == 8 || bpc == 16) && fades[2 * i] == 0.0f && fades[2 * i + 1] == 0.0f) continue;
+            env->MakeWritable(&frames[i]);
+            slot[i] = m++;
+            bf.push_back(fades[2 * i]); bf.push_back(fades[2 * i + 1]);
+        }
+        if (m > 0) {
+            dbuf_.reserve(per * m);
+            /* device layout: Y [m][h][w], then U [m][hUV][wUV], then V */
+            uint8_t *dY = dbuf_.at(0), *dU = dbuf_.at(by * m), *dV = dbuf_.at(by * m + buv * m);
+            for (int i = 0; i < nb; ++i) {
+                if (slot[i] < 0) continue;
+                const int pY = frames[i]->GetPitch(PLANAR_Y), pUV = frames[i]->GetPitch(PLANAR_U);
+                const uint8_t* hY = frames[i]->GetReadPtr(PLANAR_Y) + (size_t)imgy * pY + (size_t)imgx * es;
+                const uint8_t* hU = frames[i]->GetReadPtr(PLANAR_U) + (size_t)cy * pUV + (size_t)cx * es;
+                const uint8_t* hV = frames[i]->GetReadPtr(PLANAR_V) + (size_t)cy * pUV + (size_t)cx * es;
+                if (!amtgpu_frames_upload_strided(g, dY + by * slot[i], (int64_t)w * es, hY, pY, (uint64_t)w * es, h) ||
+                    !amtgpu_frames_upload_strided(g, dU + buv * slot[i], (int64_t)wUV * es, hU, pUV, (uint64_t)wUV * es, hUV) ||
+                    !amtgpu_frames_upload_strided(g, dV + buv * slot[i], (int64_t)wUV * es, hV, pUV, (uint64_t)wUV * es, hUV))
+                    env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+            }
+            if (!amtgpu_frames_upload_wait(g)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+            if (!amtgpu_erase_rect_batch(er_, dY, dU, dV, (int64_t)by, (int64_t)buv, w, wUV, vi.BitsPerComponent(), m, bf.data()))
+                env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+            const void* hp = nullptr;
+            if (!amtgpu_download_pinned(g, dbuf_.at(0), per * m, &hp)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+            const uint8_t* back = static_cast<const uint8_t*>(hp);
+            for (int i = 0; i < nb; ++i) {
+                if (slot[i] < 0) continue;
+                const int pY = frames[i]->GetPitch(PLANAR_Y), pUV = frames[i]->GetPitch(PLANAR_U);
+                uint8_t* hY = frames[i]->GetWritePtr(PLANAR_Y) + (size_t)imgy * pY + (size_t)imgx * es;
+                uint8_t* hU = frames[i]->GetWritePtr(PLANAR_U) + (size_t)cy * pUV + (size_t)cx * es;
+                uint8_t* hV = frames[i]->GetWritePtr(PLANAR_V) + (size_t)cy * pUV + (size_t)cx * es;
+                const uint8_t *sY = back + by * slot[i], *sU = back + by * m + buv * slot[i], *sV = back + by * m + buv * m + buv * slot[i];
+                for (int y = 0; y < h; ++y) std::memcpy(hY + (size_t)y * pY, sY + (size_t)y * w * es, (size_t)w * es);
+                for (int y = 0; y < hUV; ++y) {
+                    std::memcpy(hU + (size_t)y * pUV, sU + (size_t)y * wUV * es, (size_t)wUV * es);
+                    std::memcpy(hV + (size_t)y * pUV, sV + (size_t)y * wUV * es, (size_t)wUV * es);
+                }
+            }
+        }
+        cache_.swap(frames);
+        cache_first_ = first;
+    }
+
 public:
     AMTEraseLogo(PClip clip, PClip analyzeclip, const std::string& logoPath, const std::string& logofPath, int mode, int maxFadeLength,
-                 IScriptEnvironment* env, PContext ctx = PContext())
+                 IScriptEnvironment* env, PContext ctx = PContext(), int framesPerLaunch = 32)
         : GenericVideoFilter(clip), ctx_(ctx ? ctx : std::make_shared<Context>()), analyzeclip_(std::move(analyzeclip)), mode_(mode),
-          maxFadeLength_(maxFadeLength), dbuf_(ctx_)
+          maxFadeLength_(maxFadeLength), block_(std::max(1, framesPerLaunch)), dbuf_(ctx_)
     {
         if (mode_ != 0) env->ThrowError("[AMTEraseLogo] mode %d (debug overlay) is not available on the GPU path", mode_);
         er_ = amtgpu_erase_create(ctx_->get(), logoPath.c_str(), logofPath.c_str(), mode_, maxFadeLength_);
@@ -218,42 +319,10 @@ public:
     {
         const int es = vi.ComponentSize();
         if (es != 1 && es != 2) env->ThrowError("[AMTEraseLogo] Unsupported pixel format");
-        PVideoFrame frame = child->GetFrame(n, env);
-        env->MakeWritable(&frame);
         std::lock_guard<std::mutex> lock(mu_);
-        /* CalcFade2 reads the analysis of source frames n-8 .. n+8; a logoframe transition can widen that by maxfade/2 */
-        const int reach = 8 + (maxFadeLength_ >> 1) + 1;
-        need_analysis(n - reach, n + reach, env);
-        float fades[2];
-        if (!amtgpu_erase_calc_fades(er_, analysis_.data(), vi.num_frames, n, 1, fades)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        /* Delogo rewrites the logo rectangle and nothing else (LogoScan.hpp:1248-1261): only its rows cross PCIe -- w*h luma and
-         * 2 * w/2*h/2 chroma samples up and back instead of two whole frames -- and a frame whose fades are both 0 is returned as
-         * it came (the reference's arithmetic is the identity there) */
-        int rc[5];
-        if (!amtgpu_erase_get_rect(er_, rc)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        const int imgx = rc[0], imgy = rc[1], w = rc[2], h = rc[3];
-        if (rc[4] && fades[0] == 0.0f && fades[1] == 0.0f) return frame;
-        if (imgx < 0 || imgy < 0 || imgx + w > vi.width || imgy + h > vi.height) env->ThrowError("[AMTEraseLogo] logo rectangle outside the frame");
-        const int wUV = w >> 1, hUV = h >> 1, cx = imgx >> 1, cy = imgy >> 1;
-        const uint64_t by = (uint64_t)w * h * es, buv = (uint64_t)wUV * hUV * es;
-        dbuf_.reserve(by + 2 * buv);
-        uint8_t *dY = dbuf_.at(0), *dU = dbuf_.at(by), *dV = dbuf_.at(by + buv);
-        AmtGpuContext* g = ctx_->get();
-        const int pY = frame->GetPitch(PLANAR_Y), pUV = frame->GetPitch(PLANAR_U);
-        uint8_t* hY = frame->GetWritePtr(PLANAR_Y) + (size_t)imgy * pY + (size_t)imgx * es;
-        uint8_t* hU = frame->GetWritePtr(PLANAR_U) + (size_t)cy * pUV + (size_t)cx * es;
-        uint8_t* hV = frame->GetWritePtr(PLANAR_V) + (size_t)cy * pUV + (size_t)cx * es;
-        if (!amtgpu_frames_upload_strided(g, dY, (int64_t)w * es, hY, pY, (uint64_t)w * es, h) ||
-            !amtgpu_frames_upload_strided(g, dU, (int64_t)wUV * es, hU, pUV, (uint64_t)wUV * es, hUV) ||
-            !amtgpu_frames_upload_strided(g, dV, (int64_t)wUV * es, hV, pUV, (uint64_t)wUV * es, hUV) || !amtgpu_frames_upload_wait(g))
-            env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        if (!amtgpu_erase_rect_batch(er_, dY, dU, dV, (int64_t)by, (int64_t)buv, w, wUV, vi.BitsPerComponent(), 1, fades))
-            env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        if (!amtgpu_download_strided(g, hY, pY, dY, (int64_t)w * es, (uint64_t)w * es, h) ||
-            !amtgpu_download_strided(g, hU, pUV, dU, (int64_t)wUV * es, (uint64_t)wUV * es, hUV) ||
-            !amtgpu_download_strided(g, hV, pUV, dV, (int64_t)wUV * es, (uint64_t)wUV * es, hUV))
-            env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-        return frame;
+        n = std::max(0, std::min(vi.num_frames - 1, n));
+        if (cache_first_ < 0 || n < cache_first_ || n >= cache_first_ + (int)cache_.size()) fill(n - n % block_, env);
+        return cache_[n - cache_first_];
     }
     int SetCacheHints(int cachehints, int) override { return cachehints == AMT_AVS_NS CACHE_GET_MTMODE ? AMT_AVS_NS MT_NICE_FILTER : 0; }
 };
@@ -268,12 +337,13 @@ class LogoFrame {
     int numLogos_;
     int numFrames_ = 0;
     int framesPerLaunch_;
+    DeviceBuffer dY_[2];                          /* the two batches in flight */
 
     void check(int ok) const { if (!ok) throw std::runtime_error(ctx_->error()); }
 
 public:
-    LogoFrame(PContext ctx, const std::vector<std::string>& logofiles, float maskratio, int framesPerLaunch = 256)
-        : ctx_(std::move(ctx)), numLogos_((int)logofiles.size()), framesPerLaunch_(std::max(1, framesPerLaunch))
+    LogoFrame(PContext ctx, const std::vector<std::string>& logofiles, float maskratio, int framesPerLaunch = 2048)
+        : ctx_(std::move(ctx)), numLogos_((int)logofiles.size()), framesPerLaunch_(std::max(1, framesPerLaunch)), dY_{DeviceBuffer(ctx_), DeviceBuffer(ctx_)}
     {
         std::vector<const char*> paths;
         for (const auto& s : logofiles) paths.push_back(s.c_str());
@@ -284,6 +354,9 @@ public:
     LogoFrame(const LogoFrame&) = delete;
     LogoFrame& operator=(const LogoFrame&) = delete;
 
+    /* Batches of framesPerLaunch frames in two device buffers: while the GPU scans batch k the host pulls the frames of batch k + 1
+     * out of the clip (AMTSource::GetFrame, AMTSource.hpp:721-780) and the copy engine brings them in.  Only the rows some logo's
+     * rectangle covers travel and are resident: a device "frame" is those rows, addressed as if the rest were there. */
     void scanFrames(PClip clip, IScriptEnvironment* env)
     {
         const VideoInfo vi = clip->GetVideoInfo();
@@ -291,31 +364,52 @@ public:
         numFrames_ = vi.num_frames;
         check(amtgpu_logoframe_begin(lf_, vi.width, vi.height, vi.BitsPerComponent(), vi.num_frames, (int)vi.fps_numerator,
                                      (int)vi.fps_denominator));
-        DeviceBuffer dY(ctx_);
-        int rows[2] = {0, 0};
+        int rows[2] = {0, 0}, cols[2] = {0, 0};
         check(amtgpu_logoframe_get_rows(lf_, rows));
+        check(amtgpu_logoframe_get_columns(lf_, cols));
         const int r0 = std::max(0, std::min(vi.height, rows[0])), r1 = std::max(r0, std::min(vi.height, rows[1]));
-        for (int n0 = 0; n0 < vi.num_frames; n0 += framesPerLaunch_) {
+        const int c0 = std::max(0, std::min(vi.width, cols[0])), c1 = std::max(c0, std::min(vi.width, cols[1]));
+        int pitch = 0;
+        uint64_t part = 0;                            /* bytes of a frame that are resident: rows [r0, r1) */
+        int k = 0;
+        for (int n0 = 0; n0 < vi.num_frames; n0 += framesPerLaunch_, ++k) {
             const int nb = std::min(framesPerLaunch_, vi.num_frames - n0);
-            uint64_t plane = 0;
-            int pitch = 0;
+            DeviceBuffer& buf = dY_[k & 1];
+            check(amtgpu_marker_wait(ctx_->get(), k & 1));            /* the scan of batch k - 2 has left this buffer */
+            /* frames leave in groups: one upload call (one copy launch) per kUploadGroup frames -- per frame, the API overhead of a
+             * copy is several times the time its 32 KB take */
+            std::vector<PVideoFrame> held;
+            std::vector<const void*> srcs;
+            auto flush = [&](int first_in_batch) {
+                if (srcs.empty()) return;
+                if (r1 > r0 && c1 > c0)       /* the columns of those rows that some rectangle covers */
+                    check(amtgpu_frames_upload_gather(ctx_->get(), buf.at(part * first_in_batch) + (uint64_t)c0 * es, pitch, srcs.data(), pitch,
+                                                      (uint64_t)(c1 - c0) * es, r1 - r0, (int)srcs.size()));
+                held.clear();
+                srcs.clear();
+            };
+            int group_first = 0;
             for (int i = 0; i < nb; ++i) {
                 PVideoFrame f = clip->GetFrame(n0 + i, env);
-                if (i == 0) {
+                if (pitch == 0) {
                     pitch = f->GetPitch(PLANAR_Y);
-                    plane = (uint64_t)pitch * vi.height;
-                    dY.reserve(plane * nb);
+                    part = (uint64_t)(r1 - r0) * pitch;
                 } else if (f->GetPitch(PLANAR_Y) != pitch) {
                     throw std::runtime_error("[LogoFrame] frames of one clip must share a pitch");
                 }
-                /* only the rows some logo's rectangle covers travel (to their place in the device frame) */
-                const uint64_t off = (uint64_t)r0 * pitch;
-                check(amtgpu_frames_upload(ctx_->get(), dY.at(plane * i + off), f->GetReadPtr(PLANAR_Y) + off, (uint64_t)(r1 - r0) * pitch));
+                if (i == 0) buf.reserve(part * std::min(framesPerLaunch_, vi.num_frames));
+                if (srcs.empty()) group_first = i;
+                srcs.push_back(f->GetReadPtr(PLANAR_Y) + (uint64_t)r0 * pitch + (uint64_t)c0 * es);
+                held.push_back(std::move(f));
+                if ((int)srcs.size() == kUploadGroup) flush(group_first);
             }
+            flush(group_first);
             check(amtgpu_frames_upload_wait(ctx_->get()));
-            check(amtgpu_logoframe_scan_batch(lf_, dY.at(0), (int64_t)plane, pitch / es, n0, nb));
-            check(amtgpu_context_synchronize(ctx_->get()));       /* the batch buffer is reused by the next round */
+            /* frame i of the batch: rows r0.. at buf + part * i, i.e. its (virtual) row 0 sits r0 * pitch bytes before that */
+            check(amtgpu_logoframe_scan_batch(lf_, buf.at(0) - (uint64_t)r0 * pitch, (int64_t)part, pitch / es, n0, nb));
+            check(amtgpu_marker_record(ctx_->get(), k & 1));
         }
+        check(amtgpu_context_synchronize(ctx_->get()));
     }
     /* num_frames * numLogos * {corr0, corr1} (EvalResult, LogoScan.hpp:1532-1535) */
     std::vector<float> evalResults() const

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AMTGPU_ABI_VERSION 1
+#define AMTGPU_ABI_VERSION 2      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers */
 #define AMTGPU_NUM_FADE 11            /* LogoAnalyzeFrame p/t/b[11]  (LogoScan.hpp:1100-1103) */
 #define AMTGPU_ANALYZE_FLOATS 33      /* floats per source frame in an analysis record */
 
@@ -75,12 +75,27 @@ int   amtgpu_frames_upload(AmtGpuContext* ctx, void* ddst, const void* hsrc, uin
  * else).  async on the side stream */
 int   amtgpu_frames_upload_strided(AmtGpuContext* ctx, void* ddst, int64_t dst_stride, const void* hsrc, int64_t src_stride,
                                    uint64_t chunk_bytes, int nchunks);
+/* the same for `nsrc` separately allocated host frames at once: piece j of source i lands at ddst + (i * chunks_per_src + j) *
+ * dst_stride -- one call and one copy launch for a whole group of PVideoFrames' logo rectangles (per-frame calls cost more in
+ * API overhead than in bytes).  async on the side stream */
+int   amtgpu_frames_upload_gather(AmtGpuContext* ctx, void* ddst, int64_t dst_stride, const void* const* hsrc, int64_t src_stride,
+                                  uint64_t chunk_bytes, int chunks_per_src, int nsrc);
 int   amtgpu_frames_upload_wait(AmtGpuContext* ctx);   /* make the compute stream wait for pending uploads */
 int   amtgpu_download(AmtGpuContext* ctx, void* hdst, const void* dsrc, uint64_t bytes);        /* synchronous */
 /* nchunks pieces of chunk_bytes, src_stride apart on the device, dst_stride apart on the host (an erased rectangle back into
  * the rows of a host frame).  synchronous */
 int   amtgpu_download_strided(AmtGpuContext* ctx, void* hdst, int64_t dst_stride, const void* dsrc, int64_t src_stride,
                               uint64_t chunk_bytes, int nchunks);
+/* `bytes` from the device into a pinned landing buffer of the context: one asynchronous copy and one wait; *hptr is valid until
+ * the next call.  For callers that scatter the bytes into several host frames themselves (a block of erased rectangles back into
+ * the frames AMTEraseLogo::GetFrame serves, LogoScan.hpp:1343-1400). */
+int   amtgpu_download_pinned(AmtGpuContext* ctx, const void* dsrc, uint64_t bytes, const void** hptr);
+/* Markers on the compute stream, ids 0..15: record(id) behind a batch's launches, wait(id) on the host before that batch's device
+ * buffer is written again.  What a double-buffered caller (LogoFrame::scanFrames, LogoScan.hpp:1570-1589, over AMTSource::GetFrame)
+ * needs instead of amtgpu_context_synchronize, which would also wait for the batch in flight.  wait on a never recorded id returns
+ * at once. */
+int   amtgpu_marker_record(AmtGpuContext* ctx, int id);
+int   amtgpu_marker_wait(AmtGpuContext* ctx, int id);
 
 /* ---- frame assembly: replaces AMTSource::MakeFrame -> MergeField / Copy1 / Copy2 (AMTSource.hpp:291-366) on decoded
  *      pictures already in HBM (uploaded with amtgpu_frames_upload): output frame i takes its even rows from picture
@@ -118,10 +133,18 @@ int  amtgpu_amts_weave_plan(const AmtGpuAmtsFile* a, const int64_t* picture_pts,
 /* ---- logo model: replaces LogoData::Load / Save (AMTLogo.hpp:239-279), LogoFile_* getters
  *      (LogoGUISupport.hpp:254-275) ---- */
 AmtGpuLogo* amtgpu_logo_load(AmtGpuContext* ctx, const char* path);
+/* paths as the reference's exports take them: NUL-terminated UTF-16 (const tchar* = wchar_t* on Windows, LogoScan.hpp:1083-1086;
+ * C# CharSet.Unicode, AmatsukazeNatives.cs:391-393).  Converted to UTF-8 for the file system here (Linux). */
+AmtGpuLogo* amtgpu_logo_loadW(AmtGpuContext* ctx, const uint16_t* path);
 /* planes = aY,bY,aU,bU,aV,bV back to back (AMTLogo.hpp:204-212) */
 AmtGpuLogo* amtgpu_logo_from_planes(AmtGpuContext* ctx, int w, int h, int logUVx, int logUVy,
                                     int imgw, int imgh, int imgx, int imgy, const float* planes);
 int  amtgpu_logo_save(AmtGpuContext* ctx, const AmtGpuLogo* logo, const char* path, const char* name, int serviceId);
+int  amtgpu_logo_saveW(AmtGpuContext* ctx, const AmtGpuLogo* logo, const uint16_t* path, const char* name, int serviceId);
+/* LogoFile_GetName / GetServiceId / SetName / SetServiceId (LogoGUISupport.hpp:254-275) of the extended header (AMTLogo.hpp:19-47):
+ * name is UTF-8 bytes as stored (at most 254 + NUL); either out pointer of get may be NULL */
+int  amtgpu_logo_get_header(const AmtGpuLogo* logo, char* name, int name_cap, int* serviceId);
+int  amtgpu_logo_set_header(AmtGpuLogo* logo, const char* name, int serviceId);
 void amtgpu_logo_destroy(AmtGpuLogo* logo);
 /* out[8] = w,h,logUVx,logUVy,imgw,imgh,imgx,imgy */
 int  amtgpu_logo_get_info(const AmtGpuLogo* logo, int* out8);
@@ -147,6 +170,8 @@ int  amtgpu_logoframe_scan_batch(AmtGpuLogoFrame* lf, const void* dY, int64_t fr
 /* results: num_frames*nlogos*{corr0,corr1} (EvalResult, LogoScan.hpp:1532-1535) */
 /* out2 = {first row, one past the last row} of the Y plane that the scan of these logos reads (the union of their rectangles) */
 int  amtgpu_logoframe_get_rows(const AmtGpuLogoFrame* lf, int* out2);
+/* ... and {first column, one past the last column}: a caller that ships frames over PCIe needs to bring no other samples */
+int  amtgpu_logoframe_get_columns(const AmtGpuLogoFrame* lf, int* out2);
 int  amtgpu_logoframe_get_results(AmtGpuLogoFrame* lf, float* out);
 /* sharded scans: install results computed elsewhere (other ranks) for frames [first, first+nframes) */
 int  amtgpu_logoframe_set_results(AmtGpuLogoFrame* lf, int first, int nframes, const float* evals);
@@ -206,7 +231,9 @@ int  amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t s
 int  amtgpu_erase_rect_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
                              int pitchY, int pitchUV, int bits, int nframes, const float* fades);
 /* out5 = {imgx, imgy, w, h, fade0_is_identity}: the rectangle Delogo rewrites; the last word is 1 when a frame whose two fades
- * are 0 comes back unchanged (every a*s + b*maxv of this logo is finite), i.e. the host may skip the call for such frames */
+ * are 0 comes back unchanged (every a*s + b*maxv of this logo is finite), i.e. the host may skip the call for such frames --
+ * of an 8- or 16-bit clip: at 10 / 12 bits Delogo's min(tmp + 0.5, maxv) (LogoScan.hpp:1258) still clamps container values
+ * above maxv, so those frames must go through (the library itself skips fade-0 frames only at 8 and 16 bits) */
 int  amtgpu_erase_get_rect(const AmtGpuErase* er, int* out5);
 
 /* ---- logo generation: replaces logo::LogoScan (AddFrame :594-659, AddScanFrame :568-592,
@@ -241,6 +268,9 @@ int  amtgpu_scanlogo(AmtGpuContext* ctx, const void* dY, const void* dU, const v
  * (demux / decode are out of scope); frames stream through the pinned ring, accepted rectangles stay in HBM; workfile is unused. */
 int  amtgpu_scanlogo_file(AmtGpuContext* ctx, const char* srcpath, int serviceid, const char* workfile, const char* dstpath,
                           int imgx, int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb);
+/* the same with the reference's string type: NUL-terminated UTF-16 paths (P/Invoke CharSet.Unicode keeps working) */
+int  amtgpu_scanlogo_fileW(AmtGpuContext* ctx, const uint16_t* srcpath, int serviceid, const uint16_t* workfile, const uint16_t* dstpath,
+                           int imgx, int imgy, int w, int h, int thy, int numMaxFrames, AMTGPU_LOGO_ANALYZE_CB cb);
 
 /* ---- frame-sharded runs (one process per GPU).  The library does no communication itself: the host
  *      supplies two collectives over HOST memory -- RCCL in a C++ host (include/amt_rccl_collectives.hpp wraps an ncclComm_t),
@@ -285,7 +315,7 @@ int  amtgpu_scanlogo_sharded(AmtGpuContext* ctx, const AmtGpuCollectives* coll, 
 #define AMTGPU_FS_SUM        5   /* sum of luma */
 #define AMTGPU_FS_VERT_PREV  6   /* VERT of that weave */
 #define AMTGPU_FS_RESERVED   7
-AmtGpuFrameStats* amtgpu_framestats_create(AmtGpuContext* ctx, int width, int height, int bits, int t1, int t2);
+AmtGpuFrameStats* amtgpu_framestats_create(AmtGpuContext* ctx, int width, int height, int bits);
 void amtgpu_framestats_destroy(AmtGpuFrameStats* fs);
 /* dprevY: Y plane of the frame before the batch (device), or NULL -> frame 0 compares with itself.
  * dout: nframes*AMTGPU_FS_WORDS uint64 (device).  async */

@@ -45,12 +45,15 @@ amtgpu::PContext shared_context(IScriptEnvironment* env)
     return c;
 }
 
-AVSValue AMT_CDECL Create_AMTAnalyzeLogo(AVSValue args, void*, IScriptEnvironment* env)
+// user_data: the analysis mode.  "AMTAnalyzeLogo" is the reference's filter bit for bit (AMTGPU_ANALYZE_EXACT); "AMTAnalyzeLogoFast"
+// evaluates all fades from one window evaluation (AMTGPU_ANALYZE_LINEAR_GUARDED): every fade AMTEraseLogo takes from the clip --
+// its only consumer, CalcFade2, LogoScan.hpp:1288-1314 -- is identical, the clip's floats are within 1e-4 of the reference's.
+AVSValue AMT_CDECL Create_AMTAnalyzeLogo(AVSValue args, void* user_data, IScriptEnvironment* env)
 {
     return new amtgpu::AMTAnalyzeLogo(args[0].AsClip(),                               // source
                                       args[1].AsString(),                             // logopath
                                       (float)args[2].AsFloat(35) / 100.0f,            // maskratio (percent)
-                                      env, shared_context(env));
+                                      env, shared_context(env), 32, user_data ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
 }
 
 AVSValue AMT_CDECL Create_AMTEraseLogo(AVSValue args, void*, IScriptEnvironment* env)
@@ -75,5 +78,7 @@ AMT_PLUGIN_EXPORT const char* AMT_STDCALL AvisynthPluginInit3(IScriptEnvironment
 #endif
     env->AddFunction("AMTAnalyzeLogo", "cs[maskratio]i", Create_AMTAnalyzeLogo, 0);
     env->AddFunction("AMTEraseLogo", "ccs[logof]s[mode]i[maxfade]i", Create_AMTEraseLogo, 0);
+    // not a name of the reference's: the opt-in fast analysis for scripts that want it (same arguments)
+    env->AddFunction("AMTAnalyzeLogoFast", "cs[maskratio]i", Create_AMTAnalyzeLogo, (void*)1);
     return "Amatsukaze GPU logo plugin";
 }

@@ -6,6 +6,8 @@
 // clip.raw: int32 {W,H,bits,N,pitchY,pitchUV} then Y[N][H][pitchY], U[N][H/2][pitchUV], V[...] (elements of 1 or 2 bytes)
 #include <dlfcn.h>
 
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -79,6 +81,140 @@ public:
     }
 };
 
+// A clip whose frames exist once and are handed out by reference (AviSynth's cache does the same): eight base pictures, each with
+// and without the logo blended in (obs = (bg - B*maxv) / A, LogoScan.hpp:320-333), the logo present on frames (n / 300) % 2 == 0 with
+// linear 12-frame fades at the transitions (those frames are blended on demand).  The source costs nothing, so what --bench
+// measures is the filter layer: host copies, PCIe, launches.
+class SynthClip : public IClip {
+    VideoInfo vi_;
+    std::vector<float> a_[3], b_[3];
+    int lw_ = 0, lh_ = 0, lx_ = 0, ly_ = 0;
+    std::vector<PVideoFrame> plain_, logo_;
+    IScriptEnvironment env_;
+
+    static double vis(int n)
+    {
+        const int period = 300, fade = 12, k = n % (2 * period);
+        if (k < fade) return (k + 0.5) / fade;
+        if (k < period) return 1.0;
+        if (k < period + fade) return 1.0 - (k - period + 0.5) / fade;
+        return 0.0;
+    }
+    PVideoFrame blended(int base, double v)
+    {
+        PVideoFrame f = std::make_shared<VideoFrame>(*plain_[base]);
+        if (v <= 0) return f;
+        for (int p = 0; p < 3; ++p) {
+            const int plane = p == 0 ? PLANAR_Y : p == 1 ? PLANAR_U : PLANAR_V;
+            const int w = p ? lw_ / 2 : lw_, h = p ? lh_ / 2 : lh_, x0 = p ? lx_ / 2 : lx_, y0 = p ? ly_ / 2 : ly_;
+            for (int y = 0; y < h; ++y) {
+                uint8_t* row = f->GetWritePtr(plane) + (size_t)(y0 + y) * f->GetPitch(plane) + x0;
+                for (int x = 0; x < w; ++x) {
+                    const float A = a_[p][(size_t)y * w + x], B = b_[p][(size_t)y * w + x];
+                    const float with = (row[x] - B * 255.0f) / (A != 0.0f ? A : 1.0f);
+                    const float o = (float)(v * with + (1.0 - v) * row[x]);
+                    row[x] = (uint8_t)std::max(0.0f, std::min(255.0f, std::floor(o + 0.5f)));
+                }
+            }
+        }
+        return f;
+    }
+public:
+    SynthClip(int W, int H, int N, const std::string& logoPath)
+    {
+        vi_.width = W; vi_.height = H; vi_.num_frames = N; vi_.pixel_type = VideoInfo::CS_YV12;
+        AmtGpuLogo* lg = amtgpu_logo_load(nullptr, logoPath.c_str());
+        if (!lg) throw std::runtime_error("cannot read " + logoPath);
+        int info[8];
+        amtgpu_logo_get_info(lg, info);
+        lw_ = info[0]; lh_ = info[1]; lx_ = info[6]; ly_ = info[7];
+        const size_t ys = (size_t)lw_ * lh_, cs = ys / 4;
+        std::vector<float> planes((ys + 2 * cs) * 2);
+        amtgpu_logo_get_planes(lg, planes.data());
+        amtgpu_logo_destroy(lg);
+        const float* q = planes.data();
+        for (int p = 0; p < 3; ++p) {
+            const size_t n = p ? cs : ys;
+            a_[p].assign(q, q + n); q += n;
+            b_[p].assign(q, q + n); q += n;
+        }
+        for (int k = 0; k < 8; ++k) {
+            PVideoFrame f = env_.NewVideoFrame(vi_);
+            uint32_t h = 0x9E3779B9u * (k + 1);
+            for (int plane : {PLANAR_Y, PLANAR_U, PLANAR_V})
+                for (int y = 0; y < f->GetHeight(plane); ++y) {
+                    uint8_t* row = f->GetWritePtr(plane) + (size_t)y * f->GetPitch(plane);
+                    for (int x = 0; x < f->GetRowSize(plane); ++x) {
+                        h = h * 1664525u + 1013904223u;
+                        row[x] = (uint8_t)(plane == PLANAR_Y ? 60 + ((x + 2 * y + 37 * k) % 120) + (h >> 29) : 120 + (h >> 28));
+                    }
+                }
+            plain_.push_back(f);
+            logo_.push_back(blended(k, 1.0));
+        }
+    }
+    const VideoInfo& GetVideoInfo() override { return vi_; }
+    PVideoFrame GetFrame(int n, IScriptEnvironment*) override
+    {
+        n = std::max(0, std::min(vi_.num_frames - 1, n));
+        const double v = vis(n);
+        if (v >= 1.0) return logo_[n & 7];
+        if (v <= 0.0) return plain_[n & 7];
+        return blended(n & 7, v);
+    }
+};
+
+// --bench: frames per second THROUGH include/amt_filters.hpp -- what a host that pulls frames one GetFrame at a time gets
+// (LogoScan.hpp:1343-1419, 1570-1589; FilteredSource.hpp:441-475).  One JSON line.
+static int run_bench(int argc, char** argv)
+{
+    if (argc < 7) { std::fprintf(stderr, "usage: --bench W H N logo.lgd logo2.lgd logo3.lgd [device]\n"); return 2; }
+    const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), N = std::atoi(argv[4]);
+    const std::string l1 = argv[5], l2 = argv[6], l3 = argc > 7 ? argv[7] : argv[6];
+    IScriptEnvironment env;
+    auto ctx = std::make_shared<amtgpu::Context>(argc > 8 ? std::atoi(argv[8]) : 0);
+    PClip src = std::make_shared<SynthClip>(W, H, N, l1);
+    auto secs = [](auto&& fn) {
+        const auto t0 = std::chrono::steady_clock::now();
+        fn();
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    // the source alone (frames by reference + what the filters' callers do with them: nothing)
+    const double t_src = secs([&] { for (int n = 0; n < N; ++n) src->GetFrame(n, &env); });
+    // LogoFrame::scanFrames, 3 logos (CMAnalyze.hpp:291-299)
+    double t_scan = 0;
+    {
+        amtgpu::LogoFrame lf(ctx, {l1, l2, l3}, 0.35f);
+        lf.scanFrames(src, &env);                                     // warm-up: tables, buffers, pinned ring
+        t_scan = secs([&] { lf.scanFrames(src, &env); });
+    }
+    double t_an[2] = {0, 0}, t_er[2] = {0, 0};
+    uint64_t sum[2] = {0, 0};
+    for (int mode = 0; mode < 2; ++mode) {
+        // AMTAnalyzeLogo pulled frame by frame (8 source frames per analysis frame)
+        PClip an = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
+        const int na = an->GetVideoInfo().num_frames;
+        an->GetFrame(0, &env);
+        PClip an2 = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
+        t_an[mode] = secs([&] { for (int n = 0; n < na; ++n) an2->GetFrame(n, &env); });
+        // the MakeSource graph: AMTEraseLogo(src, AMTAnalyzeLogo(src, logo), logo) pulled in order, as the encoder does
+        PClip an3 = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
+        PClip er = std::make_shared<amtgpu::AMTEraseLogo>(src, an3, l1, "", 0, 16, &env, ctx);
+        t_er[mode] = secs([&] {
+            for (int n = 0; n < N; ++n) {
+                PVideoFrame f = er->GetFrame(n, &env);
+                sum[mode] += f->GetReadPtr(PLANAR_Y)[(size_t)80 * f->GetPitch(PLANAR_Y) + 1200];       // (the frames are used)
+            }
+        });
+    }
+    std::printf("{\"what\": \"frames/s through include/amt_filters.hpp (GetFrame by GetFrame, frames in host memory, PCIe inclusive)\", "
+                "\"frame\": \"%dx%d 8-bit\", \"frames\": %d, \"source_alone_fps\": %.0f, \"logoframe_scan_3_logos_fps\": %.0f, "
+                "\"analyze_exact_fps\": %.0f, \"analyze_linear_guarded_fps\": %.0f, \"erase_graph_exact_fps\": %.0f, "
+                "\"erase_graph_linear_guarded_fps\": %.0f, \"erased_frames_identical_in_both_modes\": %s}\n",
+                W, H, N, N / t_src, N / t_scan, N / t_an[0], N / t_an[1], N / t_er[0], N / t_er[1], sum[0] == sum[1] ? "true" : "false");
+    return 0;
+}
+
 static void dump(const std::string& path, const void* p, size_t n)
 {
     std::ofstream f(path, std::ios::binary);
@@ -96,6 +232,11 @@ int main(int argc, char** argv)
             std::printf("%s\n", desc);
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
+    if (argc >= 2 && std::string(argv[1]) == "--bench") {
+        try { return run_bench(argc, argv); }
+        catch (const AvisynthError& e) { std::fprintf(stderr, "AvisynthError: %s\n", e.msg.c_str()); return 1; }
+        catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
     if (argc < 7) { std::fprintf(stderr, "usage: %s clip.raw logo.lgd logo2.lgd logof|- outdir device\n", argv[0]); return 2; }
     const std::string clipPath = argv[1], logo = argv[2], logo2 = argv[3], logofIn = argv[4], out = argv[5];
@@ -136,7 +277,7 @@ int main(int argc, char** argv)
         // 3. erase, frame by frame, with and without a logoframe file
         for (int variant = 0; variant < 2; ++variant) {
             const std::string lfile = variant ? (logofIn == "-" ? out + "/logof.txt" : logofIn) : "";
-            PClip er = std::make_shared<amtgpu::AMTEraseLogo>(src, an, logo, lfile, 0, 16, &env, ctx);
+            PClip er = std::make_shared<amtgpu::AMTEraseLogo>(src, an, logo, lfile, 0, 16, &env, ctx, /*framesPerLaunch*/ 5);
             std::ofstream f(out + (variant ? "/erased_logof.raw" : "/erased.raw"), std::ios::binary);
             for (int n = 0; n < vi.num_frames; ++n) {
                 PVideoFrame fr = er->GetFrame(n, &env);

@@ -27,12 +27,12 @@ def lib():
 def test_exports_every_declared_symbol(lib):
     from amatsukaze_amd import binding
     hdr = open(os.path.join(ROOT, "include", "amt_gpu.h")).read()
-    declared = set(re.findall(r"\b(amtgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(amtgpu_[A-Za-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(binding.SIGNATURES), declared ^ set(binding.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.amtgpu_abi_version() == 1
+    assert lib.amtgpu_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure(lib):
@@ -86,6 +86,42 @@ def test_lgd_and_mask_tables_match_oracle(lib, tmp_path):
         assert np.float32(gblack.value).tobytes() == np.float32(black).tobytes()
     lib.amtgpu_logo_destroy(lg)
     assert not lib.amtgpu_logo_load(None, b"/nonexistent.lgd")
+
+
+def test_logo_header_access_and_utf16_paths(lib, tmp_path):
+    """LogoFile_GetName / GetServiceId / SetName / SetServiceId (LogoGUISupport.hpp:254-275) through amtgpu_logo_get_header /
+    _set_header, and the *W entry points that take the reference's own string type -- NUL-terminated UTF-16 (const tchar* =
+    wchar_t* on Windows, LogoScan.hpp:1083-1086; C# CharSet.Unicode, AmatsukazeNatives.cs:391-393) -- on a Japanese file name."""
+    LW, LH, W, H, X, Y0 = 96, 48, 352, 240, 224, 18
+    data, _, _ = S.make_logo(LW, LH)
+    orc = Oracle()
+    lo = orc.make_logo(data, LW, LH, W, H, X, Y0)
+    p1 = str(tmp_path / "o.lgd").encode()
+    assert orc.lib.orc_logo_save(lo, p1, "NHK総合".encode("utf-8"), 1024) == 1
+    lg = lib.amtgpu_logo_load(None, p1)
+    name = C.create_string_buffer(256)
+    sid = C.c_int()
+    assert lib.amtgpu_logo_get_header(lg, name, 256, C.byref(sid)) == 1
+    assert name.value.decode("utf-8") == "NHK総合" and sid.value == 1024
+    assert lib.amtgpu_logo_get_header(lg, name, 4, None) == 0                   # buffer too small: refused, nothing written past it
+    assert lib.amtgpu_logo_set_header(lg, "テレビ東京".encode("utf-8"), 1072) == 1
+    assert lib.amtgpu_logo_get_header(lg, name, 256, C.byref(sid)) == 1 and name.value.decode("utf-8") == "テレビ東京" and sid.value == 1072
+
+    def w16(s):
+        return C.create_string_buffer(s.encode("utf-16-le") + b"\0\0")
+    jp = tmp_path / "ロゴ_テスト.lgd"
+    assert lib.amtgpu_logo_saveW(None, lg, w16(str(jp)), "テレビ東京".encode("utf-8"), 1072) == 1
+    assert jp.exists()
+    want = str(tmp_path / "w.lgd").encode()
+    assert lib.amtgpu_logo_save(None, lg, want, "テレビ東京".encode("utf-8"), 1072) == 1
+    assert jp.read_bytes() == open(want, "rb").read()
+    lg2 = lib.amtgpu_logo_loadW(None, w16(str(jp)))
+    assert lg2
+    assert lib.amtgpu_logo_get_header(lg2, name, 256, C.byref(sid)) == 1 and name.value.decode("utf-8") == "テレビ東京" and sid.value == 1072
+    # a lone surrogate in a path is replaced (U+FFFD), never emitted as invalid UTF-8: the call fails cleanly on the missing file
+    assert not lib.amtgpu_logo_loadW(None, C.create_string_buffer(b"\x00\xd8x\x00\x00\x00"))
+    lib.amtgpu_logo_destroy(lg)
+    lib.amtgpu_logo_destroy(lg2)
 
 
 def test_stats_decisions_match_oracle(lib):
@@ -220,7 +256,8 @@ def test_avisynth_plugin_registration(lib):
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
     assert lines[:2] == ["AMTAnalyzeLogo\tcs[maskratio]i", "AMTEraseLogo\tccs[logof]s[mode]i[maxfade]i"]
-    assert len(lines) == 3 and lines[2]                       # the description string AviSynth shows
+    assert lines[2] == "AMTAnalyzeLogoFast\tcs[maskratio]i"   # the opt-in linear-guarded analysis (not a reference name)
+    assert len(lines) == 4 and lines[3]                       # the description string AviSynth shows
     sym = subprocess.run(["nm", "-D", "--defined-only", os.path.join(cpp, "libamt_avs_plugin.so")], capture_output=True, text=True).stdout
     assert " T AvisynthPluginInit3" in sym
 

@@ -238,6 +238,29 @@ def test_erase_field_mode_odd_chroma_rows(gpu):
     assert np.array_equal(cs["dclip"].V.cpu().numpy(), V)
 
 
+def test_erase_fade0_clamps_out_of_range_10bit_samples(gpu):
+    """Delogo with fade 0 is the identity only for samples <= maxv: min(tmp + 0.5, maxv) (LogoScan.hpp:1258) clamps container values
+    above 1023 of a 10-bit clip, so fade-0 frames may be skipped at 8 and 16 bits only."""
+    from amatsukaze_amd import AMTEraseLogo
+    torch = gpu["torch"]
+    cfg = dict(SMALL, N=3)
+    cs = make_case(gpu, cfg, bits=10)
+    X, Y0, LW, LH = cfg["IMGX"], cfg["IMGY"], cfg["LW"], cfg["LH"]
+    Y, U, V = (cs["clip"][k].copy() for k in "YUV")
+    Y[:, Y0 + 3:Y0 + 9, X + 5:X + 40] = 3000                   # out-of-range container values inside the rectangle
+    U[:, Y0 // 2 + 2, X // 2 + 4:X // 2 + 20] = 60000
+    d = cs["dclip"]
+    d.Y.copy_(torch.from_numpy(Y.view(np.int16)).to(gpu["dev"]))
+    d.U.copy_(torch.from_numpy(U.view(np.int16)).to(gpu["dev"]))
+    fades = np.array([[0.0, 0.0], [0.4, 0.0], [0.0, 0.0]], np.float32)
+    AMTEraseLogo(gpu["ctx"], cs["logo"]).erase(d, fades)
+    for i in range(3):
+        cs["orc"].lib.orc_erase_frame(cs["lo"], _ptr(Y[i]), _ptr(U[i]), _ptr(V[i]), Y.shape[2], U.shape[2], 10, float(fades[i, 0]), float(fades[i, 1]))
+    assert Y[0, Y0 + 3, X + 5] == 1023                         # the reference did clamp
+    view = lambda x: x.cpu().numpy().view(np.uint16)
+    assert np.array_equal(view(d.Y), Y) and np.array_equal(view(d.U), U) and np.array_equal(view(d.V), V)
+
+
 @pytest.mark.parametrize("bits,imgy", [(8, 16), (10, 18)])
 def test_erase_rectangle_only_planes(gpu, bits, imgy):
     """amtgpu_erase_rect_batch on planes that hold only the logo rectangle == the oracle's Delogo on whole frames, including the

@@ -57,6 +57,12 @@ def _worker(rank, world, port, tmpdir, q):
                 ok1 = ScanLogo(ctx, full, 1041, d1, X, Y0, LW, LH, 12, cap)
                 res[f"scanlogo_{tag}"] = (bool(ok) == bool(ok1)) and (not ok1 or open(d1, "rb").read() == open(d2, "rb").read())
 
+        # ---- a failure on ONE rank (here: rank 1's rectangle lies outside the frame) must end the run on BOTH, not strand rank 0 in a
+        #      collective: the status rides along every exchange (ShardGuard, amt_gpu_erase_scan.hip) ----
+        bad = SH.scan_logo_sharded(ctx, loc, 1041, None, X if rank == 0 else W, Y0, LW, LH, 12, 25, coll)
+        res["failsafe_scanlogo_failed"] = not bad
+        res["failsafe_scanlogo_msg"] = ctx.lib.amtgpu_last_error(ctx.h).decode(errors="replace")
+
         # ---- LogoFrame all-frames scan, sharded (ragged: 39 frames -> 20 + 19) + all-gather on every rank ----
         Y, U, V = G.frames(g, pitch_pad=32)
         NS = N - 1
@@ -65,6 +71,12 @@ def _worker(rank, world, port, tmpdir, q):
         lf = LogoFrame(ctx, logos, 0.35)
         lf.begin(W, H, 8, NS)
         lf.scan_batch(torch.from_numpy(Y[f0:f1]).to(dev), 8, f0, f1 - f0)
+        try:                                               # rank 1 reports a range outside the clip: both ranks get an error, nobody hangs
+            SH.logoframe_allgather(lf, f0 if rank == 0 else NS, f1 - f0, coll)
+            res["failsafe_allgather_failed"] = False
+        except Exception as e:
+            res["failsafe_allgather_failed"] = True
+            res["failsafe_allgather_msg"] = str(e)
         SH.logoframe_allgather(lf, f0, f1 - f0, coll)
         res["logoframe_equal"] = lf.evalResults.tobytes() == g["logoframe_evals"][:NS].tobytes()
         lf.selectLogo(2)
@@ -110,6 +122,11 @@ def test_sharded_hip_path_world2(tmp_path):
     assert r0["scanlogo_ok"] and r1["scanlogo_ok"]
     assert r0["scanlogo_lgd_equal"], "sharded ScanLogo .lgd differs from the reference's"
     assert r0["scanlogo_cap3"] and r0["scanlogo_capall"]
+    # one rank's failure ends the sharded call on every rank, each with a message that says whose it was
+    assert r0["failsafe_scanlogo_failed"] and r1["failsafe_scanlogo_failed"]
+    assert "another rank failed" in r0["failsafe_scanlogo_msg"] and "outside the frame" in r1["failsafe_scanlogo_msg"]
+    assert r0["failsafe_allgather_failed"] and r1["failsafe_allgather_failed"]
+    assert "another rank failed" in r0["failsafe_allgather_msg"] and "outside the clip" in r1["failsafe_allgather_msg"]
     for r in res:
         assert r["logoframe_equal"] and r["best"] == int(G.load()["logoframe_best"])
         assert r["fades_equal"] and r["erase_equal"]
