@@ -12,6 +12,9 @@
 //                     int64 framePTS @24, int64 fileOffset @32, int keyFrame @40, enum cmType @44
 //   FilterAudioFrame (:156-160)                  24 bytes: int frameIndex @0, int64 waveOffset @8, int waveLength @16
 //   DecoderSetting   (StreamUtils.hpp:526-536)   12 bytes: 3 x enum (mpeg2, h264, hevc)
+// These numbers are pinned to the reference's own definitions: oracle/ref_shim/layout_probe.cpp compiles the structs out of the reference
+// headers (-fshort-wchar) and tests/test_abi_and_host.py::test_amts_layout_is_the_reference_structs checks sizeof/offsetof and reads a
+// file written from those structs (tests/golden/amts_ref_layout.json, amts_ref_sample.dat) back through amtgpu_amts_load.
 // The plan: AMTSource::OnFrameOutput (:482-566) matches every decoded picture to the frame list by its 33-bit PTS; a frame whose
 // halfDelay is set is woven from the PREVIOUS picture's top field and this picture's bottom field (MakeFrame(prev, cur)), any other
 // frame from one picture -- exactly the (top_index, bottom_index) pairs amtgpu_weave_fields_batch takes.

@@ -36,3 +36,15 @@ COMMON="-O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mno-fma -w"
 "$CXX" $COMMON -I"$STAGE" -c "$STAGE/ref_driver.cpp" -o "$STAGE/ref_driver.o"
 "$CXX" -shared -o "$OUT/libamt_ref.so" "$STAGE/ComputeKernel.o" "$STAGE/ref_driver.o"
 echo "built $OUT/libamt_ref.so"
+
+# layout probe (oracle/ref_shim/layout_probe.cpp): the amts struct definitions, cut by name out of the reference headers into the stage
+# directory (removed with it), compiled with the reference's 2-byte wchar_t
+cut_type() { iconv -f CP932 -t UTF-8 "$1" | tr -d '\r' | awk -v n="$2" '$0 ~ "^(enum|struct) "n"( |\\{|$)" && !fin {on=1} on{print} on && /^\};/ {on=0; fin=1}'; }
+{
+  for n in DECODER_TYPE DecoderSetting CMType VIDEO_STREAM_FORMAT VideoFormat AUDIO_CHANNELS AudioFormat; do
+    cut_type "$REF/Amatsukaze/StreamUtils.hpp" "$n"
+  done
+  for n in FilterSourceFrame FilterAudioFrame; do cut_type "$REF/Amatsukaze/StreamReform.hpp" "$n"; done
+} > "$STAGE/ref_types.inc"
+"$CXX" -O1 -std=c++17 -fshort-wchar -w -I"$STAGE" "$HERE/ref_shim/layout_probe.cpp" -o "$OUT/layout_probe"
+echo "built $OUT/layout_probe"

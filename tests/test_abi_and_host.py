@@ -4,6 +4,7 @@ bit for bit.  No GPU compute calls here."""
 import ctypes as C
 import os
 import re
+import subprocess
 import sys
 
 import numpy as np
@@ -260,6 +261,68 @@ def test_avisynth_plugin_registration(lib):
     assert len(lines) == 4 and lines[3]                       # the description string AviSynth shows
     sym = subprocess.run(["nm", "-D", "--defined-only", os.path.join(cpp, "libamt_avs_plugin.so")], capture_output=True, text=True).stdout
     assert " T AvisynthPluginInit3" in sym
+
+
+def test_amts_layout_is_the_reference_structs(lib, tmp_path):
+    """The byte layout amts_file.cpp parses is pinned to the reference's OWN definitions, not to this repo's reading of them:
+    tests/golden/amts_ref_layout.json holds sizeof/offsetof of VideoFormat / AudioFormat / FilterSourceFrame / FilterAudioFrame /
+    DecoderSetting as compiled from StreamUtils.hpp:526-536,633-641,778-781 and StreamReform.hpp:145-160 under -fshort-wchar
+    (oracle/ref_shim/layout_probe.cpp), and amts_ref_sample.dat is a file those structs were fwrite()n into the way SaveAMTSource does
+    (AMTSource.hpp:835-852), padding bytes poisoned with 0xEE.  Where oracle/_ref/layout_probe exists (this container) it is re-run and
+    must reproduce the committed fixtures; everywhere, amtgpu_amts_load must read every field of the sample back."""
+    import json
+    import struct
+    import amts_util as A
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    layout = json.load(open(os.path.join(gold, "amts_ref_layout.json")))
+    sample = open(os.path.join(gold, "amts_ref_sample.dat"), "rb").read()
+    probe = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "layout_probe")
+    if os.path.exists(probe):
+        live = json.loads(subprocess.run([probe, "layout"], capture_output=True, text=True, check=True).stdout)
+        assert live == layout
+        subprocess.run([probe, "sample", str(tmp_path / "s.dat")], check=True)
+        assert (tmp_path / "s.dat").read_bytes() == sample
+    # the test-side writer every other amts test uses packs the same layout
+    assert layout["sizeof(wchar_t)"] == 2
+    assert struct.calcsize("<9i3B2?3x") == layout["sizeof(VideoFormat)"] == 44
+    assert [layout["VideoFormat." + k] for k in ("format", "width", "frameRateDenom", "colorPrimaries", "colorSpace", "progressive",
+                                                  "fixedFrameRate")] == [0, 4, 32, 36, 38, 39, 40]
+    assert struct.calcsize("<2i") == layout["sizeof(AudioFormat)"] and layout["AudioFormat.sampleRate"] == 4
+    assert struct.calcsize("<?3xiddqqii") == layout["sizeof(FilterSourceFrame)"] == 48
+    assert [layout["FilterSourceFrame." + k] for k in ("halfDelay", "frameIndex", "pts", "frameDuration", "framePTS", "fileOffset",
+                                                        "keyFrame", "cmType")] == [0, 4, 8, 16, 24, 32, 40, 44]
+    assert struct.calcsize("<i4xqi4x") == layout["sizeof(FilterAudioFrame)"] == 24
+    assert [layout["FilterAudioFrame." + k] for k in ("frameIndex", "waveOffset", "waveLength")] == [0, 8, 16]
+    assert struct.calcsize("<3i") == layout["sizeof(DecoderSetting)"] and layout["DecoderSetting.hevc"] == 8
+    # the library reads the reference-written bytes
+    path = tmp_path / "amts_ref.dat"
+    path.write_bytes(sample)
+    h = lib.amtgpu_amts_load(None, str(path).encode())
+    assert h
+    info = np.zeros(19, np.int32)
+    nf, na = C.c_int(), C.c_int()
+    assert lib.amtgpu_amts_get_info(h, _ptr(info), C.byref(nf), C.byref(na))
+    assert info.tolist() == [layout["VS_H264"], 1440, 1080, 1440, 1080, 4, 3, 30000, 1001, 1, 6, 9, 0, 1, layout["AUDIO_32_LFE"], 48000,
+                             0, layout["DECODER_CUVID"], 1]
+    assert nf.value == 7 and na.value == 3
+    b1, b2 = C.create_string_buffer(256), C.create_string_buffer(256)
+    assert lib.amtgpu_amts_get_paths(h, b1, 256, b2, 256)
+    assert b1.value.decode("utf-8") == "D:\\rec\\\u756a\u7d44 #12.ts" and b2.value.decode() == "C:\\tmp\\amt0\\a0-0.wav"
+    gp, go = np.zeros(7, np.int64), np.zeros(7, np.int64)
+    gk, gc, gh = np.zeros(7, np.int32), np.zeros(7, np.int32), np.zeros(7, np.uint8)
+    assert lib.amtgpu_amts_get_frames(h, _ptr(gp), _ptr(go), _ptr(gk), _ptr(gh), _ptr(gc))
+    want_pts = [(1 << 33) - 6006 + 3003 * (i - (1 if i >= 4 else 0)) for i in range(7)]
+    assert gp.tolist() == want_pts
+    assert go.tolist() == [5000000000 + 188 * i for i in range(7)]
+    assert gk.tolist() == [i if i % 3 == 0 else -1 for i in range(7)]
+    assert gh.tolist() == [0, 0, 0, 1, 1, 0, 0]
+    assert gc.tolist() == [layout["CMTYPE_CM"] if i & 1 else 1 for i in range(7)]
+    pics = [p & ((1 << 33) - 1) for p in sorted(set(want_pts))]
+    top, bot = np.zeros(7, np.int32), np.zeros(7, np.int32)
+    assert lib.amtgpu_amts_weave_plan(h, _ptr(np.array(pics, np.int64)), len(pics), _ptr(top), _ptr(bot))
+    wt, wb = A.reference_plan(want_pts, [bool(x) for x in gh], pics)
+    assert top.tolist() == wt and bot.tolist() == wb
+    lib.amtgpu_amts_destroy(h)
 
 
 def test_amts_stream_index_reader_and_weave_plan(lib, tmp_path):
