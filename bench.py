@@ -360,6 +360,19 @@ def main():
         assert dist.get_world_size() == world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # what the collective backend itself reports, not what the environment asked for: an all_reduce of ones over the device tensors
+    # (its sum is the number of ranks the RCCL communicator really joined) and an all_gather of each rank's PCI bus id
+    rccl = {"backend": None, "world_size_observed": 1, "distinct_devices": 1}
+    if world > 1:
+        one = torch.ones(1, device="cpu" if shared_gpu else dev, dtype=torch.int32)
+        dist.all_reduce(one)
+        ids = [None] * world
+        dist.all_gather_object(ids, torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id")
+                               else f"{os.uname().nodename}:{local_rank}")
+        rccl = {"backend": ("rccl" if dist.get_backend() == "nccl" else dist.get_backend()), "world_size_observed": int(one.item()),
+                "distinct_devices": len(set(ids))}
+        if rccl["world_size_observed"] != world:
+            raise SystemExit(f"collective backend joined {rccl['world_size_observed']} ranks, WORLD_SIZE says {world}")
 
     import amt_synth as S
     from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Context, DeviceClip, FrameStats, Logo, LogoFrame
@@ -470,7 +483,7 @@ def main():
                     "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                     "config": {"workload": ss["workload"], "frames_total": ss["frames_total"], "logo": f"{LW}x{LH}@({IMGX},{IMGY})",
                                "maskratio": MASKRATIO, "parallelism": f"frames sharded x{world}"},
-                    "strong_scan": ss}
+                    "collectives": rccl, "strong_scan": ss}
             print(json.dumps(line), flush=True)
         if world > 1:
             dist.barrier()
@@ -769,7 +782,7 @@ def main():
                        "analysis_mode": args.analysis_mode,
                        "frames_per_gpu": N, "logo": f"{LW}x{LH}@({IMGX},{IMGY})", "maskratio": MASKRATIO,
                        "parallelism": f"frames sharded x{world} (one private batch per rank)" if world > 1 else "single GPU"},
-            "timed_region_s": elapsed, "step_phases_ms": phases,
+            "timed_region_s": elapsed, "step_phases_ms": phases, "collectives": rccl,
             "roofline": roofline, "roofline_second": roofline_second, "cpu_baseline": cpu,
             "gpu_over_cpu": (fps / cpu["value"]) if cpu else None,
             "gpu_over_cpu_all_cores": (fps / cpu["all_cores"]["value"]) if cpu else None,

@@ -152,6 +152,7 @@ def test_bench_multi_rank_control_flow_dry_run():
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
+        assert line["collectives"]["world_size_observed"] == 2 and line["collectives"]["backend"] in ("rccl", "gloo")
         ss = line["strong_scan"]
         assert ss["n_gpus"] == 2 and ss["verified"]["sharded_equals_single_launch"] and ss["verified"]["equals_cpu_oracle"]
         sl = ss["scanlogo"]                              # the sharded "full LogoScan" of the same stream: quota hand-out + 3 all-reduces

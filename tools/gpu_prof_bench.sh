@@ -3,9 +3,9 @@
 #   1. --kernel-trace --stats            -> profiles/<tag>_bench_rocprofv3_kernel_stats.csv (rows of this repo's kernels)
 #   2. --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, never combined with tracing) for both analysis modes
 #      -> profiles/<tag>_pmc_traffic.json: HBM bytes per frame per kernel (FETCH_SIZE doubled per MI355X_MICROARCH.md)
-# Run on the GPU box from the repo root:  bash tools/gpu_prof_bench.sh r02
+# Run on the GPU box from the repo root:  bash tools/gpu_prof_bench.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profb_$TAG
 mkdir -p $OUT
