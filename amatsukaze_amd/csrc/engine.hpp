@@ -174,7 +174,7 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
 hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                    const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
                                    long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
-                                   int take_abs, float bin_delta);
+                                   int take_abs, float bin_eps, int qlog2);
 // eval_pair_kernels.hip: fades {0, 1} of every logo, bit-exact
 hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                  const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,

@@ -347,20 +347,29 @@ void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitc
     const int es = bits <= 8 ? 1 : 2;
     // The linear kernel evaluates AMTAnalyzeLogo's 11 fades on tile plans.  A logo without mask pixels (maskratio 0: results are
     // 0 / blackScore = 0 / 0, as the reference's), odd or tiny shapes and any other fade list keep the exact kernel.
-    if ((int)fades_.size() != 11 || !tiles_usable(pitch * es)) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }
+    // the linear kernel is written for AMTAnalyzeLogo's fades: eleven, from exactly 0 to exactly 1
+    if ((int)fades_.size() != 11 || fades_.front() != 0.0f || fades_.back() != 1.0f || !tiles_usable(pitch * es)) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }
     ensure_linear();
     ensure_tiles();
     ctx_->bind();
     if (frame_stride_bytes % es) throw std::runtime_error("frame stride not a multiple of the sample size");
     const int nl = (int)specs_.size();
-    // the interpolated mean is within 19 u v of the exactly evaluated one (7 + 7 roundings of the two means, 3 to combine them, 9 on
-    // the exact side... see ensure_linear); a 32 u v window decides when the exact mean is computed for the bin
-    const float bin_delta = 32.0f / 16777216.0f * vmax_unit_ * (float)((1 << bits) - 1);
-    const int G = group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048));
+    // The interpolated mean is within 19 u v of the exactly evaluated one (7 + 7 roundings of the two means, 3 to combine them, 9 on
+    // the exact side... see ensure_linear), v = a bound on the window values: fades in [0, 1] blend convexly, so v = max(1, |a| + |b|) * maxv
+    // (vmax_unit_ carries a factor 2 for fades outside that range).  The kernel compares in fixed point -- mean * 2^qlog2 with
+    // v * 2^qlog2 < 2^30 -- through three more fp32 roundings of values below v * 2^qlog2: 22 u v in all.
+    bool unit_fades = true;
+    for (float f : fades_) unit_fades = unit_fades && f >= 0.0f && f <= 1.0f;
+    const double vwin = (double)vmax_unit_ * (unit_fades ? 0.5 : 1.0) * (double)((1 << bits) - 1);
+    const float bin_eps = (float)(22.0 / 16777216.0 * vwin * 1.0001);
+    int qlog2 = 24;
+    while (qlog2 > 4 && std::ldexp(vwin, qlog2) >= 1073741824.0) --qlog2;
+    if (!(std::ldexp(vwin, qlog2) < 1073741824.0)) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }   // (absurd coefficients: the exact kernel)
+    const int G = std::min(kLinMaxFrames, group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048)));
     const size_t dot = prof_name_.find('.');
     const int sp = ctx_->prof_begin(("logo_eval_linear_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
     AMT_HIP(launch_logo_eval_linear(ctx_->stream, bits, d_logos_.get(), d_tls_.get(), nl, d_fades_.get(), 11, 0, dY, dframe_map,
-                                    frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0, bin_delta));
+                                    frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0, bin_eps, qlog2));
     ctx_->prof_end(sp);
 }
 

@@ -7,8 +7,9 @@
 // (LogoScan.hpp:302-308) -- is applied per fade as the reference does.  Results differ from the reference's fp32
 // evaluation order by rounding only (bounded by EvalEngine::linear_error_bound(), ~1e-6 typical), which is inside the 1e-4
 // the north star allows for the float scores; the INTEGER decisions taken from them are protected separately:
-//   * the bin select is discontinuous: when the interpolated mean lies within `bin_delta` of a bin edge, that fade's mean is
-//     re-computed in the reference's exact order (blend, column sums, hsum, /25) and the bin comes from the exact value;
+//   * the bin select is discontinuous: when the interpolated mean lies within `bin_eps` (the bound on its distance from the exactly
+//     evaluated mean) of a bin edge, that fade's mean is re-computed in the reference's exact order (blend, column sums, hsum, /25)
+//     and the bin comes from the exact value;
 //   * argmin over fades (CalcFade2, :1288-1314): analysis_mark_kernel lists every frame whose best / second-best margin is
 //     below twice the error bound, and the exact kernel (eval_fused_kernels.hip) re-evaluates just those frames.
 //
@@ -35,6 +36,16 @@ using namespace tile;
 #endif
 constexpr int kLinWaves = AMT_LIN_WAVES;     // waves per workgroup: one per SIMD, so that three workgroups always fit a CU at <= 168 registers
 constexpr int kLinWgThreads = kLinWaves * 64;
+// A wave's running sums of one frame: the C/D image of v_mfma_f32_16x16x4_f32 for rows 0..11 -- lane l < 48 owns 16 bytes, the
+// sums of fades 4*(l/16) .. +3 over the lanes congruent to l mod 16 (16 partial sums per fade, added up at the very end).
+#ifndef AMT_LIN_DIRECT_ENDS
+#define AMT_LIN_DIRECT_ENDS 1
+#endif
+#ifndef AMT_LIN_MFMA_CHAINS
+#define AMT_LIN_MFMA_CHAINS 1
+#endif
+constexpr int kLinAccLanes = 48;
+constexpr int kLinAccFrameBytes = kLinAccLanes * 16;
 
 // sum over the 64 lanes of a wave in a fixed order (DPP: every step is one v_add_f32); the total lands in lane 63
 __device__ __forceinline__ float wave_sum_dpp(float v)
@@ -85,7 +96,8 @@ struct LinLaunch {
     int nframes, G, ngroups;
     float* out;
     int out_frame_stride, take_abs;
-    float bin_delta;
+    float bin_eps;      // bound on |interpolated mean - exactly evaluated mean|, fixed-point rounding included (gray levels)
+    int qlog2;          // means are compared with the bin edges in units of 2^-qlog2 gray levels (v * 2^qlog2 < 2^31)
 };
 
 #ifndef AMT_LIN_OCC
@@ -101,7 +113,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     const int nfades = NF > 0 ? NF : A.nfades;
     extern __shared__ float lds[];
     f2* const planes = reinterpret_cast<f2*>(lds);                 // [kLinWaves][2][kTileCap] a wave's own tile: {s, bg} and the logo's {a, b*maxv}
-    float* const wacc = lds + kLinWaves * 2 * kTileCap * 2;        // [kLinWaves][G][NFMAX] a wave's running sums
+    float* const wacc = lds + kLinWaves * 2 * kTileCap * 2;        // [kLinWaves][G][48 lanes][4] a wave's running sums (kLinAccFrameBytes per frame)
 
     const int G = A.G;
     const int logo = blockIdx.x / A.ngroups;
@@ -117,8 +129,16 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     const gptr_t gSc = (gptr_t)Xp->sc;
     const unsigned nslots8 = (unsigned)Xp->nslots * 8u;
     const const_tile_ptr tiles = (const_tile_ptr)Xp->tiles;
-    // bin edges in 1/4096 fixed point: a mean within dq of a multiple of 8 takes the exact path
-    const int dq = (int)(A.bin_delta * 4096.0f) + 3;
+    // Bin edges in fixed point, Q = 2^qlog2 units per gray level.  qd = floor(mean * Q + dq) with dq = e + 1, e = ceil(bin_eps * Q):
+    // an edge within bin_eps ABOVE the mean has been crossed by qd (low bits in [0, dq]), one within bin_eps BELOW leaves low bits
+    // in [dq - 1, dq + e]; so "low bits <= qwin = dq + e" flags every (pixel, fade) whose exact mean might fall in another bin, and for
+    // all others qd >> (qlog2 + 3) is the bin of the exact mean.
+    const float qscale = __builtin_amdgcn_ldexpf(1.0f, A.qlog2);
+    const int qe = (int)__builtin_ceilf(A.bin_eps * qscale);
+    const int dq = qe + 1;
+    const unsigned qwin = (unsigned)(dq + qe);
+    const int qshift = A.qlog2 + 3;
+    const unsigned qmask = (1u << qshift) - 1u;
     const float dqf = (float)dq;
 
 #ifdef AMT_LIN_TIMING
@@ -136,8 +156,14 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #pragma unroll
         for (int f = 0; f < NFMAX; ++f) fd[f] = fp[min(f, nfades - 1)];
     }
-    float* const myacc = wacc + wave * G * NFMAX;
-    for (int i = lane; i < G * NFMAX; i += 64) myacc[i] = 0.0f;
+    static_assert(NFMAX <= 12, "the running sums hold rows 0..11 of the 16x16 accumulator");
+    float* const myacc = wacc + wave * G * (kLinAccFrameBytes / 4);
+    for (int i = lane; i < G * (kLinAccFrameBytes / 4); i += 64) myacc[i] = 0.0f;
+    const unsigned myacc_base = __builtin_amdgcn_readfirstlane(lds_address(myacc));
+    // the wave's own copy of the fades, lane f <-> fade f (read back by the bin fix-up; a wave's LDS operations complete in order)
+    float* const myfades = wacc + kLinWaves * G * (kLinAccFrameBytes / 4) + wave * 16;
+    if (lane < 16) myfades[lane] = A.fades[A.fade0 + min(lane, nfades - 1)];
+    const unsigned myfades_base = __builtin_amdgcn_readfirstlane(lds_address(myfades));
 
     f2* const myplane = planes + wave * 2 * kTileCap;
     const unsigned plane_base = lds_address(myplane);
@@ -190,27 +216,41 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #pragma unroll
     for (int f = 0; f < NFMAX; ++f) psc[f] = f2{0.0f, 0.0f};
     auto flush_terms = [&]() {
-        float term[NFMAX];
+        // Sum over the wave on the matrix pipe, which is otherwise idle: with B[k][j] = term_f of lane 16 k + j and A[i][k] = (i == f),
+        // v_mfma_f32_16x16x4_f32 adds  D[f][j] += sum_k term_f[16 k + j]  -- an exact fp32 fma chain (products with 1.0 and 0.0), a
+        // fixed order.  Eleven of them (two accumulator chains, so that they issue back to back) leave 16 partial sums per fade in
+        // the accumulator image; the frame's running sums enter as C of the first chain and leave as one 16-byte write per lane.
+        // A lane's cells are its own and LDS operations of a wave complete in order: no barrier, no atomics.
+        // (A non-finite term turns the frame's other fades NaN as well: the decision guard lists such a frame for exact re-evaluation.)
+        typedef __attribute__((address_space(3))) f4* lds_quad;
+        const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)pg * (unsigned)kLinAccFrameBytes + (unsigned)lane * 16u);
+        f4 c0 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (lane < kLinAccLanes) c0 = *cell;
+        // the row selector of fade f: lanes with l % 16 == f; fade f's is fade f-1's moved up one lane within its row of 16 (DPP
+        // row_shr:1, zero shifted in): one instruction each.  (Plain C, not inline asm: the compiler does not see a vector write inside
+        // an asm block and omits the wait states an MFMA reading that register needs -- tools/ubench/mfma_rowsum.hip.)
+        // (the selectors are loop-invariant: left visible, the compiler keeps all eleven in registers across the loop)
+        int lane_opaque = lane;
+        asm volatile("" : "+v"(lane_opaque));
+        float sel = (lane_opaque & 15) == 0 ? 1.0f : 0.0f;
+#if AMT_LIN_MFMA_CHAINS == 2
+        f4 c1 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#endif
 #pragma unroll
-        for (int f = 0; f < NFMAX; ++f)                            // per-pixel terms (LogoScan.hpp:305-308)
-            term[f] = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;
-        // the wave's sums (in lane 63 after the DPP steps) -> the wave's running sums: eleven reads, eleven adds, eleven writes by
-        // that lane, in two batches (two LDS round trips, not eleven)
-#pragma unroll
-        for (int f = 0; f < NFMAX; ++f) term[f] = wave_sum_dpp(term[f]);
-        if (lane == 63) {
-            float* const acc = myacc + pg * NFMAX;
-            constexpr int H = (NFMAX + 1) / 2;
-            float old[H];
-#pragma unroll
-            for (int f = 0; f < H; ++f) old[f] = acc[f];
-#pragma unroll
-            for (int f = 0; f < H; ++f) acc[f] = old[f] + term[f];
-#pragma unroll
-            for (int f = H; f < NFMAX; ++f) old[f - H] = acc[f];
-#pragma unroll
-            for (int f = H; f < NFMAX; ++f) acc[f] = old[f - H] + term[f];
+        for (int f = 0; f < NFMAX; ++f) {
+            if (f > 0) sel = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sel), 0x111, 0xF, 0xF, true));
+            const float term = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;   // (LogoScan.hpp:305-308)
+#if AMT_LIN_MFMA_CHAINS == 2
+            if (f & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, term, c1, 0, 0, 0);
+            else
+#endif
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, term, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                     // (left alone the scheduler computes all terms first: eleven registers too many)
         }
+#if AMT_LIN_MFMA_CHAINS == 2
+        c0 += c1;
+#endif
+        if (lane < kLinAccLanes) *cell = c0;
     };
     while (i0 < ntl) {
         AMT_LTICK(0);
@@ -223,37 +263,56 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         {
             unsigned wrow[5];
             px.rows(wrow);
+#ifdef AMT_LIN_NO_EVAL                                          // (ablations of the instrumented builds: wrong results, timing only)
+            R = px.Kp[0]; M = px.Kp[1] + f2{100.0f, 120.0f};
+#else
             window_eval_streamed(wrow, px.Kp, M, R);         // idle lanes read the tile's first window: finite values, zero taps
+#endif
         }
         AMT_LTICK(2);
         // ---- D. the previous iteration's terms (their scales arrived long ago) leave their registers to this iteration's gathers ----
+#ifndef AMT_LIN_NO_FLUSH
         flush_terms();
+#endif
         AMT_LTICK(4);
         // ---- B. bins.  qd = interpolated mean in 1/4096 units + dq: its low 15 bits are the distance (+ dq) from the bin edge below,
         //      qd >> 15 the bin.  The bin select is discontinuous (LogoScan.hpp:304): for a mean within dq of an edge -- about 1e-4
         //      of all (pixel, fade) pairs -- the mean is evaluated exactly as the reference does and ITS bin is taken ----
-        const float m0qd = __builtin_fmaf(M.x, 4096.0f, dqf), dMq = (M.y - M.x) * 4096.0f;
-        unsigned emin = 0x7FFFu;
+        const float m0q = M.x * qscale, m1q = M.y * qscale;         // (exact: powers of two)
+        const float dMq = m1q - m0q;
+        unsigned emin = qmask;
+        const unsigned slot8 = px.slotbase8 + (unsigned)lane * 8u;     // (not kept: one instruction instead of a register)
         unsigned goff[NFMAX];                                      // byte offset of the fade's {scale, scale2} in the slot table
+        // Fade 0 blends to s and fade 1 to bg exactly (0 * x + y == y), and M holds their means in the reference's own order (column
+        // sums, hsum, /25: window_eval_streamed): those two bins are the reference's without any test.  (The caller guarantees that the
+        // first fade is 0 and the last is 1.)  It matters: mean(s) is an integer / 25 and sits exactly ON a bin edge once in 200 pixels.
 #pragma unroll
         for (int f = 0; f < NFMAX; ++f) {
-            const int qd = (int)__builtin_fmaf(fd[f], dMq, m0qd);
-            emin = min(emin, (unsigned)qd & 0x7FFFu);
-            goff[f] = __umul24((unsigned)clamp_bin(qd >> 15), nslots8) + px.slot8;
+            const bool end = AMT_LIN_DIRECT_ENDS && (f == 0 || f == NFMAX - 1);
+            const int qd = (int)(end ? (f == 0 ? m0q : m1q) : __builtin_fmaf(fd[f], dMq, m0q) + dqf);
+            if (!end) emin = min(emin, (unsigned)qd & qmask);
+            goff[f] = __umul24((unsigned)clamp_bin(qd >> qshift), nslots8) + slot8;
         }
-        // (rare, and kept small in code and registers: rolled loops -- unrolled, the eleven inlined window re-reads cost the whole
-        //  kernel 70 registers)
-        if (px.act && emin <= (unsigned)(2 * dq)) {
-            typedef const __attribute__((address_space(4))) float* const_float_ptr;
-            const const_float_ptr fp = (const_float_ptr)(A.fades + A.fade0);
+        // (uncommon -- one wave iteration in ten has such a pixel -- and kept small in code and registers: rolled loops; unrolled, the
+        //  eleven inlined window re-reads cost the whole kernel 40 registers.  The fades come out of a vector register by v_readlane,
+        //  filled from the wave's copy in LDS: a scalar load per fade would put eleven memory latencies in a row.)
+#ifdef AMT_LIN_NO_FIXUP
+        const bool near_edge = false;
+#else
+        const bool near_edge = px.act && emin <= qwin;
+#endif
+        if (__builtin_amdgcn_ballot_w64(near_edge) != 0) {         // wave-uniform: every lane reads the fades (v_readlane needs lanes 0..10)
             unsigned wrow[5];
             px.rows(wrow);
+            int lane_here = lane;                                  // (opaque: hoisted out of the loop this address would be spilled, and its
+            asm volatile("" : "+v"(lane_here));                    //  reload waits for every load in flight)
+            const float fadev = *(const __attribute__((address_space(3))) float*)(unsigned long long)(myfades_base + (unsigned)(lane_here & 15) * 4u);
 #pragma unroll 1
-            for (int f = 0; f < nfades; ++f) {
-                const float fade = fp[f];
-                const int qd = (int)__builtin_fmaf(fade, dMq, m0qd);
-                if (((unsigned)qd & 0x7FFFu) <= (unsigned)(2 * dq)) {
-                    const unsigned go = __umul24((unsigned)score_bin_dev(exact_blend_mean_rolled(wrow, fade)), nslots8) + px.slot8;
+            for (int f = AMT_LIN_DIRECT_ENDS; f < nfades - AMT_LIN_DIRECT_ENDS; ++f) {
+                const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fadev), f));
+                const int qd = (int)(__builtin_fmaf(fade, dMq, m0q) + dqf);
+                if (near_edge && ((unsigned)qd & qmask) <= qwin) {
+                    const unsigned go = __umul24((unsigned)score_bin_dev(exact_blend_mean_rolled(wrow, fade)), nslots8) + px.slotbase8 + (unsigned)lane * 8u;
 #pragma unroll
                     for (int ff = 0; ff < NFMAX; ++ff) goff[ff] = ff == f ? go : goff[ff];
                 }
@@ -270,12 +329,18 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         }
         // ---- E. this iteration's gathers, into the registers the previous terms were read from ----
 #pragma unroll
+#ifdef AMT_LIN_NO_GATHER
+        for (int f = 0; f < NFMAX; ++f) { asm volatile("" :: "v"(goff[f])); psc[f] = f2{1e-3f, 1.0f}; }
+#else
         for (int f = 0; f < NFMAX; ++f) psc[f] = gld<f2>(gSc, goff[f]);
+#endif
         pR0 = R.x; pdR = R.y - R.x; pg = g0;
         AMT_LTICK(5);
         // ---- C. the next iteration's tile into the plane, its pixel if the tile changes, the raw samples of the one after ----
         if (i1 < ntl) {
+#ifndef AMT_LIN_NO_CONVERT
             st.convert();
+#endif
             int i2 = i1, g2 = g1;
             advance(i2, g2);
             if (i2 < ntl) {
@@ -296,12 +361,19 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         for (int k = 0; k < 8; ++k) tb[slot * 8 + k] = tacc[k];
     }
 #endif
-    // the waves' sums, in order
-    if (tid < gcount * nfades) {
-        const int gg = tid / nfades, f = tid - gg * nfades;
+    // the waves' sums, in order: per wave the 16 partial sums of a fade, front to back
+    // (the thread index is re-derived: kept across the loop it would be one register too many)
+    const int tid_end = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (tid_end < gcount * nfades) {
+        const int gg = tid_end / nfades, f = tid_end - gg * nfades;
         float r = 0.0f;
+        for (int q = 0; q < kLinWaves; ++q) {
+            const float* const cells = wacc + (q * G + gg) * (kLinAccFrameBytes / 4) + (f >> 2) * 64 + (f & 3);      // lane 16 (f / 4) + j, register f % 4
+            float rq = 0.0f;
 #pragma unroll
-        for (int q = 0; q < kLinWaves; ++q) r += wacc[(q * G + gg) * NFMAX + f];
+            for (int j = 0; j < 16; ++j) rq += cells[j * 4];
+            r += rq;
+        }
         r = r / Lp->blackScore;
         if (A.take_abs) r = fabsf(r);
         A.out[(long long)(F0 + gg) * A.out_frame_stride + Lp->out_off + A.fade0 + f] = r;
@@ -318,17 +390,19 @@ void logo_eval_linear_kernel16(const LinLaunch A) { logo_eval_linear_body<uint16
 hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                    const float* dfades, int nfades, int fade0, const void* dY,
                                    const int* dframe_map, long long frame_stride_elems, int pitch, int nframes, int G, float* dout,
-                                   int out_frame_stride, int take_abs, float bin_delta)
+                                   int out_frame_stride, int take_abs, float bin_eps, int qlog2)
 {
+    // (the caller guarantees dfades[fade0] == 0 and dfades[fade0 + nfades - 1] == 1: EvalEngine::run_linear)
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
-    if (nfades != 11 || G * nfades > kLinWgThreads) return hipErrorInvalidValue;       // (AMTAnalyzeLogo's fades; anything else keeps the exact kernel)
+    if (qlog2 < 4 || qlog2 > 24 || !(bin_eps >= 0.0f) || bin_eps * (float)(1 << qlog2) > 1048576.0f) return hipErrorInvalidValue;
+    if (nfades != 11 || G < 1 || G > kLinMaxFrames || G * nfades > kLinWgThreads) return hipErrorInvalidValue;       // (AMTAnalyzeLogo's fades; anything else keeps the exact kernel)
     LinLaunch A;
     A.logos = dlogos; A.tls = dtls; A.fades = dfades; A.Y = dY; A.frame_map = dframe_map; A.frame_stride = frame_stride_elems; A.pitch = pitch;
     A.maxv = (float)((1 << bits) - 1);
     A.nfades = nfades; A.fade0 = fade0;
     A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
-    A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs; A.bin_delta = bin_delta;
-    const size_t lds = ((size_t)kLinWaves * 2 * kTileCap * 2 + (size_t)kLinWaves * G * nfades) * sizeof(float);
+    A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs; A.bin_eps = bin_eps; A.qlog2 = qlog2;
+    const size_t lds = (size_t)kLinWaves * 2 * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * 16 * sizeof(float);
     dim3 grid((unsigned)((long long)A.ngroups * nlogos));
     if (bits <= 8) hipLaunchKernelGGL(logo_eval_linear_kernel, grid, dim3(kLinWgThreads), lds, st, A);
     else hipLaunchKernelGGL(logo_eval_linear_kernel16, grid, dim3(kLinWgThreads), lds, st, A);

@@ -35,6 +35,10 @@ struct EvalLogoDev {
 };
 
 constexpr int kLinMaxFades = 12;    // fades the linear kernel's source is written for (11 for AMTAnalyzeLogo, the instantiated case)
+#ifndef AMT_LIN_G
+#define AMT_LIN_G 6
+#endif
+constexpr int kLinMaxFrames = AMT_LIN_G;     // frames per workgroup of the linear kernel: bounded by the LDS its running sums take (three workgroups share a CU)
 
 // a band = up to kEvalThreads consecutive run slots (one per thread) and the logo rows their windows touch
 struct EvalBand {

@@ -176,7 +176,7 @@ __device__ __forceinline__ void fetch_tile(TileDesc& D, const_tile_ptr t)
 // AB_LDS: the units' logo coefficients live in a second LDS plane of the wave ({a, b*maxv} at the unit's tile offset) instead of in
 // 16 registers -- for kernels that are short of registers.
 // SLIM: the byte offsets of the rows above / below a unit are re-derived at every request (4 more instructions) instead of kept (4
-// registers).
+// registers), and "this row is blended" rides in the sign bit of the unit's LDS offset instead of in a register of its own.
 template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileStager {
     static constexpr int ES = (int)sizeof(pix_t);
     // (wave-uniform)
@@ -209,8 +209,8 @@ template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileSta
         for (int k = 0; k < kTileUnits; ++k) {
             const TileUnit U = tile_unit(T, lane + 64 * k, w);
             const bool blend = deint && U.y > 0 && U.y < h - 1;       // DeintY copies the first and the last row (LogoScan.hpp:763-780)
-            ulds[k] = U.lds;
-            ubias[k] = blend ? Quad<pix_t>::kBias : 0u;
+            ulds[k] = SLIM ? (U.lds | (blend ? (int)0x80000000 : 0)) : U.lds;
+            if (!SLIM) ubias[k] = blend ? Quad<pix_t>::kBias : 0u;
             ug[k][1] = (srow0 + U.y * srow_step) * pitchB + (scol0 + U.xs) * ES;
             if (!SLIM) {
                 ug[k][0] = blend ? ug[k][1] - pitchB : ug[k][1];
@@ -220,7 +220,7 @@ template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileSta
             const f4 av = gld<f4a8>(gA, (unsigned)(U.y * w + U.xs) * 4u);
             const f4 bmv = gld<f4a8>(gB, (unsigned)(U.y * w + U.xs) * 4u) * maxv;     // rounded once, exactly as in a*s + b*maxv
             if (AB_LDS) {
-                f4* d = reinterpret_cast<f4*>(abplane + ulds[k]);
+                f4* d = reinterpret_cast<f4*>(abplane + U.lds);
                 d[0] = f4{av[0], bmv[0], av[1], bmv[1]};
                 d[1] = f4{av[2], bmv[2], av[3], bmv[3]};
             } else {
@@ -234,7 +234,7 @@ template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileSta
 #pragma unroll
         for (int k = 0; k < kTileUnits; ++k) {
             if (SLIM) {
-                const int d = ubias[k] ? pitchB : 0;              // a blended row: the rows above and below; otherwise the row itself
+                const int d = (ulds[k] >> 31) & pitchB;           // a blended row: the rows above and below; otherwise the row itself
                 raw[k][0].load(frame, ug[k][1] - d);
                 raw[k][1].load(frame, ug[k][1]);
                 raw[k][2].load(frame, ug[k][1] + d);
@@ -248,10 +248,12 @@ template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileSta
     __device__ __forceinline__ void convert_unit(int k)
     {
         float sv[4];
-        Quad<pix_t>::blend(raw[k][0], raw[k][1], raw[k][2], ubias[k], sv);
-        f2* dst = plane + ulds[k];
+        const unsigned bias = SLIM ? ((unsigned)(ulds[k] >> 31) & Quad<pix_t>::kBias) : ubias[k];
+        const int lds = SLIM ? (ulds[k] & 0x7FFFFFFF) : ulds[k];
+        Quad<pix_t>::blend(raw[k][0], raw[k][1], raw[k][2], bias, sv);
+        f2* dst = plane + lds;
         if (AB_LDS) {
-            const f4* c = reinterpret_cast<const f4*>(abplane + ulds[k]);
+            const f4* c = reinterpret_cast<const f4*>(abplane + lds);
             const f4 c0 = c[0], c1 = c[1];
             reinterpret_cast<f4*>(dst)[0] = f4{sv[0], c0[0] * sv[0] + c0[1], sv[1], c0[2] * sv[1] + c0[3]};
             reinterpret_cast<f4*>(dst)[1] = f4{sv[2], c1[0] * sv[2] + c1[1], sv[3], c1[2] * sv[3] + c1[3]};
@@ -286,6 +288,7 @@ struct TilePixel {
     int ridx;
     bool act;
     unsigned slot8;
+    unsigned slotbase8;              // (wave-uniform) slot8 of lane 0: slot8 == slotbase8 + 8 * lane, for kernels short of registers
     __device__ __forceinline__ void load(const TileLogoDev* Xp, unsigned slot, const TileDesc& T, unsigned plane_base)
     {
         const gptr_t gK = (gptr_t)Xp->kp, gInfo = (gptr_t)Xp->sinfo;
@@ -296,6 +299,7 @@ struct TilePixel {
         ridx = (int)((si >> 12) & 0xFFFu);
         act = (si >> 31) != 0;
         slot8 = slot * 8u;
+        slotbase8 = __builtin_amdgcn_readfirstlane(slot8);
 #pragma unroll
         for (int j = 0; j < 13; ++j) Kp[j] = gld<f2>(gK, (unsigned)j * nslots8 + slot8);
     }
