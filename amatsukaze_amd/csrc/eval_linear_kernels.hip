@@ -17,9 +17,10 @@
 // TILES (64 mask pixels and the bounding box of their windows) round-robin and never meet before the end: a wave stages its
 // tile for one frame into its own LDS plane as {s, bg} pairs -- raw samples prefetched into registers an iteration ahead --
 // evaluates the window mean and the correlation of BOTH operands with the same packed fp32 instructions (the 25 taps broadcast
-// to both halves), forms the fades, adds the terms over its lanes with DPP adds and keeps the sums per (frame, fade) in LDS
-// cells that only it touches.  The summation order of this mode is free (it is not the reference's; the error bound covers any
-// order) but fixed: lanes by DPP tree, tiles in turn, the four waves in order at the end -- deterministic.  No barrier in the loop.
+// to both halves), forms the fades, adds the terms over each quad of lanes with two DPP adds and keeps the quads' sums per (frame,
+// fade) in LDS cells that only it touches.  The summation order of this mode is free (it is not the reference's; the error bound
+// covers any order) but fixed: quads by DPP, tiles in turn, the 16 quads and the four waves in order at the end -- deterministic.
+// No barrier in the loop.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>
@@ -36,51 +37,40 @@ using namespace tile;
 #endif
 constexpr int kLinWaves = AMT_LIN_WAVES;     // waves per workgroup: one per SIMD, so that three workgroups always fit a CU at <= 168 registers
 constexpr int kLinWgThreads = kLinWaves * 64;
-// A wave's running sums of one frame: the C/D image of v_mfma_f32_16x16x4_f32 for rows 0..11 -- lane l < 48 owns 16 bytes, the
-// sums of fades 4*(l/16) .. +3 over the lanes congruent to l mod 16 (16 partial sums per fade, added up at the very end).
-#ifndef AMT_LIN_DIRECT_ENDS
-#define AMT_LIN_DIRECT_ENDS 1
-#endif
-#ifndef AMT_LIN_MFMA_CHAINS
-#define AMT_LIN_MFMA_CHAINS 1
-#endif
-constexpr int kLinAccLanes = 48;
-constexpr int kLinAccFrameBytes = kLinAccLanes * 16;
-
-// sum over the 64 lanes of a wave in a fixed order (DPP: every step is one v_add_f32); the total lands in lane 63
-__device__ __forceinline__ float wave_sum_dpp(float v)
-{
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));   // row_shr:1
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));   // row_shr:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));   // row_shr:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));   // row_shr:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));   // row_bcast:15
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, true));   // row_bcast:31
-    return v;
-}
+// A wave's running sums of one frame: 48 bytes per quad of lanes (twelve floats: the eleven fades' sums over the quad's mask pixels),
+// i.e. 16 partial sums per fade that are added up at the very end.  (Tried and not kept: the same sums on the matrix pipe,
+// v_mfma_f32_16x16x4_f32 with row selectors -- tools/ubench/mfma_rowsum.hip, profiles/r03_notes.md.)
+constexpr int kLinAccFrameBytes = 16 * 48;
 
 __device__ __forceinline__ int clamp_bin(int b) { return min(max(b, 0), 31); }      // (v_med3_i32)
 
-// mean of the blended window exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it (LogoScan.hpp:244-251, ComputeKernel.cpp:88-98),
-// one column at a time (the rare path of the bin select: few registers matter more than speed)
-__device__ __forceinline__ float exact_blend_mean_rolled(const unsigned (&wrow)[5], float fade)
+// mean of the blended window exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it (LogoScan.hpp:244-251, ComputeKernel.cpp:88-98):
+// the uncommon path of the bin select.  Two LDS round trips (rows 0-2, rows 3-4) instead of one per row: what this path costs
+// is mostly the latency of its reads.
+__device__ __forceinline__ float exact_blend_mean_2trips(const unsigned (&wrow)[5], float fade)
 {
     typedef const __attribute__((address_space(3))) f2* lds_pair;
-    const float omf = 1 - fade;
-    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f;
-#pragma unroll 1
-    for (int i = 0; i < 5; ++i) {
-        float v[5];
+    f2 e[3][5];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const f2 e = ((lds_pair)(unsigned long long)wrow[r])[i];
-            v[r] = fade_mix(fade, e.y, e.x);
-        }
-        (void)omf;
-        const float c = ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
-        c0 = i == 0 ? c : c0; c1 = i == 1 ? c : c1; c2 = i == 2 ? c : c2; c3 = i == 3 ? c : c3; c4 = i == 4 ? c : c4;
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) e[r][i] = ((lds_pair)(unsigned long long)wrow[r])[i];
+    float t01[5], v2[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        t01[i] = fade_mix(fade, e[0][i].y, e[0][i].x) + fade_mix(fade, e[1][i].y, e[1][i].x);
+        v2[i] = fade_mix(fade, e[2][i].y, e[2][i].x);
     }
-    return div25(hsum5(c0, c1, c2, c3, c4));
+    __builtin_amdgcn_sched_barrier(0);                             // (the second round of reads goes into the registers of the first)
+    f2 g[2][5];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) g[r][i] = ((lds_pair)(unsigned long long)wrow[3 + r])[i];
+    float c[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = (t01[i] + (v2[i] + fade_mix(fade, g[0][i].y, g[0][i].x))) + fade_mix(fade, g[1][i].y, g[1][i].x);
+    return div25(hsum5(c[0], c[1], c[2], c[3], c[4]));
 }
 
 struct LinLaunch {
@@ -215,42 +205,32 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     int pg = 0;                                                  // (scalar)
 #pragma unroll
     for (int f = 0; f < NFMAX; ++f) psc[f] = f2{0.0f, 0.0f};
+    // Sum over the wave: two DPP steps add the four lanes of every quad, lane 0 of the quad adds the eleven sums to the
+    // quad's running sums of the frame in LDS (48 bytes per quad: 16 partial sums per fade, added up at the very end).  A lane's
+    // cells are its own and LDS operations of a wave complete in order: no barrier, no atomics.
     auto flush_terms = [&]() {
-        // Sum over the wave on the matrix pipe, which is otherwise idle: with B[k][j] = term_f of lane 16 k + j and A[i][k] = (i == f),
-        // v_mfma_f32_16x16x4_f32 adds  D[f][j] += sum_k term_f[16 k + j]  -- an exact fp32 fma chain (products with 1.0 and 0.0), a
-        // fixed order.  Eleven of them (two accumulator chains, so that they issue back to back) leave 16 partial sums per fade in
-        // the accumulator image; the frame's running sums enter as C of the first chain and leave as one 16-byte write per lane.
-        // A lane's cells are its own and LDS operations of a wave complete in order: no barrier, no atomics.
-        // (A non-finite term turns the frame's other fades NaN as well: the decision guard lists such a frame for exact re-evaluation.)
         typedef __attribute__((address_space(3))) f4* lds_quad;
-        const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)pg * (unsigned)kLinAccFrameBytes + (unsigned)lane * 16u);
-        f4 c0 = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (lane < kLinAccLanes) c0 = *cell;
-        // the row selector of fade f: lanes with l % 16 == f; fade f's is fade f-1's moved up one lane within its row of 16 (DPP
-        // row_shr:1, zero shifted in): one instruction each.  (Plain C, not inline asm: the compiler does not see a vector write inside
-        // an asm block and omits the wait states an MFMA reading that register needs -- tools/ubench/mfma_rowsum.hip.)
-        // (the selectors are loop-invariant: left visible, the compiler keeps all eleven in registers across the loop)
-        int lane_opaque = lane;
-        asm volatile("" : "+v"(lane_opaque));
-        float sel = (lane_opaque & 15) == 0 ? 1.0f : 0.0f;
-#if AMT_LIN_MFMA_CHAINS == 2
-        f4 c1 = f4{0.0f, 0.0f, 0.0f, 0.0f};
-#endif
+        const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)pg * (unsigned)kLinAccFrameBytes + (unsigned)(lane >> 2) * 48u);
+        // (four fades at a time, fenced: left alone the scheduler computes all eleven terms first -- eleven registers too many)
 #pragma unroll
-        for (int f = 0; f < NFMAX; ++f) {
-            if (f > 0) sel = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sel), 0x111, 0xF, 0xF, true));
-            const float term = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;   // (LogoScan.hpp:305-308)
-#if AMT_LIN_MFMA_CHAINS == 2
-            if (f & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, term, c1, 0, 0, 0);
-            else
-#endif
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, term, c0, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);                     // (left alone the scheduler computes all terms first: eleven registers too many)
+        for (int q = 0; q < 3; ++q) {
+            float term[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * q + r;
+                if (f < NFMAX) {
+                    float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;   // (LogoScan.hpp:305-308)
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+                    term[r] = t;
+                } else term[r] = 0.0f;
+            }
+            if ((lane & 3) == 0) {
+                const f4 o = cell[q];
+                cell[q] = f4{o[0] + term[0], o[1] + term[1], o[2] + term[2], o[3] + term[3]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#if AMT_LIN_MFMA_CHAINS == 2
-        c0 += c1;
-#endif
-        if (lane < kLinAccLanes) *cell = c0;
     };
     while (i0 < ntl) {
         AMT_LTICK(0);
@@ -288,7 +268,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         // first fade is 0 and the last is 1.)  It matters: mean(s) is an integer / 25 and sits exactly ON a bin edge once in 200 pixels.
 #pragma unroll
         for (int f = 0; f < NFMAX; ++f) {
-            const bool end = AMT_LIN_DIRECT_ENDS && (f == 0 || f == NFMAX - 1);
+            const bool end = f == 0 || f == NFMAX - 1;
             const int qd = (int)(end ? (f == 0 ? m0q : m1q) : __builtin_fmaf(fd[f], dMq, m0q) + dqf);
             if (!end) emin = min(emin, (unsigned)qd & qmask);
             goff[f] = __umul24((unsigned)clamp_bin(qd >> qshift), nslots8) + slot8;
@@ -308,11 +288,11 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             asm volatile("" : "+v"(lane_here));                    //  reload waits for every load in flight)
             const float fadev = *(const __attribute__((address_space(3))) float*)(unsigned long long)(myfades_base + (unsigned)(lane_here & 15) * 4u);
 #pragma unroll 1
-            for (int f = AMT_LIN_DIRECT_ENDS; f < nfades - AMT_LIN_DIRECT_ENDS; ++f) {
+            for (int f = 1; f < nfades - 1; ++f) {
                 const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fadev), f));
                 const int qd = (int)(__builtin_fmaf(fade, dMq, m0q) + dqf);
                 if (near_edge && ((unsigned)qd & qmask) <= qwin) {
-                    const unsigned go = __umul24((unsigned)score_bin_dev(exact_blend_mean_rolled(wrow, fade)), nslots8) + px.slotbase8 + (unsigned)lane * 8u;
+                    const unsigned go = __umul24((unsigned)score_bin_dev(exact_blend_mean_2trips(wrow, fade)), nslots8) + px.slotbase8 + (unsigned)lane * 8u;
 #pragma unroll
                     for (int ff = 0; ff < NFMAX; ++ff) goff[ff] = ff == f ? go : goff[ff];
                 }
@@ -345,7 +325,9 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             advance(i2, g2);
             if (i2 < ntl) {
                 if (i2 != iu) { fetch_tile(T, tiles + tlist[i2]); st.setup_units(T, lane); iu = i2; }
+#ifndef AMT_LIN_NO_RAW                                           // (ablation: the samples of the first two requests are converted over and over)
                 st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + g2));
+#endif
             }
         }
         AMT_LTICK(1);
@@ -368,10 +350,10 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         const int gg = tid_end / nfades, f = tid_end - gg * nfades;
         float r = 0.0f;
         for (int q = 0; q < kLinWaves; ++q) {
-            const float* const cells = wacc + (q * G + gg) * (kLinAccFrameBytes / 4) + (f >> 2) * 64 + (f & 3);      // lane 16 (f / 4) + j, register f % 4
+            const float* const cells = wacc + (q * G + gg) * (kLinAccFrameBytes / 4) + f;      // quad j: 12 floats at 12 j
             float rq = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) rq += cells[j * 4];
+            for (int j = 0; j < 16; ++j) rq += cells[j * 12];
             r += rq;
         }
         r = r / Lp->blackScore;
