@@ -126,7 +126,9 @@ void logo_eval_pair_kernel(const PairLaunch A)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             AMT_PTICK(5);
             const int npix = bd[b].npix;
+#ifndef AMT_PAIR_NO_SUM                                         // (ablations of the instrumented builds: wrong results, timing only)
             if (lane < 2 * gcount) acc = ordered_row_sum(rows + ((b & 1) * 2 * G + lane) * kPairRowPitch, npix, acc);
+#endif
 #ifdef AMT_PAIR_TIMING
             asm volatile("" : "+v"(acc));
 #endif
@@ -183,14 +185,18 @@ void logo_eval_pair_kernel(const PairLaunch A)
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // (timing build: the wait for the raw samples on its own)
         AMT_PTICK(7);
 #endif
+#ifndef AMT_PAIR_NO_CONVERT
         st.convert();
+#endif
         AMT_PTICK(0);
         // ---- 2. the next iteration's raw samples travel during the evaluation (past the last iteration: a repeat nobody reads) ----
         if (band_end && b + 1 < nbands) {
             fetch_tile(T, tiles + (b + 1) * kTileWaves);
             st.setup_units(T, lane);
         }
+#ifndef AMT_PAIR_NO_RAW
         st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + (band_end ? 0 : g + 1)));
+#endif
         AMT_PTICK(1);
         // ---- 3. both fades of the frame: one packed window evaluation ----
         // (the taps are loop-invariant: LICM would hoist their {k,k} broadcasts and keep 50 registers of copies; the empty asm
@@ -200,17 +206,28 @@ void logo_eval_pair_kernel(const PairLaunch A)
         f2 W[25];
         unsigned wrow[5];
         px.rows(wrow);
+#ifdef AMT_PAIR_NO_EVAL
+        const f2 M = px.Kp[1] + f2{100.0f, 120.0f}, R = px.Kp[0];
+        (void)W;
+#else
         const f2 M = window_load_means(wrow, W);
         const f2 R = window_corr_exact(px.Kp, W, M);
+#endif
 #ifdef AMT_PAIR_TIMING
         { f2 Rt = R; asm volatile("" : "+v"(Rt)); }
 #endif
         AMT_PTICK(2);
         // ---- 4. the previous iteration's terms -> the band's score rows, at the pixel's raster position; then this iteration's two
         //      scale gathers go straight into the registers the terms were read from (a copy would wait for them here) ----
+#ifndef AMT_PAIR_NO_FLUSH
         flush_terms();
+#endif
+#ifdef AMT_PAIR_NO_GATHER
+        psc0 = f2{1e-3f, 1.0f} + M; psc1 = f2{1e-3f, 1.0f} - M;
+#else
         psc0 = gld<f2>(gSc, __umul24(score_bin_bounded(M.x), nslots8) + px.slot8);
         psc1 = gld<f2>(gSc, __umul24(score_bin_bounded(M.y), nslots8) + px.slot8);
+#endif
         pR = R; pact = px.act;
         AMT_PTICK(3);
         prow = (b & 1) * 2 * G + g * 2;
