@@ -79,7 +79,7 @@ public:
     size_t size() const { return n_; }
 };
 
-// tile plan of one evaluation logo resident in HBM (eval_tiles.hpp; eval_pair_kernels.hip).  slot = (band * 8 + wave) * 64 + lane
+// tile plan of one evaluation logo resident in HBM (eval_tiles.hpp; eval_pair_kernels.hip).  slot = (band * kTileWaves + wave) * 64 + lane
 struct TileLogoDev {
     const float2* kp;            // [13][nslots]  taps of the slot's mask pixel as pairs {k[2j], k[2j+1]} (k[25] = 0), pair-major
     const float2* sc;            // [32][nslots]  bin-major {scale, scale2} of the slot's mask pixel

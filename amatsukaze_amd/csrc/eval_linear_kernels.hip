@@ -337,10 +337,9 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     flush_terms();
     __syncthreads();
 #ifdef AMT_LIN_TIMING
-    if (lane == 0 && blockIdx.x == gridDim.x / 6 && (wave == 0 || wave == 2 || wave == 4 || wave == 5)) {      // a workgroup of logo 0 (the deint logo)
+    if (lane == 0 && blockIdx.x == gridDim.x / 6 && wave < 4) {      // a workgroup of logo 0 (the deint logo)
         long long* tb = reinterpret_cast<long long*>(A.out + (long long)A.nframes * A.out_frame_stride);      // host reserves room
-        const int slot = wave == 0 ? 0 : (wave == 2 ? 1 : (wave == 4 ? 2 : 3));
-        for (int k = 0; k < 8; ++k) tb[slot * 8 + k] = tacc[k];
+        for (int k = 0; k < 8; ++k) tb[wave * 8 + k] = tacc[k];
     }
 #endif
     // the waves' sums, in order: per wave the 16 partial sums of a fade, front to back

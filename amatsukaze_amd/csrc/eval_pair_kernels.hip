@@ -9,13 +9,13 @@
 // low half evaluates fade 0 and whose high half evaluates fade 1 -- no blend arithmetic, no FMA contraction
 // (-ffp-contract=off), the 25 taps broadcast to both halves through op_sel.
 //
-// Shape (eval_tiles.hpp): workgroup = (logo, G <= 8 frames) = 8 evaluation waves + 1 summing wave, walking the logo's bands of
-// <= 512 raster-consecutive mask pixels.  Within a band every evaluation wave owns a TILE: 64 of the band's mask pixels (the
+// Shape (eval_tiles.hpp): workgroup = (logo, G <= 8 frames) = kTileWaves (11) evaluation waves + 1 summing wave, walking the logo's
+// bands of <= 64 kTileWaves raster-consecutive mask pixels.  Within a band every evaluation wave owns a TILE: 64 of the band's mask pixels (the
 // band sorted by column and dealt out 64 at a time) and the bounding box of their 5x5 windows.  The wave stages its tile for
 // one frame per iteration into LDS nobody else touches -- raw samples prefetched into registers an iteration ahead, converted to
 // {s, bg} with the tile's logo coefficients held in registers for the whole band -- and evaluates its pixels from it.  LDS
 // operations of one wave complete in order, so nothing in an iteration needs a barrier.  The per-pixel terms go to an LDS row
-// per (frame, fade) at the pixel's raster position; the waves meet ONCE PER BAND, and the ninth wave then adds the band's
+// per (frame, fade) at the pixel's raster position; the waves meet ONCE PER BAND, and the last wave then adds the band's
 // 2 G rows front to back -- one lane per row, the reference's order (`result += score`, LogoScan.hpp:295-315) -- while the
 // others evaluate the next band into the second set of rows.
 //

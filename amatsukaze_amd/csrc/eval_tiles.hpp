@@ -1,13 +1,14 @@
-// eval_tiles.hpp -- host-side plan of the tile evaluation kernels (eval_pair_kernels.hip): bands of raster-consecutive mask
-// pixels, each split into up to eight wave tiles.  Pure C++ (no HIP) so that tests/cpp/eval_tiles_test.cpp can replay the
+// eval_tiles.hpp -- host-side plan of the tile evaluation kernels (eval_pair_kernels.hip, eval_linear_kernels.hip): bands of
+// raster-consecutive mask pixels, each split into up to kTileWaves wave tiles.  Pure C++ (no HIP) so that tests/cpp/eval_tiles_test.cpp can replay the
 // kernel's addressing on the CPU.
 //
-// Why tiles: CorrelationScore (LogoScan.hpp:288-318) adds the per-pixel terms in raster order, so the terms of a band of <= 512
-// raster-consecutive mask pixels go to an LDS row that one lane adds front to back.  WHICH thread evaluates a mask pixel is
-// free, though: a band's pixels are sorted by column and dealt to the eight evaluation waves 64 at a time, and every wave stages
+// Why tiles: CorrelationScore (LogoScan.hpp:288-318) adds the per-pixel terms in raster order, so the terms of a band of
+// <= kTileBandPix raster-consecutive mask pixels go to an LDS row that one lane adds front to back.  WHICH thread evaluates a mask
+// pixel is free, though: a band's pixels are sorted by column and dealt to the evaluation waves 64 at a time, and every wave stages
 // only the bounding box of its own pixels' 5x5 windows -- a tile of ~36 x 10 samples instead of a share of the band's full-width
 // rows -- into LDS that no other wave reads.  Staging, window reads and evaluation of a wave then need no workgroup barrier; the
-// waves meet once per band (eight frames), when the summing wave takes over the band's rows.
+// waves meet once per band (G frames), when the summing wave takes over the band's rows.  (The linear analysis kernel uses the
+// tiles alone: its summation order is free, so its waves never meet.)
 #pragma once
 
 #include <algorithm>
@@ -26,7 +27,7 @@ constexpr int kTileWaves = AMT_TILE_WAVES;            // evaluation waves per wo
 #endif
 constexpr int kTileMaxFrames = AMT_TILE_G;            // frames per workgroup: 2 * kTileMaxFrames score rows per band, twice (double buffer)
 constexpr int kTileLanes = 64;                        // mask pixels per tile
-constexpr int kTileBandPix = kTileWaves * kTileLanes; // 512: mask pixels per band, one LDS score row per (frame, fade)
+constexpr int kTileBandPix = kTileWaves * kTileLanes; // 704: mask pixels per band, one LDS score row per (frame, fade)
 constexpr int kTileCap = 512;                         // {s, bg} pairs an LDS tile plane holds (4 KB)
 constexpr int kTileUnits = kTileCap / 4 / kTileLanes; // staging units (one row x four columns) per lane per frame: 2
 

@@ -69,12 +69,12 @@ if a.what == "scan":
     print("  total                                    " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
     sys.exit(0)
 if a.what != "scan" and a.mode != "exact":
-    ln = ["loop bookkeeping", "next tile + request raw samples", "window reads + evaluation of s and bg", "fades (gathers, terms, fix-up)",
-          "DPP wave sums -> running sums", "tile end: next pixel + taps", "convert raw -> {s,bg}", "-"]
+    ln = ["loop bookkeeping", "convert next frame's tile, request the one after", "window reads + evaluation of s and bg", "bins of the 11 fades + fix-up",
+          "previous terms, quad sums -> running sums", "new tile's pixel + taps, scale gathers", "-", "-"]
     tot = t.sum(1)
-    print("linear kernel: cycles (s_memtime ticks) of a workgroup of the deint logo; waves 0, 2, 4, 5:")
+    print("linear kernel: cycles (s_memtime ticks) of a workgroup of the deint logo, its four waves (the timing build spills: indicative only):")
     for k in range(8):
-        print(f"  {ln[k]:36s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
+        print(f"  {ln[k]:48s} " + "  ".join(f"{t[w, k]:10d} ({100.0 * t[w, k] / max(1, tot[w]):4.1f}%)" for w in range(4)))
     print("  total                                " + "  ".join(f"{tot[w]:10d}        " for w in range(4)))
     sys.exit(0)
 names = ["band prologue (slot, taps)", "staging loads+LDS writes", "ordered sum (one wave)", "wait B1", "window reads", "fade loop",
