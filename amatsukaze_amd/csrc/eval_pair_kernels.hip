@@ -194,7 +194,9 @@ void logo_eval_pair_kernel(const PairLaunch A)
             fetch_tile(T, tiles + (b + 1) * kTileWaves);
             st.setup_units(T, lane);
         }
-#ifndef AMT_PAIR_NO_RAW
+#if defined(AMT_PAIR_RAW_SAMEFRAME)                             // (ablation: every request hits the cache -- separates the loads' latency from their issue cost)
+        st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, 0));
+#elif !defined(AMT_PAIR_NO_RAW)
         st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + (band_end ? 0 : g + 1)));
 #endif
         AMT_PTICK(1);
