@@ -1,3 +1,7 @@
+"""The unguarded linear analysis kernel against the exact GPU kernel on a small clip, frame by frame: max |difference|, which frames
+and which of the 33 scores exceed 1e-4.  What located this round's two bugs (an inline-asm row selector read too early by the MFMA
+behind it; v_readlane of a lane the divergent branch had switched off).  Honours AMTGPU_LIB (instrumented builds).
+    python tools/diag_linear_vs_exact.py [frames]        on the GPU box, from the repo root"""
 import sys, numpy as np, torch
 sys.path.insert(0,'.'); sys.path.insert(0,'tests'); sys.path.insert(0,'tools')
 import amt_synth as S
