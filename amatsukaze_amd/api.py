@@ -35,6 +35,12 @@ class Context:
     """AMTContext stand-in bound to one GPU (StreamUtils.hpp:343-511)."""
 
     def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        if use_torch_stream:
+            # torch BEFORE the library: both link libamdhip64, and the process must end up with one HIP runtime.  With torch's copy
+            # loaded first the library binds to it; the other way round torch initialises a second runtime and reports
+            # "No HIP GPUs are available".
+            import torch
+            torch.cuda.init()
         self.lib = binding.load()
         self.h = self.lib.amtgpu_context_create(device)
         if not self.h:

@@ -190,12 +190,25 @@ static int run_bench(int argc, char** argv)
     }
     double t_an[2] = {0, 0}, t_er[2] = {0, 0};
     uint64_t sum[2] = {0, 0};
-    for (int mode = 0; mode < 2; ++mode) {
+    const bool swap_order = std::getenv("AMT_BENCH_SWAP") != nullptr;      // (diagnostic: the fast mode first)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int mode = swap_order ? 1 - pass : pass;
         // AMTAnalyzeLogo pulled frame by frame (8 source frames per analysis frame)
         PClip an = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
         const int na = an->GetVideoInfo().num_frames;
         an->GetFrame(0, &env);
         PClip an2 = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
+        if (std::getenv("AMT_BENCH_VERBOSE")) {                      // per-call times of the first blocks (diagnostic)
+            PClip an4 = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
+            amtgpu_profile_enable(ctx->get(), 1);
+            for (int n = 0; n < std::min(na, 200); ++n) {
+                const double t = secs([&] { an4->GetFrame(n, &env); });
+                if (t > 2e-4) std::fprintf(stderr, "mode %d GetFrame(%d): %.3f ms\n", mode, n, t * 1e3);
+            }
+            char rep[4096];
+            if (amtgpu_profile_report(ctx->get(), rep, sizeof rep) >= 0) std::fprintf(stderr, "kernel times (name calls total_ms):\n%s\n", rep);
+            amtgpu_profile_enable(ctx->get(), 0);
+        }
         t_an[mode] = secs([&] { for (int n = 0; n < na; ++n) an2->GetFrame(n, &env); });
         // the MakeSource graph: AMTEraseLogo(src, AMTAnalyzeLogo(src, logo), logo) pulled in order, as the encoder does
         PClip an3 = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
