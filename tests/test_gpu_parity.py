@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import amt_synth as S
-from amtlib import Oracle, _ptr
+from amtlib import ROOT, Oracle, _ptr
 
 pytestmark = pytest.mark.gpu
 
@@ -506,6 +506,21 @@ def test_analyze_linear_guarded_mode(gpu, cfgname, bits):
     exact = AMTAnalyzeLogo(ctx, cs["logo"], 0.35).analyze(cs["dclip"])
     assert exact.tobytes() == want.tobytes()
     print(f"linear mode {cfgname}/{bits}: max err {err.max():.2e}, bounds {bounds}, refined {refined}/{n}")
+
+
+@pytest.mark.gpu
+def test_context_before_torch_touches_the_gpu():
+    """A fresh process that creates a Context BEFORE torch has initialised HIP: the library and torch both link libamdhip64 and must end
+    up on ONE runtime (torch's, loaded first) -- the other order left torch reporting "No HIP GPUs are available" (api.Context)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from amatsukaze_amd import Context\n"
+            "c = Context(0)\n"
+            "import torch\n"
+            "x = torch.ones(4, device='cuda:0'); torch.cuda.synchronize(); c.synchronize(); print(int(x.sum().item()))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("4"), r.stderr[-800:]
 
 
 def test_one_context_shared_by_two_host_threads(gpu):
