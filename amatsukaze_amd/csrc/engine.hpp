@@ -160,7 +160,7 @@ private:
     // linear mode (built on first use)
     void ensure_linear();
     bool linear_ready_ = false;
-    float vmax_unit_ = 1.0f;                       // max over logos / pixels of max(1, |a| + |b|): window values are <= this * maxv
+    float vmax_unit_ = 1.0f;                       // max over logos / pixels of max(1, |a| + |b|) (x 2 for fades outside [0, 1]): window values are <= this * maxv
     std::vector<double> lin_err_corr_, lin_err_sum_;   // per logo: the two parts of the error bound, in units of (u * vmax) and u
 };
 

@@ -320,7 +320,11 @@ void EvalEngine::ensure_linear()
         lin_err_corr_[i] = ecorr / black;                                       // x u x v
         lin_err_sum_[i] = ((double)T.count + 40.0) * tsum / black + 8.0;        // x u  (+ the final division / abs, results are O(1))
     }
-    vmax_unit_ = (float)(vunit * 2.0);          // fades of ReMakeLogo reach 1.9: |f| + |1-f| <= 3; analysis fades are in [0,1]; 2x margin
+    // v, the bound on window values in units of maxv: a blend with fades in [0, 1] is convex, so max(1, |a| + |b|) holds; fades
+    // outside that range (ReMakeLogo's reach 1.9: |f| + |1 - f| <= 3) get a factor 2
+    bool unit_fades = true;
+    for (float f : fades_) unit_fades = unit_fades && f >= 0.0f && f <= 1.0f;
+    vmax_unit_ = (float)(vunit * (unit_fades ? 1.0 : 2.0));
     linear_ready_ = true;
 }
 
@@ -356,11 +360,9 @@ void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitc
     const int nl = (int)specs_.size();
     // The interpolated mean is within 19 u v of the exactly evaluated one (7 + 7 roundings of the two means, 3 to combine them, 9 on
     // the exact side... see ensure_linear), v = a bound on the window values: fades in [0, 1] blend convexly, so v = max(1, |a| + |b|) * maxv
-    // (vmax_unit_ carries a factor 2 for fades outside that range).  The kernel compares in fixed point -- mean * 2^qlog2 with
-    // v * 2^qlog2 < 2^30 -- through three more fp32 roundings of values below v * 2^qlog2: 22 u v in all.
-    bool unit_fades = true;
-    for (float f : fades_) unit_fades = unit_fades && f >= 0.0f && f <= 1.0f;
-    const double vwin = (double)vmax_unit_ * (unit_fades ? 0.5 : 1.0) * (double)((1 << bits) - 1);
+    // (vmax_unit_, ensure_linear).  The kernel compares in fixed point -- mean * 2^qlog2 with v * 2^qlog2 < 2^30 -- through three more
+    // fp32 roundings of values below v * 2^qlog2: 22 u v in all.
+    const double vwin = (double)vmax_unit_ * (double)((1 << bits) - 1);
     const float bin_eps = (float)(22.0 / 16777216.0 * vwin * 1.0001);
     int qlog2 = 24;
     while (qlog2 > 4 && std::ldexp(vwin, qlog2) >= 1073741824.0) --qlog2;
