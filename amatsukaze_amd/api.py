@@ -367,6 +367,22 @@ class AMTEraseLogo:
         self.ctx.check(self.ctx.lib.amtgpu_erase_calc_fades(self.h, _p(analysis), num_frames, first, n, _p(out)))
         return out
 
+    def calc_fades_device(self, d_analysis, num_frames, first=0, nframes=None, analysis_first=0, out=None):
+        """CalcFade / CalcFade2 on the device: d_analysis = torch float32 [count, 33] records of source frames
+        [analysis_first, analysis_first + count) still in HBM; returns a torch float32 [nframes, 2] tensor (async)."""
+        import torch
+        n = num_frames - first if nframes is None else nframes
+        if out is None:
+            out = torch.empty((n, 2), dtype=torch.float32, device=d_analysis.device)
+        self.ctx.check(self.ctx.lib.amtgpu_erase_calc_fades_device(self.h, _p(d_analysis), analysis_first, int(d_analysis.shape[0]), num_frames,
+                                                                   first, n, _p(out)))
+        return out
+
+    def erase_device_fades(self, clip: DeviceClip, d_fades):
+        """Delogo with fades that are already on the device (calc_fades_device's output).  async"""
+        self.ctx.check(self.ctx.lib.amtgpu_erase_batch_dfades(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV,
+                                                              clip.pitchY, clip.pitchUV, clip.bits, clip.num_frames, _p(d_fades)))
+
     def erase(self, clip: DeviceClip, fades):
         fades = np.ascontiguousarray(fades, np.float32)
         self.ctx.check(self.ctx.lib.amtgpu_erase_batch(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV,

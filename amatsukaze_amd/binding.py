@@ -90,6 +90,9 @@ SIGNATURES = {
     "amtgpu_erase_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_erase_rect_batch": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_erase_get_rect": (c_i, [c_p, c_p]),
+    "amtgpu_erase_calc_fades_device": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "amtgpu_erase_batch_dfades": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "amtgpu_erase_rect_batch_dfades": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_analyze_get_rect": (c_i, [c_p, c_p]),
     "amtgpu_logoframe_get_rows": (c_i, [c_p, c_p]),
     "amtgpu_logoframe_get_columns": (c_i, [c_p, c_p]),
@@ -107,6 +110,8 @@ SIGNATURES = {
     "amtgpu_framestats_create": (c_p, [c_p, c_i, c_i, c_i]),
     "amtgpu_framestats_destroy": (None, [c_p]),
     "amtgpu_framestats_batch": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_i, c_p]),
+    "amtgpu_framestats_allgather": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "amtgpu_framestats_sharded": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p, c_i, c_i, c_i, c_p]),
     "amtgpu_cm_scene_changes": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "amtgpu_kfm_cadence": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "amtgpu_kfm_write_durations": (c_i, [c_p, c_p, c_i, c_s, c_p]),

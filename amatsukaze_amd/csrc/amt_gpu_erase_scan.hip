@@ -19,6 +19,8 @@ struct EraseGeom {
 };
 hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
                          int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades, int zero_identity);
+hipError_t launch_calc_fades(hipStream_t st, const float* danalysis, int analysis_first, int analysis_count, int num_frames, int first,
+                             int nframes, const uint8_t* dstate, int half, float2* dout);
 hipError_t launch_scan_border(hipStream_t st, int bits, const void* dY, const void* dU, const void* dV, long long strideY,
                               long long strideUV, int pitchY, int pitchUV, int imgx, int imgy, int cx, int cy, int w, int h,
                               int wUV, int hUV, int thy, int nframes, int4* dout);
@@ -48,6 +50,8 @@ struct AmtGpuErase {
     DevBuf<float2> dFades[2];
     hipEvent_t fadesUploaded[2] = {nullptr, nullptr};
     int fadeSlot = 0;
+    DevBuf<uint8_t> dState;         // frameState on the device (amtgpu_erase_calc_fades_device), for dStateFrames frames
+    int dStateFrames = -1;
     ~AmtGpuErase()
     {
         for (int i = 0; i < 2; ++i) {
@@ -125,7 +129,7 @@ int amtgpu_erase_calc_fades(AmtGpuErase* er, const float* analysis, int num_fram
 }
 
 static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY, int pitchUV,
-                         int bits, int nframes, const float* fades, bool rect_only)
+                         int bits, int nframes, const float* fades, bool rect_only, const float* d_fades = nullptr)
 {
     if (bits < 8 || bits > 16) throw std::runtime_error("[AMTEraseLogo] Unsupported pixel format");
     if (er->mode != 0) throw std::runtime_error("[AMTEraseLogo] only mode 0 is supported (debug overlay modes are out of scope)");
@@ -135,20 +139,25 @@ static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t 
     if (strideY % es || strideUV % es) throw std::runtime_error("frame stride not a multiple of the sample size");
     if (rect_only && (pitchY < P.w || pitchUV < P.wUV())) throw std::runtime_error("[AMTEraseLogo] rectangle pitch smaller than the logo width");
     er->ctx->bind();
-    const int slot = er->fadeSlot;
-    er->fadeSlot ^= 1;
-    if (!er->fadesUploaded[slot]) AMT_HIP(hipEventCreateWithFlags(&er->fadesUploaded[slot], hipEventDisableTiming));
-    else AMT_HIP(hipEventSynchronize(er->fadesUploaded[slot]));          // the upload two batches ago
-    if (er->fadesCap[slot] < (size_t)nframes) {
-        if (er->hFades[slot]) AMT_HIP(hipHostFree(er->hFades[slot]));
-        er->hFades[slot] = nullptr;
-        AMT_HIP(hipHostMalloc((void**)&er->hFades[slot], (size_t)nframes * sizeof(float2), hipHostMallocDefault));
-        er->fadesCap[slot] = (size_t)nframes;
-        er->dFades[slot].alloc(nframes);                                   // hipFree waits for the kernels that read the old copy
+    const float2* dfades = reinterpret_cast<const float2*>(d_fades);
+    if (!dfades) {
+        if (!fades) throw std::runtime_error("[AMTEraseLogo] null fades");
+        const int slot = er->fadeSlot;
+        er->fadeSlot ^= 1;
+        if (!er->fadesUploaded[slot]) AMT_HIP(hipEventCreateWithFlags(&er->fadesUploaded[slot], hipEventDisableTiming));
+        else AMT_HIP(hipEventSynchronize(er->fadesUploaded[slot]));          // the upload two batches ago
+        if (er->fadesCap[slot] < (size_t)nframes) {
+            if (er->hFades[slot]) AMT_HIP(hipHostFree(er->hFades[slot]));
+            er->hFades[slot] = nullptr;
+            AMT_HIP(hipHostMalloc((void**)&er->hFades[slot], (size_t)nframes * sizeof(float2), hipHostMallocDefault));
+            er->fadesCap[slot] = (size_t)nframes;
+            er->dFades[slot].alloc(nframes);                                   // hipFree waits for the kernels that read the old copy
+        }
+        std::memcpy(er->hFades[slot], fades, (size_t)nframes * sizeof(float2));
+        AMT_HIP(hipMemcpyAsync(er->dFades[slot].get(), er->hFades[slot], (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
+        AMT_HIP(hipEventRecord(er->fadesUploaded[slot], er->ctx->stream));
+        dfades = er->dFades[slot].get();
     }
-    std::memcpy(er->hFades[slot], fades, (size_t)nframes * sizeof(float2));
-    AMT_HIP(hipMemcpyAsync(er->dFades[slot].get(), er->hFades[slot], (size_t)nframes * sizeof(float2), hipMemcpyHostToDevice, er->ctx->stream));
-    AMT_HIP(hipEventRecord(er->fadesUploaded[slot], er->ctx->stream));
     EraseGeom g;
     g.w = P.w; g.h = P.h; g.wUV = P.wUV(); g.hUV = P.hUV();
     // rectangle-only planes start at the logo's top-left sample; the chroma row parity is a property of the logo's position in
@@ -162,7 +171,7 @@ static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t 
     // frames skipped.
     const bool skip_fade0 = er->zeroIdentity && (bits == 8 || bits == 16);
     AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
-                          nframes, er->dFades[slot].get(), skip_fade0 ? 1 : 0));
+                          nframes, dfades, skip_fade0 ? 1 : 0));
     er->ctx->prof_end(sp);
 }
 
@@ -176,6 +185,57 @@ int amtgpu_erase_rect_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64
                             int pitchUV, int bits, int nframes, const float* fades)
 {
     return guard(er->ctx, [&] { erase_launch(er, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, nframes, fades, true); });
+}
+
+int amtgpu_erase_batch_dfades(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY,
+                              int pitchUV, int bits, int nframes, const float* d_fades)
+{
+    return guard(er->ctx, [&] {
+        if (!d_fades && nframes > 0) throw std::runtime_error("[AMTEraseLogo] null device fades");
+        erase_launch(er, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, nframes, nullptr, false, d_fades);
+    });
+}
+
+int amtgpu_erase_rect_batch_dfades(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY,
+                                   int pitchUV, int bits, int nframes, const float* d_fades)
+{
+    return guard(er->ctx, [&] {
+        if (!d_fades && nframes > 0) throw std::runtime_error("[AMTEraseLogo] null device fades");
+        erase_launch(er, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, nframes, nullptr, true, d_fades);
+    });
+}
+
+// CalcFade / CalcFade2 on the device (erase_scan_kernels.hip calc_fades_kernel); the host routine above stays the checker's
+// counterpart and what the per-frame filter layer uses
+int amtgpu_erase_calc_fades_device(AmtGpuErase* er, const float* d_analysis, int analysis_first, int analysis_count, int num_frames,
+                                   int first, int nframes, float* d_fades_out)
+{
+    return guard(er->ctx, [&] {
+        if (first < 0 || nframes < 0 || first + nframes > num_frames) throw std::runtime_error("frame range outside the clip");
+        if (nframes == 0) return;
+        if (!d_analysis || !d_fades_out) throw std::runtime_error("[AMTEraseLogo] null device pointer");
+        // every record the decision of [first, first + nframes) can read: n - 8 .. n + 8, clamped the reference's way (which keeps
+        // reads at the clip's ends inside the first / last eight frames)
+        const int need0 = std::max(0, first - 8), need1 = std::min(num_frames, first + nframes + 8);
+        if (analysis_first < 0 || analysis_count <= 0 || analysis_first > need0 || analysis_first + analysis_count < need1)
+            throw std::runtime_error("[AMTEraseLogo] the analysis records do not cover frames first-8 .. first+nframes+8 (CalcFade2's window)");
+        er->ctx->bind();
+        const uint8_t* dstate = nullptr;
+        if (er->haveLogof) {
+            if ((int)er->frameState.size() != num_frames) er->frameState = parse_logoframe(er->logofText, num_frames);
+            if (er->dStateFrames != num_frames) {
+                std::vector<uint8_t> st(num_frames);
+                for (int i = 0; i < num_frames; ++i) st[i] = (uint8_t)er->frameState[i];
+                er->dState.upload(st, er->ctx->stream);          // (synchronous: once per clip)
+                er->dStateFrames = num_frames;
+            }
+            dstate = er->dState.get();
+        }
+        const int sp = er->ctx->prof_begin("calc_fades_kernel");
+        AMT_HIP(launch_calc_fades(er->ctx->stream, d_analysis, analysis_first, analysis_count, num_frames, first, nframes, dstate,
+                                  er->maxFade >> 1, reinterpret_cast<float2*>(d_fades_out)));
+        er->ctx->prof_end(sp);
+    });
 }
 
 int amtgpu_erase_get_rect(const AmtGpuErase* er, int* out5)

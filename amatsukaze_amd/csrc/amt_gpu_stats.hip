@@ -3,6 +3,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "api_common.hpp"
 #include "stats_decisions.hpp"
@@ -16,7 +18,56 @@ using namespace amt;
 struct AmtGpuFrameStats {
     AmtGpuContext* ctx;
     int width, height, bits;
+    DevBuf<unsigned long long> dShard;      // amtgpu_framestats_sharded: the local records before the exchange
 };
+
+namespace {
+// the exchange of amtgpu_framestats_allgather.  A rank whose own part failed (local_error) still enters every collective with
+// neutral data -- the others would block in it for ever -- and all ranks throw together once the status is known.
+void gather_frame_metrics(const AmtGpuCollectives* coll, const uint64_t* local, int first, int nlocal, int num_frames,
+                          uint64_t* out, std::string local_error)
+{
+    const size_t rec = AMTGPU_FS_WORDS;
+    const bool sharded = coll && coll->world > 1;
+    if (local_error.empty()) {
+        if (num_frames < 0 || first < 0 || nlocal < 0 || (long long)first + nlocal > num_frames) local_error = "frame range outside the clip";
+        else if (!out || (nlocal > 0 && !local)) local_error = "null metrics pointer";
+    }
+    if (!sharded) {
+        if (!local_error.empty()) throw std::runtime_error(local_error);
+        if (first != 0 || nlocal != num_frames) throw std::runtime_error("a single rank must hold the whole clip");
+        if (nlocal) std::memcpy(out, local, (size_t)nlocal * rec * sizeof(uint64_t));
+        return;
+    }
+    if (!coll->allgather || coll->rank < 0 || coll->rank >= coll->world) throw std::runtime_error("AmtGpuCollectives incomplete");
+    const bool ok = local_error.empty();
+    const int64_t mine[3] = {ok ? first : 0, ok ? nlocal : 0, ok ? 1 : 0};
+    std::vector<int64_t> ranges((size_t)coll->world * 3);
+    if (!coll->allgather(coll->user, mine, ranges.data(), sizeof mine)) throw std::runtime_error("allgather failed");
+    bool all_ok = true;
+    int64_t nmax = 0, next = 0;
+    bool tiles = true;                          // ranks hold contiguous ranges in rank order that tile [0, num_frames)
+    for (int r = 0; r < coll->world; ++r) {
+        const int64_t f = ranges[3 * r], n = ranges[3 * r + 1];
+        all_ok = all_ok && ranges[3 * r + 2] == 1;
+        tiles = tiles && f == next && n >= 0;
+        next = f + n;
+        nmax = std::max(nmax, n);
+    }
+    tiles = tiles && next == num_frames;
+    if (!ok) throw std::runtime_error(local_error);
+    if (!all_ok) throw std::runtime_error("another rank failed before the exchange of the frame metrics");
+    if (!tiles) throw std::runtime_error("the ranks' frame ranges do not tile the clip in rank order");
+    if (nmax == 0) return;
+    std::vector<uint64_t> send((size_t)nmax * rec, 0), recv((size_t)nmax * rec * coll->world);
+    if (nlocal) std::memcpy(send.data(), local, (size_t)nlocal * rec * sizeof(uint64_t));
+    if (!coll->allgather(coll->user, send.data(), recv.data(), (int64_t)(send.size() * sizeof(uint64_t)))) throw std::runtime_error("allgather failed");
+    for (int r = 0; r < coll->world; ++r) {
+        const int64_t f = ranges[3 * r], n = ranges[3 * r + 1];
+        if (n) std::memcpy(out + (size_t)f * rec, recv.data() + (size_t)r * nmax * rec, (size_t)n * rec * sizeof(uint64_t));
+    }
+}
+} // namespace
 
 extern "C" {
 
@@ -40,6 +91,39 @@ int amtgpu_framestats_batch(AmtGpuFrameStats* fs, const void* dY, int64_t frame_
         AMT_HIP(launch_frame_stats(fs->ctx->stream, fs->bits, dY, frame_stride, pitch, fs->width, fs->height, dprevY, nframes,
                                    (unsigned long long*)dout));
         fs->ctx->prof_end(sp);
+    });
+}
+
+int amtgpu_framestats_allgather(AmtGpuFrameStats* fs, const AmtGpuCollectives* coll, const uint64_t* local_metrics, int first, int nlocal,
+                                int num_frames, uint64_t* metrics_out)
+{
+    return guard(fs->ctx, [&] { gather_frame_metrics(coll, local_metrics, first, nlocal, num_frames, metrics_out, std::string()); });
+}
+
+int amtgpu_framestats_sharded(AmtGpuFrameStats* fs, const AmtGpuCollectives* coll, const void* dY, int64_t frame_stride, int pitch,
+                              const void* dprevY, int first, int nlocal, int num_frames, uint64_t* metrics_out)
+{
+    return guard(fs->ctx, [&] {
+        std::string err;
+        std::vector<uint64_t> local;
+        try {
+            if (first < 0 || nlocal < 0 || (long long)first + nlocal > num_frames) throw std::runtime_error("frame range outside the clip");
+            // the first frame of a shard is compared with the frame before it: only the shard that starts the clip has none
+            if (first > 0 && nlocal > 0 && !dprevY) throw std::runtime_error("[FrameStats] a shard that does not start the clip needs the frame before it (dprevY)");
+            if (nlocal > 0) {
+                fs->ctx->bind();
+                const size_t n = (size_t)nlocal * AMTGPU_FS_WORDS;
+                if (fs->dShard.size() < n) fs->dShard.alloc(n);
+                const int sp = fs->ctx->prof_begin("frame_stats_kernel");
+                AMT_HIP(launch_frame_stats(fs->ctx->stream, fs->bits, dY, frame_stride, pitch, fs->width, fs->height, first > 0 ? dprevY : nullptr,
+                                           nlocal, fs->dShard.get()));
+                fs->ctx->prof_end(sp);
+                local.resize(n);
+                AMT_HIP(hipMemcpyAsync(local.data(), fs->dShard.get(), n * sizeof(uint64_t), hipMemcpyDeviceToHost, fs->ctx->stream));
+                AMT_HIP(hipStreamSynchronize(fs->ctx->stream));
+            }
+        } catch (const std::exception& e) { err = e.what(); }
+        gather_frame_metrics(coll, local.data(), first, nlocal, num_frames, metrics_out, err);
     });
 }
 

@@ -194,6 +194,92 @@ hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV,
 }
 
 // ------------------------------------------------------------------------------------------------
+// AMTEraseLogo::CalcFade / CalcFade2 (LogoScan.hpp:1263-1341) for a whole batch: one thread per frame.  The decision reads
+// nine analysis records around frame n (the argmin over the 11 fades of p for each; t and b of the centre one) -- 99 + 22 floats
+// of a table that is L2 resident -- so this is a latency-sized kernel whose point is that the fades never leave the device:
+// analysis -> fades -> Delogo is one stream-ordered chain without a host synchronise in the middle.
+// Index arithmetic as decisions.cpp fade_from_analysis: k = clamp(n + i) + i, analyze frame q = clamp(k >> 3), source frame
+// clamp(8 q + (k & 7)) -- the AviSynth cache's clamping of the analyze clip's frame number, negative k included.
+// ------------------------------------------------------------------------------------------------
+// i / 10.0f for i = 0..10 and the two threshold tests of (sum of four argmins) / 40 against 0.3 and 0.7 for every possible sum 0..40,
+// all evaluated on the host exactly as the reference writes them (float division, comparison against double literals): the
+// kernel itself does no floating-point arithmetic, so nothing depends on the device's division
+struct FadeTable { float v[11]; unsigned long long below03, above07; };
+
+__device__ __forceinline__ int argmin11_dev(const float* __restrict__ v)
+{
+    int best = 0;
+    float bv = v[0];
+#pragma unroll
+    for (int i = 1; i < 11; ++i) {
+        const float x = v[i];
+        if (x < bv) { bv = x; best = i; }       // strict <: the first minimum wins, NaN never does (as the host loop)
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(128)
+void calc_fades_kernel(const float* __restrict__ analysis, int analysis_first, int analysis_count, int num_frames, int first, int nframes,
+                       const uint8_t* __restrict__ frame_state /* null = no logoframe file */, int half, FadeTable tab,
+                       float2* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nframes) return;
+    const int n = first + i;
+    const int last = num_frames - 1;
+    auto clampf = [&](int v) { return max(0, min(last, v)); };
+    if (frame_state) {
+        // CalcFade (:1317-1341): a window of maxfade frames in one state -> fade 1 if that state is "logo on", else 0
+        const int st0 = frame_state[clampf(n - half)];
+        bool uniform = true;
+        for (int d = -half + 1; d <= half; ++d) uniform = uniform && frame_state[clampf(n + d)] == st0;
+        if (uniform) {
+            const float f = frame_state[clampf(n)] == 2 ? 1.0f : 0.0f;
+            out[i] = make_float2(f, f);
+            return;
+        }
+    }
+    const int nAnalyze = (num_frames + 7) / 8;
+    int best[9];
+    const float* centre = analysis;
+#pragma unroll
+    for (int d = -4; d <= 4; ++d) {
+        const int k = clampf(n + d) + d;
+        const int q = max(0, min(nAnalyze - 1, k >> 3));
+        const int src = clampf(q * 8 + (k & 7));
+        // the host has checked that every record read lies inside [analysis_first, analysis_first + analysis_count)
+        const int rel = max(0, min(analysis_count - 1, src - analysis_first));
+        const float* rec = analysis + (size_t)rel * 33;
+        best[d + 4] = argmin11_dev(rec);
+        if (d == 0) centre = rec;
+    }
+    const int before = best[3] + best[2] + best[1] + best[0], after = best[5] + best[6] + best[7] + best[8];     // 0..40 each
+    auto bit = [](unsigned long long m, int s) { return ((m >> s) & 1ull) != 0; };
+    const bool abrupt = (bit(tab.below03, before) && bit(tab.above07, after)) || (bit(tab.above07, before) && bit(tab.below03, after));
+    if (abrupt) out[i] = make_float2(tab.v[argmin11_dev(centre + 11)], tab.v[argmin11_dev(centre + 22)]);
+    else out[i] = make_float2(tab.v[best[4]], tab.v[best[4]]);
+}
+
+hipError_t launch_calc_fades(hipStream_t st, const float* danalysis, int analysis_first, int analysis_count, int num_frames, int first,
+                             int nframes, const uint8_t* dstate, int half, float2* dout)
+{
+    if (nframes <= 0) return hipSuccess;
+    FadeTable tab;
+    for (int i = 0; i < 11; ++i) tab.v[i] = (float)i / 10.0f;
+    tab.below03 = tab.above07 = 0;
+    for (int s = 0; s <= 40; ++s) {
+        float q = 0;
+        q += s;                 // (the sum of four small integers is exact in fp32 whatever the order)
+        q /= 40;
+        if (q < 0.3) tab.below03 |= 1ull << s;
+        if (q > 0.7) tab.above07 |= 1ull << s;
+    }
+    hipLaunchKernelGGL(calc_fades_kernel, dim3((unsigned)((nframes + 127) / 128)), dim3(128), 0, st, danalysis, analysis_first,
+                       analysis_count, num_frames, first, nframes, dstate, half, tab, dout);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // LogoScan::AddFrame, first half (LogoScan.hpp:604-653): the rectangle's border samples of each plane,
 // reject when max-min > thy, else background = med_average (:414-428) = (int)((sum of the middle half of
 // the sorted samples + nn/2) / nn).  Sorting is replaced by a histogram (exact: the sorted sequence is

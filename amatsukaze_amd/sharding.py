@@ -8,6 +8,9 @@ frame range with no data-path collective.  What has to be exchanged is tiny and 
     numMaxFrames quota ("first N valid frames in stream order", LogoScan.hpp:885)  -> all_gather + all_reduce
   * erase needs analysis records of 8 frames either side of a shard for CalcFade2 (:1265-1285): recomputed
     locally as a halo, nothing is sent.
+  * the self-specified CM / KFM frame metrics compare a frame with the one before it: a shard brings the frame before its
+    range along as a one-frame halo (decoded locally, nothing is sent), the 64-byte metric records are all-gathered and the
+    cadence / scene-change decisions run replicated on every rank             -> all_gather   (64 B per frame)
 Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests).
 """
 from __future__ import annotations
@@ -123,6 +126,28 @@ class TorchCollectives:
 def logoframe_allgather(lf, first: int, nlocal: int, coll: TorchCollectives):
     """after lf.scan_batch over this rank's frames [first, first+nlocal): every rank gets the whole clip's records"""
     lf.ctx.check(lf.ctx.lib.amtgpu_logoframe_allgather_results(lf.h, coll.ref(), first, nlocal))
+
+
+def framestats_allgather(fs, local_metrics, first: int, num_frames: int, coll: TorchCollectives):
+    """amtgpu_framestats_allgather: this rank's (nlocal, 8) uint64 records of frames [first, first + nlocal) -> the whole clip's
+    (num_frames, 8) records on every rank; the cadence / scene-change decisions then run replicated (fs.cadence, fs.scene_changes)."""
+    local = np.ascontiguousarray(local_metrics, np.uint64).reshape(-1, 8)
+    out = np.zeros((num_frames, 8), np.uint64)
+    from .api import _p
+    fs.ctx.check(fs.ctx.lib.amtgpu_framestats_allgather(fs.h, coll.ref() if coll is not None else None, _p(local), first, int(local.shape[0]),
+                                                        num_frames, _p(out)))
+    return out
+
+
+def framestats_sharded(fs, Y, first: int, num_frames: int, coll: TorchCollectives, prevY=None):
+    """amtgpu_framestats_sharded: Y = this rank's frames [first, first + n) resident in HBM, prevY = frame first - 1 (the one-frame
+    halo; None on the rank that starts the clip) -> (num_frames, 8) uint64 records of the whole clip on every rank."""
+    from .api import _p
+    es = 1 if fs.bits <= 8 else 2
+    out = np.zeros((num_frames, 8), np.uint64)
+    fs.ctx.check(fs.ctx.lib.amtgpu_framestats_sharded(fs.h, coll.ref() if coll is not None else None, _p(Y), int(Y.stride(0)) * es, int(Y.stride(1)),
+                                                      _p(prevY), first, int(Y.shape[0]), num_frames, _p(out)))
+    return out
 
 
 def scan_logo_sharded(ctx, clip_local, serviceid, dstpath, imgx, imgy, w, h, thy, numMaxFrames, coll: TorchCollectives, cb=None):

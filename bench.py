@@ -5,7 +5,7 @@ One "step" = one pass of the hot path over one HBM-resident batch of frames (con
     AMTAnalyzeLogo (33 evaluations per frame, LogoScan.hpp:1119-1161)
  -> LogoFrame scan (2 candidate logos + 1 erase logo, :1543-1568) and the whole-frame field-difference / combing
     metrics (self-specified CM / KFM pass) on the source frames, while the host turns the analysis records into fades
- -> CalcFade on the host (:1317-1341)  -> AMTEraseLogo in place (:1248-1261, :1374-1397)
+ -> CalcFade on the device (:1317-1341, amtgpu_erase_calc_fades_device)  -> AMTEraseLogo in place (:1248-1261, :1374-1397)
 Inputs are already in HBM when the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
@@ -74,6 +74,15 @@ def parse_args():
     ap.add_argument("--no-alt-mode", action="store_true", help="do not time the other analysis mode after the timed region (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the attached measurements of BASELINE configs[2], the 10-bit format and ScanLogo")
     ap.add_argument("--exact-steps", type=int, default=40, help="timed steps of the same pass with the exact (bit-identical) analysis, reported as exact_mode")
+    ap.add_argument("--workload", choices=("headline", "e2e10"), default="headline",
+                    help="e2e10: BASELINE configs[4] (tools/bench_e2e.py) as the line's own workload, frames sharded over --gpus ranks (strong scaling)")
+    ap.add_argument("--e2e-frames", type=int, default=0, help="frames of the e2e10 stream (default: 53 946 = one GPU's share of the 4-hour stream at N = 8; "
+                                                              "431568 = the whole stream)")
+    ap.add_argument("--e2e-chunk", type=int, default=1024, help="frames generated and processed per chunk of the e2e10 stream")
+    ap.add_argument("--fades", choices=("device", "host"), default="device",
+                    help="where CalcFade runs inside the step: device = amtgpu_erase_calc_fades_device, the whole step stream-ordered (default); "
+                         "host = round 3's step (records to the host, host CalcFade while the scan runs, fades back up)")
+    ap.add_argument("--no-e2e", action="store_true", help="do not attach the e2e10 measurement to the default line")
     ap.add_argument("--analysis-mode", choices=("linear", "exact"), default="linear",
                     help="AMTAnalyzeLogo evaluation: linear = all fades from one window evaluation of s and bg, decisions guarded by exact "
                          "re-evaluation (identical fades / erased frames, scores within 1e-4); exact = the reference's fp32 order for every fade")
@@ -396,6 +405,34 @@ def main():
     logos = [Logo.from_planes(ctx, d, LW, LH, W, H, IMGX, IMGY) for d in logos_np]
 
     # ================================================================================================================
+    # BASELINE configs[4]: end-to-end 10-bit stream, frames sharded (tools/bench_e2e.py)
+    # ================================================================================================================
+    def e2e10():
+        import types
+        import bench_e2e
+        E = types.SimpleNamespace(torch=torch, dist=dist, rank=rank, world=world, dev=dev, ctx=ctx, logos_np=logos_np, alpha=alpha, alphaUV=alphaUV,
+                                  fence=fence, max_over_ranks=max_over_ranks, OracleLogos=OracleLogos, maskratio=MASKRATIO)
+        return bench_e2e.run(E, nt=args.e2e_frames or bench_e2e.SHARE_FRAMES, chunk=args.e2e_chunk, verify=not args.no_verify, mode=args.analysis_mode)
+
+    if args.workload == "e2e10":
+        r = e2e10()
+        if rank == 0:
+            if r["verified"]["ok"] is False:
+                print(json.dumps({"e2e10": r}), file=sys.stderr, flush=True)
+                raise SystemExit("e2e10 verification FAILED: sampled blocks differ from the CPU oracle")
+            line = {"metric": "frames/sec 1920x1080i 10-bit logo+CM+KFM end-to-end pass", "value": r["value"], "unit": "frames/sec", "n_gpus": world,
+                    "steps": 1, "warmup": 0, "ms_per_step": r["timed_s"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": r["workload"], "frames_total": r["frames_total"], "logo": f"{LW}x{LH}@(1600,64)", "maskratio": MASKRATIO,
+                               "analysis_mode": args.analysis_mode, "parallelism": f"frames sharded x{world}"},
+                    "collectives": rccl, "e2e10": r}
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ================================================================================================================
     # strong scaling: BASELINE configs[3] -- the all-frames LogoFrame scan of a 60-minute stream, frames sharded
     # ================================================================================================================
     def strong_scan():
@@ -506,6 +543,7 @@ def main():
     d_analysis = torch.empty((N, 33), dtype=torch.float32, device=dev)
     d_stats = torch.empty((N, 8), dtype=torch.int64, device=dev)
     h_analysis = torch.empty((N, 33), dtype=torch.float32).pin_memory()
+    d_fades = torch.empty((N, 2), dtype=torch.float32, device=dev)
     an_ready = torch.cuda.Event()
     last = {}
     # AMTEraseLogo rewrites the logo rectangle in place; every frame is erased ONCE in a real run, so the step puts the rectangles
@@ -537,10 +575,15 @@ def main():
         lf.scan_batch(dclip.Y, 8, 0, N)                              # a9: all-frames scan, 3 logos x 2 fades
         stats.run_device(dclip.Y, d_stats)                           # CM field-diff + KFM comb metrics (source frames)
         if not args.no_erase:
-            an_ready.synchronize()                                   # the host decides while the scan / metrics kernels run
-            fades = eraser.calc_fades(h_analysis.numpy(), N)         # a12 CalcFade / CalcFade2
-            eraser.erase(dclip, fades)                               # a12 Delogo, in place
-            last["fades"] = fades
+            if args.fades == "device":
+                eraser.calc_fades_device(d_analysis, N, out=d_fades)     # a12 CalcFade / CalcFade2 on the device: no host round trip
+                eraser.erase_device_fades(dclip, d_fades)                # a12 Delogo, in place
+                last["fades"] = None                                     # (read back from d_fades where needed, outside the timed region)
+            else:
+                an_ready.synchronize()                                   # the host decides while the scan / metrics kernels run
+                fades = eraser.calc_fades(h_analysis.numpy(), N)         # a12 CalcFade / CalcFade2
+                eraser.erase(dclip, fades)                               # a12 Delogo, in place
+                last["fades"] = fades
             if restore:
                 restore_rectangles()                                 # bench housekeeping (inside the timed region, ~0.3 ms)
         if world > 1 and collective:
@@ -559,6 +602,8 @@ def main():
     prof = ctx.profile_report()
     ctx.profile(False)
     elapsed = max_over_ranks(elapsed)
+    if not args.no_erase and last.get("fades") is None:
+        last["fades"] = d_fades.cpu().numpy()
 
     # ---- the same pass with the exact (bit-identical records) analysis, for the record next to the headline ----
     exact_mode = None
@@ -591,11 +636,13 @@ def main():
         phases["scan"], _ = timed(lambda: lf.scan_batch(dclip.Y, 8, 0, N))
         phases["frame_metrics"], _ = timed(lambda: stats.run_device(dclip.Y, d_stats))
         phases["host_calc_fades"], fd = timed(lambda: eraser.calc_fades(h_analysis.numpy(), N))
+        phases["device_calc_fades"], _ = timed(lambda: eraser.calc_fades_device(d_analysis, N, out=d_fades))
         phases["erase"], _ = timed(lambda: eraser.erase(dclip, fd))
         phases["restore_rectangles_bench_housekeeping"], _ = timed(restore_rectangles)
         phases = {k: round(v, 3) for k, v in phases.items()}
-        phases["note"] = ("each call fenced with a device synchronise (so launch latency is inside every figure); in the timed steps the host "
-                          "fade computation overlaps the scan and the frame metrics")
+        phases["note"] = ("each call fenced with a device synchronise (so launch latency is inside every figure); the timed steps use "
+                          + ("the device CalcFade: the whole step is stream-ordered, the host only enqueues" if args.fades == "device" else
+                             "the host CalcFade, overlapped with the scan and the frame metrics"))
 
     # ---- verification (untimed): fresh frames, one more step at the same launch geometry, sampled blocks vs the oracle ----
     verified = None
@@ -620,6 +667,11 @@ def main():
             del exact_an
         step(collective=False, restore=False)                        # rank 0 alone; the erased frames are what gets checked
         torch.cuda.synchronize()
+        if not args.no_erase and last.get("fades") is None:
+            last["fades"] = d_fades.cpu().numpy()
+            # the device decision against the host routine on the same records (bytes, every frame)
+            if eraser.calc_fades(h_analysis.numpy(), N).tobytes() != last["fades"].tobytes():
+                raise SystemExit("bench verification FAILED: amtgpu_erase_calc_fades_device differs from the host CalcFade")
         outputs = (lf.evalResults, h_analysis.numpy(), last.get("fades"), dclip, d_stats.cpu().numpy().astype(np.uint64))
         verified = verify_step(N, blocks, outputs, pristine, logos_np, not args.no_erase, 1e-4 if args.analysis_mode == "linear" else 0.0)
         verified["analysis_mode"] = args.analysis_mode
@@ -660,6 +712,8 @@ def main():
         dist.barrier()
 
     # free the batch before the attached measurements
+    d_fades_host = d_fades.cpu().numpy()
+    del d_fades
     del dclip, lf, analyzer, eraser, stats, d_analysis, d_stats, dst_views, rect
     torch.cuda.empty_cache()
 
@@ -683,6 +737,20 @@ def main():
             except Exception as e:                                   # never lose the line to an attached measurement
                 configs[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+
+    # BASELINE configs[4] end to end, strong-sharded over the ranks of this run (every rank takes part; the same stream at every N)
+    e2e = None
+    if not args.no_e2e and not args.no_configs:
+        try:
+            e2e = e2e10()
+        except SystemExit:
+            raise
+        except Exception as e:
+            e2e = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+        if rank == 0 and e2e and e2e.get("verified", {}).get("ok") is False:
+            print(json.dumps({"e2e10": e2e}), file=sys.stderr, flush=True)
+            raise SystemExit("e2e10 verification FAILED: sampled blocks differ from the CPU oracle")
+        torch.cuda.empty_cache()
 
     boundary = None
     if rank == 0 and world == 1 and not args.no_configs:
@@ -719,6 +787,8 @@ def main():
         except Exception:
             pass
 
+        if "fades" in last and last["fades"] is None:
+            last["fades"] = d_fades_host
         erased_share = float((np.abs(last["fades"]).sum(axis=1) != 0).mean()) if "fades" in last else 1.0
 
         def kernel_entry(name, calls, ms, frames_per_call, timed):
@@ -779,7 +849,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"single MI355X: {N}-frame 1440x1080i 8-bit YUV420 resident in HBM; AMTAnalyzeLogo + LogoFrame scan (3 logos) "
                                    "+ CM/KFM frame metrics + CalcFade + AMTEraseLogo (BASELINE configs[1])",
-                       "analysis_mode": args.analysis_mode,
+                       "analysis_mode": args.analysis_mode, "calc_fade": args.fades,
                        "frames_per_gpu": N, "logo": f"{LW}x{LH}@({IMGX},{IMGY})", "maskratio": MASKRATIO,
                        "parallelism": f"frames sharded x{world} (one private batch per rank)" if world > 1 else "single GPU"},
             "timed_region_s": elapsed, "step_phases_ms": phases, "collectives": rccl,
@@ -787,7 +857,7 @@ def main():
             "gpu_over_cpu": (fps / cpu["value"]) if cpu else None,
             "gpu_over_cpu_all_cores": (fps / cpu["all_cores"]["value"]) if cpu else None,
             "exact_mode": exact_mode,
-            "verified": verified, "configs": configs, "boundary": boundary, "strong_scan": strong, "ingest": ingest,
+            "verified": verified, "configs": configs, "e2e10": e2e, "boundary": boundary, "strong_scan": strong, "ingest": ingest,
             "kernels": out_kern,
         }
         print(json.dumps(line), flush=True)

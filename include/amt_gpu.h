@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define AMTGPU_ABI_VERSION 2      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers */
+#define AMTGPU_ABI_VERSION 3      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers
+                                   * 3: additions only -- device-side CalcFade (amtgpu_erase_calc_fades_device, *_dfades), sharded frame
+                                   *    metrics (amtgpu_framestats_allgather / _sharded), registered host frames (amtgpu_frames_register),
+                                   *    amtgpu_download_scatter */
 #define AMTGPU_NUM_FADE 11            /* LogoAnalyzeFrame p/t/b[11]  (LogoScan.hpp:1100-1103) */
 #define AMTGPU_ANALYZE_FLOATS 33      /* floats per source frame in an analysis record */
 
@@ -230,6 +233,21 @@ int  amtgpu_erase_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t s
  * (LogoScan.hpp:1248-1261, 1374-1397).  async */
 int  amtgpu_erase_rect_batch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
                              int pitchY, int pitchUV, int bits, int nframes, const float* fades);
+/* CalcFade / CalcFade2 (LogoScan.hpp:1263-1341) on the DEVICE: the same decision as amtgpu_erase_calc_fades, frame by frame in one small
+ * kernel, from analysis records that are still in HBM (the output of amtgpu_analyze_batch) -- no host round trip between analysis
+ * and erase, the whole analyse -> decide -> erase chain is stream-ordered.  d_analysis holds the records of source frames
+ * [analysis_first, analysis_first + analysis_count) of a num_frames clip, 33 floats each; it must cover every record the fades of
+ * [first, first + nframes) read: frames max(0, first - 8) .. min(num_frames, first + nframes + 8) - 1 (CalcFade2 samples n - 8 .. n + 8;
+ * near the clip ends the reference's clamped indices stay inside that range).  d_fades_out: nframes * {fadeT, fadeB} floats on the
+ * device, bit-identical to the host routine's.  async */
+int  amtgpu_erase_calc_fades_device(AmtGpuErase* er, const float* d_analysis, int analysis_first, int analysis_count, int num_frames,
+                                    int first, int nframes, float* d_fades_out);
+/* amtgpu_erase_batch / amtgpu_erase_rect_batch with the fades taken from DEVICE memory (nframes * 2 floats, e.g. the output of
+ * amtgpu_erase_calc_fades_device).  async */
+int  amtgpu_erase_batch_dfades(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
+                               int pitchY, int pitchUV, int bits, int nframes, const float* d_fades);
+int  amtgpu_erase_rect_batch_dfades(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
+                                    int pitchY, int pitchUV, int bits, int nframes, const float* d_fades);
 /* out5 = {imgx, imgy, w, h, fade0_is_identity}: the rectangle Delogo rewrites; the last word is 1 when a frame whose two fades
  * are 0 comes back unchanged (every a*s + b*maxv of this logo is finite), i.e. the host may skip the call for such frames --
  * of an 8- or 16-bit clip: at 10 / 12 bits Delogo's min(tmp + 0.5, maxv) (LogoScan.hpp:1258) still clamps container values
@@ -321,6 +339,20 @@ void amtgpu_framestats_destroy(AmtGpuFrameStats* fs);
  * dout: nframes*AMTGPU_FS_WORDS uint64 (device).  async */
 int  amtgpu_framestats_batch(AmtGpuFrameStats* fs, const void* dY, int64_t frame_stride, int pitch,
                              const void* dprevY, int nframes, uint64_t* dout);
+/* Frame-sharded runs of the whole-frame passes (fourth row): every rank computes the metrics of its own
+ * contiguous frame range [first, first + nlocal) with amtgpu_framestats_batch, passing the frame before its range as dprevY (the
+ * one-frame halo: a rank decodes / generates frame first - 1 itself, nothing is exchanged for it; rank 0 passes NULL).  What IS
+ * exchanged is the 64-byte record per frame: amtgpu_framestats_allgather takes this rank's records (HOST, nlocal * 8 uint64) and
+ * leaves the records of the WHOLE clip (num_frames * 8 uint64, host) in metrics_out on every rank -- ragged shards padded to the
+ * largest, ranges checked to tile [0, num_frames) exactly.  The cadence / scene-change decisions (amtgpu_kfm_cadence,
+ * amtgpu_cm_scene_changes) then run replicated on every rank from identical input: sequential over the clip, integer only, tiny.
+ * A rank-local failure travels as a status word through the exchange; all ranks return 0 together. */
+int  amtgpu_framestats_allgather(AmtGpuFrameStats* fs, const AmtGpuCollectives* coll, const uint64_t* local_metrics, int first,
+                                 int nlocal, int num_frames, uint64_t* metrics_out);
+/* the same for a shard that is resident in HBM as ONE batch: metrics kernel over dY (nlocal frames, dprevY = frame first - 1 or
+ * NULL on the rank that holds frame 0), then the exchange.  Synchronises. */
+int  amtgpu_framestats_sharded(AmtGpuFrameStats* fs, const AmtGpuCollectives* coll, const void* dY, int64_t frame_stride, int pitch,
+                               const void* dprevY, int first, int nlocal, int num_frames, uint64_t* metrics_out);
 /* host decisions from the metrics of a whole clip (nframes*8 uint64, host): scene-change list in
  * chapter_exe's "SCPos:" sense and per-frame cadence class 0=30i/60p 1=24p(3:2) 2=30p + 3:2 phase.
  * sc_out: up to cap frame numbers, returns count via *nsc.  cadence_out: nframes bytes, phase_out: nframes bytes */

@@ -33,7 +33,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(binding.SIGNATURES), declared ^ set(binding.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.amtgpu_abi_version() == 2
+    assert lib.amtgpu_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -97,6 +97,35 @@ def _worker(rank, world, port, tmpdir, q):
         cy, cu, cv = G.crops(g, own.Y.cpu().numpy(), own.U.cpu().numpy(), own.V.cpu().numpy())
         res["erase_equal"] = bool(np.array_equal(cy, g["erase_nolf_Y"][e0:e1]) and np.array_equal(cu, g["erase_nolf_U"][e0:e1])
                                   and np.array_equal(cv, g["erase_nolf_V"][e0:e1]))
+        # ---- the same shard with the decision on the DEVICE: halo analysis records stay in HBM, fades computed and consumed there ----
+        d_an = torch.from_numpy(an[h0:h1]).to(dev)
+        d_f = er.calc_fades_device(d_an, N, e0, e1 - e0, analysis_first=h0)
+        res["device_fades_equal"] = d_f.cpu().numpy().tobytes() == g["erase_nolf_fades"][e0:e1].tobytes()
+        own2 = DeviceClip(torch.from_numpy(Y[e0:e1]).to(dev), torch.from_numpy(U[e0:e1]).to(dev), torch.from_numpy(V[e0:e1]).to(dev), W, H)
+        er.erase_device_fades(own2, d_f)
+        ctx.synchronize()
+        res["device_erase_equal"] = bool(torch.equal(own2.Y, own.Y) and torch.equal(own2.U, own.U) and torch.equal(own2.V, own.V))
+
+        # ---- self-specified CM / KFM frame metrics, sharded: contiguous range + the frame before it as halo,
+        #      all-gather of the 64-byte records, decisions replicated; against the numpy oracle over the whole clip ----
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import frame_stats_oracle as FS
+        from amatsukaze_amd import FrameStats
+        fs = FrameStats(ctx, W, H, 8)
+        Yd = torch.from_numpy(Y).to(dev)                      # (this rank only touches its own rows of it below)
+        m = SH.framestats_sharded(fs, Yd[e0:e1], e0, N, coll, prevY=Yd[e0 - 1] if e0 > 0 else None)
+        whole = FS.frame_metrics(Y[:, :, :W])
+        res["metrics_equal"] = bool(np.array_equal(m, whole))
+        cad, ph = fs.cadence(m)
+        ocad, oph = FS.classify_cadence(whole, W, H)
+        res["decisions_equal"] = bool(np.array_equal(cad, ocad) and np.array_equal(ph, oph) and fs.scene_changes(m).tolist() == FS.scene_changes(whole, W, H))
+        try:                                                  # a shard that does not start the clip must bring its halo frame
+            SH.framestats_sharded(fs, Yd[e0:e1], e0, N, coll, prevY=None)
+            res["metrics_halo_required"] = False
+        except Exception as e:
+            res["metrics_halo_required"] = True
+            res["metrics_halo_msg"] = str(e)
         q.put(res)
     except Exception as e:      # surface the failure in the parent instead of a bare timeout
         import traceback
@@ -130,6 +159,10 @@ def test_sharded_hip_path_world2(tmp_path):
     for r in res:
         assert r["logoframe_equal"] and r["best"] == int(G.load()["logoframe_best"])
         assert r["fades_equal"] and r["erase_equal"]
+        assert r["device_fades_equal"] and r["device_erase_equal"]
+        assert r["metrics_equal"] and r["decisions_equal"]
+        assert r["metrics_halo_required"]                    # rank 1 lacks its halo: BOTH ranks fail, with their own message
+    assert "needs the frame before it" in r1["metrics_halo_msg"] and "another rank failed" in r0["metrics_halo_msg"]
     assert all(p.exitcode == 0 for p in procs)
 
 

@@ -3,6 +3,7 @@ Per-shard numbers come from the oracle (checker side); the product code under te
 import ctypes as C
 import os
 import socket
+import sys
 
 import numpy as np
 import torch
@@ -11,7 +12,7 @@ import torch.multiprocessing as mp
 
 import golden_util as G
 from amatsukaze_amd import sharding as SH
-from amtlib import Oracle, _ptr
+from amtlib import ROOT, Oracle, _ptr
 
 
 def test_shard_range_partitions():
@@ -124,3 +125,58 @@ def test_torch_collectives_callbacks_world2():
         assert ok == 1 and ok2 == 1 and noerr and srank == rank and sworld == 2
         assert recv == [1, 2, 11, 12]
         assert buf == [2, 2 ** 41 + 1, -10]
+
+
+def _fs_worker(rank, world, port, q):
+    """per-rank metrics of a contiguous range with the frame before it as halo (numpy oracle = checker side),
+    amtgpu_framestats_allgather through the C ABI with torch.distributed collectives, replicated decisions"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import frame_stats_oracle as FS
+        import amt_synth as S
+        from amatsukaze_amd import binding
+        lib = binding.load()
+        W, H, N = 64, 36, 47                                 # ragged: 24 + 23
+        Y = np.concatenate([S.make_clip_np(24, W, H, 0x5EED0099, cadence="24p")["Y"], S.make_clip_np(23, W, H, 0x5EED0098, cadence="30i", start=24)["Y"]])
+        whole = FS.frame_metrics(Y)
+        first, last = SH.shard_range(N, rank, world)
+        local = FS.frame_metrics(Y[first:last], prev_first=Y[first - 1] if first > 0 else None)
+        coll = SH.TorchCollectives()
+        fs = lib.amtgpu_framestats_create(None, W, H, 8)     # the exchange and the decisions are host code: no context needed
+        out = np.zeros((N, 8), np.uint64)
+        ok = lib.amtgpu_framestats_allgather(fs, coll.ref(), local.ctypes.data_as(C.c_void_p), first, last - first, N, out.ctypes.data_as(C.c_void_p))
+        same = bool(ok) and np.array_equal(out, whole)
+        cad, ph = np.zeros(N, np.uint8), np.zeros(N, np.uint8)
+        lib.amtgpu_kfm_cadence(out.ctypes.data_as(C.c_void_p), N, W, H, cad.ctypes.data_as(C.c_void_p), ph.ctypes.data_as(C.c_void_p))
+        ocad, oph = FS.classify_cadence(whole, W, H)
+        sc, nsc = np.zeros(N, np.int32), C.c_int()
+        lib.amtgpu_cm_scene_changes(out.ctypes.data_as(C.c_void_p), N, W, H, sc.ctypes.data_as(C.c_void_p), N, C.byref(nsc))
+        dec = bool(np.array_equal(cad, ocad) and np.array_equal(ph, oph) and sc[:nsc.value].tolist() == FS.scene_changes(whole, W, H))
+        # ranges that do not tile the clip (rank 1 claims one frame too few) and a rank-local failure: every rank returns 0, nobody hangs
+        bad1 = lib.amtgpu_framestats_allgather(fs, coll.ref(), local.ctypes.data_as(C.c_void_p), first, last - first - (1 if rank == 1 else 0), N,
+                                               out.ctypes.data_as(C.c_void_p))
+        bad2 = lib.amtgpu_framestats_allgather(fs, coll.ref(), local.ctypes.data_as(C.c_void_p), first if rank == 0 else N, last - first, N,
+                                               out.ctypes.data_as(C.c_void_p))
+        lib.amtgpu_framestats_destroy(fs)
+        q.put((rank, same, dec, int(bad1), int(bad2), coll.error is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_frame_metrics_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, dec, bad1, bad2, noerr in res:
+        assert same, "gathered frame metrics differ from the single-process ones"
+        assert dec, "replicated cadence / scene-change decisions differ"
+        assert bad1 == 0 and bad2 == 0 and noerr
