@@ -17,6 +17,11 @@ ALLGATHER_CB = C.CFUNCTYPE(c_i, c_p, c_p, c_p, c_i64)            # (user, send, 
 ALLREDUCE_CB = C.CFUNCTYPE(c_i, c_p, c_p, c_i64)                 # (user, buf int64*, count)
 
 
+class Scatter(C.Structure):
+    """AmtGpuScatter (include/amt_gpu.h)"""
+    _fields_ = [("hdst", c_p), ("dst_stride", c_i64), ("src_offset", c_u64), ("chunk_bytes", c_u64), ("nchunks", c_i)]
+
+
 class Collectives(C.Structure):
     """AmtGpuCollectives (include/amt_gpu.h)"""
     _fields_ = [("rank", c_i), ("world", c_i), ("allgather", ALLGATHER_CB), ("allreduce_sum_i64", ALLREDUCE_CB), ("user", c_p)]
@@ -42,6 +47,15 @@ SIGNATURES = {
     "amtgpu_download_strided": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_u64, c_i]),
     "amtgpu_frames_upload_gather": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_u64, c_i, c_i]),
     "amtgpu_download_pinned": (c_i, [c_p, c_p, c_u64, c_p]),
+    "amtgpu_context_set_upload_threads": (c_i, [c_p, c_i]),
+    "amtgpu_frames_register": (c_i, [c_p, c_p, c_u64]),
+    "amtgpu_frames_unregister": (c_i, [c_p, c_p]),
+    "amtgpu_download_scatter": (c_i, [c_p, c_p, c_u64, c_p, c_i]),
+    "amtgpu_marker_create": (c_p, [c_p]),
+    "amtgpu_marker_destroy": (None, [c_p, c_p]),
+    "amtgpu_marker_record_on": (c_i, [c_p, c_p]),
+    "amtgpu_marker_wait_on": (c_i, [c_p, c_p]),
+    "amtgpu_context_set_keepalive": (c_i, [c_p, c_i, c_i]),
     "amtgpu_marker_record": (c_i, [c_p, c_i]),
     "amtgpu_marker_wait": (c_i, [c_p, c_i]),
     "amtgpu_logo_loadW": (c_p, [c_p, c_p]),

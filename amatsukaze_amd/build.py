@@ -17,6 +17,7 @@ SOURCES = [
     "amt_gpu_erase_scan.hip",
     "amt_gpu_stats.hip",
     "amt_gpu_ingest.hip",
+    "amt_gpu_upload.hip",
     "eval_engine.hip",
     "eval_fused_kernels.hip",
     "eval_linear_kernels.hip",

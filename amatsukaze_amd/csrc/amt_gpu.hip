@@ -30,6 +30,7 @@ AmtGpuContext* amtgpu_context_create(int device)
         AMT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         AMT_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
         for (auto& e : c->slot_free) AMT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        amt::upload_pool_default(c);
         c->stream = c->own_stream;
     } catch (const std::exception&) {
         amtgpu_context_destroy(c);
@@ -42,6 +43,8 @@ void amtgpu_context_destroy(AmtGpuContext* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    amt::context_stop_threads(c);                      // keep-alive heartbeat and staging workers
+    for (auto& r : c->registered) (void)hipHostUnregister((void*)r.first);
     for (auto& sp : c->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -99,187 +102,6 @@ int amtgpu_profile_report(AmtGpuContext* c, char* out, int cap)
         n = (int)s.size();
     });
     return n;
-}
-
-// ---------------------------------------------------------------------------------------------
-// ingest
-// ---------------------------------------------------------------------------------------------
-void* amtgpu_device_alloc(AmtGpuContext* c, uint64_t bytes)
-{
-    void* p = nullptr;
-    if (!guard(c, [&] { c->bind(); AMT_HIP(hipMalloc(&p, bytes)); })) return nullptr;
-    return p;
-}
-void amtgpu_device_free(AmtGpuContext* c, void* p)
-{
-    if (c && p) { (void)hipSetDevice(c->device); (void)hipFree(p); }
-}
-
-// host -> pinned slot (memcpy) -> device (hipMemcpyAsync on the side stream); two slots so that the CPU
-// fills one while the DMA engine drains the other
-namespace {
-constexpr size_t kSlotBytes = 32u << 20;
-// `n` bytes (<= kSlotBytes) of the slot being filled.  A slot that cannot take them is closed -- an event behind its last copy -- and
-// the other one, once ITS copies have drained, becomes the slot being filled.  Small uploads (one frame's logo rows) thus share a
-// slot and cost a memcpy and a copy launch each, no event wait.
-uint8_t* stage_acquire(AmtGpuContext* c, size_t n)
-{
-    if (!c->pinned) {
-        AMT_HIP(hipHostMalloc(&c->pinned, kSlotBytes * 2, hipHostMallocDefault));
-        c->pinned_bytes = kSlotBytes;
-    }
-    if (c->slot_fill + n > kSlotBytes) {
-        AMT_HIP(hipEventRecord(c->slot_free[c->next_slot], c->copy_stream));
-        c->next_slot ^= 1;
-        AMT_HIP(hipEventSynchronize(c->slot_free[c->next_slot]));
-        c->slot_fill = 0;
-    }
-    uint8_t* p = (uint8_t*)c->pinned + (size_t)c->next_slot * kSlotBytes + c->slot_fill;
-    c->slot_fill += (n + 255) & ~(size_t)255;
-    return p;
-}
-} // namespace
-
-int amtgpu_frames_upload(AmtGpuContext* c, void* ddst, const void* hsrc, uint64_t bytes)
-{
-    return guard(c, [&] {
-        c->bind();
-        uint64_t done = 0;
-        while (done < bytes) {
-            const size_t n = (size_t)std::min<uint64_t>(kSlotBytes, bytes - done);
-            uint8_t* stage = stage_acquire(c, n);
-            std::memcpy(stage, (const uint8_t*)hsrc + done, n);
-            AMT_HIP(hipMemcpyAsync((uint8_t*)ddst + done, stage, n, hipMemcpyHostToDevice, c->copy_stream));
-            done += n;
-        }
-        AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
-        c->copies_pending = true;
-    });
-}
-
-// the same ring for `nchunks` equally sized pieces that sit `dst_stride` apart on the device (e.g. the logo rectangle's rows of
-// every frame of a batch: the logo passes read nothing else of a frame): pieces are packed into the pinned slot and leave
-// as ONE 2-D copy per slot
-int amtgpu_frames_upload_strided(AmtGpuContext* c, void* ddst, int64_t dst_stride, const void* hsrc, int64_t src_stride,
-                                 uint64_t chunk_bytes, int nchunks)
-{
-    return guard(c, [&] {
-        c->bind();
-        if (chunk_bytes == 0 || nchunks <= 0) return;
-        if (chunk_bytes > kSlotBytes) throw std::runtime_error("chunk larger than a staging slot");
-        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
-        const int per_slot = (int)(kSlotBytes / chunk_bytes);
-        for (int i0 = 0; i0 < nchunks; i0 += per_slot) {
-            const int n = std::min(per_slot, nchunks - i0);
-            uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
-            for (int i = 0; i < n; ++i)
-                std::memcpy(stage + (size_t)i * chunk_bytes, (const uint8_t*)hsrc + (size_t)(i0 + i) * src_stride, chunk_bytes);
-            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
-                                     hipMemcpyHostToDevice, c->copy_stream));
-        }
-        AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
-        c->copies_pending = true;
-    });
-}
-
-// `nsrc` sources of `chunks_per_src` pieces each (e.g. the logo rectangle's rows of nsrc separately allocated host frames) to
-// destinations that continue one another: piece j of source i lands at ddst + (i * chunks_per_src + j) * dst_stride.  Packed into
-// the pinned ring and sent as one 2-D copy per slot -- one call and one copy launch for a whole group of frames
-int amtgpu_frames_upload_gather(AmtGpuContext* c, void* ddst, int64_t dst_stride, const void* const* hsrc, int64_t src_stride,
-                                uint64_t chunk_bytes, int chunks_per_src, int nsrc)
-{
-    return guard(c, [&] {
-        c->bind();
-        if (chunk_bytes == 0 || chunks_per_src <= 0 || nsrc <= 0) return;
-        if (!hsrc) throw std::runtime_error("null source list");
-        if (chunk_bytes > kSlotBytes) throw std::runtime_error("chunk larger than a staging slot");
-        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
-        const int64_t total = (int64_t)chunks_per_src * nsrc;
-        const int64_t per_slot = (int64_t)(kSlotBytes / chunk_bytes);
-        for (int64_t i0 = 0; i0 < total; i0 += per_slot) {
-            const int64_t n = std::min(per_slot, total - i0);
-            uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
-            for (int64_t i = 0; i < n; ++i) {
-                const int64_t q = i0 + i;
-                std::memcpy(stage + (size_t)i * chunk_bytes, (const uint8_t*)hsrc[q / chunks_per_src] + (size_t)(q % chunks_per_src) * src_stride,
-                            chunk_bytes);
-            }
-            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
-                                     hipMemcpyHostToDevice, c->copy_stream));
-        }
-        AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
-        c->copies_pending = true;
-    });
-}
-
-int amtgpu_frames_upload_wait(AmtGpuContext* c)
-{
-    return guard(c, [&] {
-        c->bind();
-        if (c->copies_pending) { AMT_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0)); c->copies_pending = false; }
-    });
-}
-
-int amtgpu_download(AmtGpuContext* c, void* hdst, const void* dsrc, uint64_t bytes)
-{
-    return guard(c, [&] {
-        c->bind();
-        AMT_HIP(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
-        AMT_HIP(hipStreamSynchronize(c->stream));
-    });
-}
-
-int amtgpu_download_strided(AmtGpuContext* c, void* hdst, int64_t dst_stride, const void* dsrc, int64_t src_stride, uint64_t chunk_bytes,
-                            int nchunks)
-{
-    return guard(c, [&] {
-        c->bind();
-        if (chunk_bytes == 0 || nchunks <= 0) return;
-        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
-        AMT_HIP(hipMemcpy2DAsync(hdst, (size_t)dst_stride, dsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyDeviceToHost,
-                                 c->stream));
-        AMT_HIP(hipStreamSynchronize(c->stream));
-    });
-}
-
-// device -> a pinned landing buffer of the context in ONE asynchronous copy + one wait; *hptr stays valid until the next call.  For
-// callers that scatter the bytes into several host frames themselves (AMTEraseLogo's block of erased rectangles)
-int amtgpu_download_pinned(AmtGpuContext* c, const void* dsrc, uint64_t bytes, const void** hptr)
-{
-    return guard(c, [&] {
-        c->bind();
-        if (!hptr) throw std::runtime_error("null result pointer");
-        if (bytes > c->pinned_down_bytes) {
-            if (c->pinned_down) { (void)hipHostFree(c->pinned_down); c->pinned_down = nullptr; c->pinned_down_bytes = 0; }
-            AMT_HIP(hipHostMalloc(&c->pinned_down, (size_t)bytes, hipHostMallocDefault));
-            c->pinned_down_bytes = (size_t)bytes;
-        }
-        if (bytes) {
-            AMT_HIP(hipMemcpyAsync(c->pinned_down, dsrc, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
-            AMT_HIP(hipStreamSynchronize(c->stream));
-        }
-        *hptr = c->pinned_down;
-    });
-}
-
-// markers on the compute stream: record(id) after a batch's launches, wait(id) on the host before the batch's device buffer is
-// written again -- what a double-buffered caller needs instead of amtgpu_context_synchronize (which also waits for the NEXT batch)
-int amtgpu_marker_record(AmtGpuContext* c, int id)
-{
-    return guard(c, [&] {
-        c->bind();
-        if (id < 0 || id >= 16) throw std::runtime_error("marker id out of range (0..15)");
-        if (!c->markers[id]) AMT_HIP(hipEventCreateWithFlags(&c->markers[id], hipEventDisableTiming));
-        AMT_HIP(hipEventRecord(c->markers[id], c->stream));
-    });
-}
-int amtgpu_marker_wait(AmtGpuContext* c, int id)
-{
-    return guard(c, [&] {
-        c->bind();
-        if (id < 0 || id >= 16) throw std::runtime_error("marker id out of range (0..15)");
-        if (c->markers[id]) AMT_HIP(hipEventSynchronize(c->markers[id]));          // never recorded: nothing to wait for
-    });
 }
 
 // ---------------------------------------------------------------------------------------------

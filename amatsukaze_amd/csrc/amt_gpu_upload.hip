@@ -1,0 +1,511 @@
+// amt_gpu_upload.hip -- C ABI part 5: frames between host and HBM (the step AMTSource::GetFrame feeds, AMTSource.hpp:721-780,
+// 428-442): device allocation, the pinned staging ring with its worker threads, registered (page-locked in place) host frames,
+// downloads, stream markers, and the optional queue keep-alive.
+//
+// Ingest path.  A decoder's frames normally sit in pageable memory, which the DMA engines cannot read: they are staged through
+// a ring of pinned slots on the way -- host memcpy into a slot, hipMemcpyAsync out of it on the side stream.  One core's memcpy
+// (~10-25 GB/s) is below what PCIe Gen5 x16 carries (~55 GB/s), so the staging copy of a large upload is shared out over a few
+// worker threads, and the ring has four slots so that the CPU fills slots k+1.. while the copy engine drains slot k.  A host that
+// can keep its frame buffers in place (a decoder's frame pool) registers them once (amtgpu_frames_register = hipHostRegister):
+// uploads from inside a registered range skip the ring altogether.
+#include "../../include/amt_gpu.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <thread>
+
+#include "api_common.hpp"
+
+using namespace amt;
+
+// ---------------------------------------------------------------------------------------------
+// staging workers: a fixed set of threads that run slices of one job at a time (the caller takes a slice itself)
+// ---------------------------------------------------------------------------------------------
+struct AmtGpuContext::UploadPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)>* job = nullptr;      // job(slice)
+    int nslices = 0, next = 0, pending = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+
+    explicit UploadPool(int nworkers)
+    {
+        for (int i = 0; i < nworkers; ++i) workers.emplace_back([this] { loop(); });
+    }
+    ~UploadPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || (job && next < nslices); });
+            if (stop) return;
+            while (job && next < nslices) {
+                const int s = next++;
+                const std::function<void(int)>* j = job;
+                lk.unlock();
+                (*j)(s);
+                lk.lock();
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    // runs fn(0..n-1), the calling thread included; returns when all slices are done
+    void run(int n, const std::function<void(int)>& fn)
+    {
+        if (n <= 0) return;
+        std::unique_lock<std::mutex> lk(m);
+        job = &fn; nslices = n; next = 0; pending = n;
+        ++generation;
+        cv_work.notify_all();
+        while (next < nslices) {
+            const int s = next++;
+            lk.unlock();
+            fn(s);
+            lk.lock();
+            --pending;
+        }
+        cv_done.wait(lk, [&] { return pending == 0; });
+        job = nullptr;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// keep-alive: see amtgpu_context_set_keepalive in amt_gpu.h
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void keepalive_kernel(long long spin_ticks)
+{
+    // wall_clock64: the constant 100 MHz counter.  spin_ticks == 0: an empty launch
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(64);
+}
+} // namespace
+
+struct AmtGpuContext::KeepAlive {
+    std::thread th;
+    std::atomic<bool> stop{false};
+    hipStream_t stream = nullptr;
+    int device = 0, period_us = 0, spin_us = 0;
+    std::atomic<long long> beats{0};
+
+    void loop()
+    {
+        if (hipSetDevice(device) != hipSuccess) return;
+        while (!stop.load(std::memory_order_relaxed)) {
+            // never let launches pile up: a beat is skipped while the previous one has not finished
+            if (hipStreamQuery(stream) == hipSuccess) {
+                hipLaunchKernelGGL(keepalive_kernel, dim3(1), dim3(64), 0, stream, (long long)spin_us * 100);
+                beats.fetch_add(1, std::memory_order_relaxed);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(period_us));
+        }
+        (void)hipStreamSynchronize(stream);
+    }
+};
+
+namespace amt {
+
+void upload_pool_default(AmtGpuContext* c)
+{
+    // staging threads: enough to pass PCIe Gen5 x16 with headroom, never more than a quarter of the host's cores.  The pool itself
+    // is created on the first large upload.
+    const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+    c->upload_threads = (int)std::max(1u, std::min(8u, hc / 4));
+}
+
+void context_stop_threads(AmtGpuContext* c)
+{
+    if (c->keepalive) {
+        c->keepalive->stop.store(true);
+        if (c->keepalive->th.joinable()) c->keepalive->th.join();
+        if (c->keepalive->stream) (void)hipStreamDestroy(c->keepalive->stream);
+        delete c->keepalive;
+        c->keepalive = nullptr;
+    }
+    delete c->pool;
+    c->pool = nullptr;
+}
+
+} // namespace amt
+
+namespace {
+constexpr size_t kSlotBytes = 16u << 20;
+constexpr size_t kParallelMin = 1u << 20;          // staging copies below this stay on the calling thread
+constexpr size_t kSliceBytes = 512u << 10;
+
+// `n` bytes (<= kSlotBytes) of the slot being filled.  A slot that cannot take them is closed -- an event behind its last copy -- and
+// the next one in the ring, once ITS copies (issued three slots ago) have drained, becomes the slot being filled.  Small uploads
+// (one frame's logo rows) thus share a slot and cost a memcpy and a copy launch each, no event wait.
+uint8_t* stage_acquire(AmtGpuContext* c, size_t n)
+{
+    if (!c->pinned) {
+        AMT_HIP(hipHostMalloc(&c->pinned, kSlotBytes * AmtGpuContext::kRingSlots, hipHostMallocDefault));
+        c->pinned_bytes = kSlotBytes;
+    }
+    if (c->slot_fill + n > kSlotBytes) {
+        AMT_HIP(hipEventRecord(c->slot_free[c->next_slot], c->copy_stream));
+        c->next_slot = (c->next_slot + 1) % AmtGpuContext::kRingSlots;
+        AMT_HIP(hipEventSynchronize(c->slot_free[c->next_slot]));
+        c->slot_fill = 0;
+    }
+    uint8_t* p = (uint8_t*)c->pinned + (size_t)c->next_slot * kSlotBytes + c->slot_fill;
+    c->slot_fill += (n + 255) & ~(size_t)255;
+    return p;
+}
+
+AmtGpuContext::UploadPool* pool_of(AmtGpuContext* c)
+{
+    if (c->upload_threads <= 1) return nullptr;
+    if (!c->pool || (int)c->pool->workers.size() != c->upload_threads - 1) {
+        delete c->pool;
+        c->pool = nullptr;
+        c->pool = new AmtGpuContext::UploadPool(c->upload_threads - 1);
+    }
+    return c->pool;
+}
+
+// dst <- src, n bytes, shared out over the staging threads in kSliceBytes pieces
+void staged_copy(AmtGpuContext* c, uint8_t* dst, const uint8_t* src, size_t n)
+{
+    AmtGpuContext::UploadPool* P = n >= kParallelMin ? pool_of(c) : nullptr;
+    if (!P) { std::memcpy(dst, src, n); return; }
+    const int slices = (int)((n + kSliceBytes - 1) / kSliceBytes);
+    const std::function<void(int)> fn = [&](int s) {
+        const size_t o = (size_t)s * kSliceBytes;
+        std::memcpy(dst + o, src + o, std::min(kSliceBytes, n - o));
+    };
+    P->run(slices, fn);
+}
+
+// `count` pieces of chunk bytes, piece i read from src_of(i), packed back to back at dst
+template <typename SrcOf> void staged_gather(AmtGpuContext* c, uint8_t* dst, size_t chunk, int64_t count, SrcOf src_of)
+{
+    AmtGpuContext::UploadPool* P = (size_t)count * chunk >= kParallelMin ? pool_of(c) : nullptr;
+    if (!P) {
+        for (int64_t i = 0; i < count; ++i) std::memcpy(dst + (size_t)i * chunk, src_of(i), chunk);
+        return;
+    }
+    const int64_t per = std::max<int64_t>(1, (int64_t)(kSliceBytes / chunk));
+    const int slices = (int)((count + per - 1) / per);
+    const std::function<void(int)> fn = [&](int s) {
+        const int64_t i1 = std::min(count, (int64_t)(s + 1) * per);
+        for (int64_t i = (int64_t)s * per; i < i1; ++i) std::memcpy(dst + (size_t)i * chunk, src_of(i), chunk);
+    };
+    P->run(slices, fn);
+}
+
+// [p, p + n) lies inside a range registered with amtgpu_frames_register
+bool is_registered(const AmtGpuContext* c, const void* p, size_t n)
+{
+    const uintptr_t a = (uintptr_t)p;
+    for (const auto& r : c->registered)
+        if (a >= r.first && a + n <= r.first + r.second) return true;
+    return false;
+}
+
+void copies_issued(AmtGpuContext* c)
+{
+    AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
+    c->copies_pending = true;
+}
+} // namespace
+
+extern "C" {
+
+void* amtgpu_device_alloc(AmtGpuContext* c, uint64_t bytes)
+{
+    void* p = nullptr;
+    if (!guard(c, [&] { c->bind(); AMT_HIP(hipMalloc(&p, bytes)); })) return nullptr;
+    return p;
+}
+void amtgpu_device_free(AmtGpuContext* c, void* p)
+{
+    if (c && p) { (void)hipSetDevice(c->device); (void)hipFree(p); }
+}
+
+int amtgpu_context_set_upload_threads(AmtGpuContext* c, int nthreads)
+{
+    return guard(c, [&] {
+        if (!c) throw std::runtime_error("no context");
+        if (nthreads < 1 || nthreads > 64) throw std::runtime_error("upload threads must be 1..64");
+        c->upload_threads = nthreads;
+    });
+}
+
+int amtgpu_frames_register(AmtGpuContext* c, void* hptr, uint64_t bytes)
+{
+    return guard(c, [&] {
+        if (!c) throw std::runtime_error("no context");
+        if (!hptr || !bytes) throw std::runtime_error("empty host range");
+        c->bind();
+        AMT_HIP(hipHostRegister(hptr, (size_t)bytes, hipHostRegisterDefault));
+        c->registered.emplace_back((uintptr_t)hptr, (size_t)bytes);
+    });
+}
+
+int amtgpu_frames_unregister(AmtGpuContext* c, void* hptr)
+{
+    return guard(c, [&] {
+        if (!c) throw std::runtime_error("no context");
+        for (size_t i = 0; i < c->registered.size(); ++i)
+            if (c->registered[i].first == (uintptr_t)hptr) {
+                c->bind();
+                // copies out of the range may still be in flight on the side stream
+                AMT_HIP(hipStreamSynchronize(c->copy_stream));
+                AMT_HIP(hipHostUnregister(hptr));
+                c->registered.erase(c->registered.begin() + (long)i);
+                return;
+            }
+        throw std::runtime_error("host range was not registered");
+    });
+}
+
+int amtgpu_frames_upload(AmtGpuContext* c, void* ddst, const void* hsrc, uint64_t bytes)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (bytes && is_registered(c, hsrc, (size_t)bytes)) {            // page-locked in place: the DMA engine reads it where it is
+            AMT_HIP(hipMemcpyAsync(ddst, hsrc, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
+            copies_issued(c);
+            return;
+        }
+        uint64_t done = 0;
+        while (done < bytes) {
+            const size_t n = (size_t)std::min<uint64_t>(kSlotBytes, bytes - done);
+            uint8_t* stage = stage_acquire(c, n);
+            staged_copy(c, stage, (const uint8_t*)hsrc + done, n);
+            AMT_HIP(hipMemcpyAsync((uint8_t*)ddst + done, stage, n, hipMemcpyHostToDevice, c->copy_stream));
+            done += n;
+        }
+        copies_issued(c);
+    });
+}
+
+// the same ring for `nchunks` equally sized pieces that sit `dst_stride` apart on the device (e.g. the logo rectangle's rows of
+// every frame of a batch: the logo passes read nothing else of a frame): pieces are packed into the pinned slot and leave
+// as ONE 2-D copy per slot
+int amtgpu_frames_upload_strided(AmtGpuContext* c, void* ddst, int64_t dst_stride, const void* hsrc, int64_t src_stride,
+                                 uint64_t chunk_bytes, int nchunks)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (chunk_bytes == 0 || nchunks <= 0) return;
+        if (chunk_bytes > kSlotBytes) throw std::runtime_error("chunk larger than a staging slot");
+        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
+        if (is_registered(c, hsrc, (size_t)(nchunks - 1) * (size_t)src_stride + (size_t)chunk_bytes)) {
+            AMT_HIP(hipMemcpy2DAsync(ddst, (size_t)dst_stride, hsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyHostToDevice,
+                                     c->copy_stream));
+            copies_issued(c);
+            return;
+        }
+        const int per_slot = (int)(kSlotBytes / chunk_bytes);
+        for (int i0 = 0; i0 < nchunks; i0 += per_slot) {
+            const int n = std::min(per_slot, nchunks - i0);
+            uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
+            staged_gather(c, stage, (size_t)chunk_bytes, n, [&](int64_t i) { return (const uint8_t*)hsrc + (size_t)(i0 + i) * src_stride; });
+            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
+                                     hipMemcpyHostToDevice, c->copy_stream));
+        }
+        copies_issued(c);
+    });
+}
+
+// `nsrc` sources of `chunks_per_src` pieces each (e.g. the logo rectangle's rows of nsrc separately allocated host frames) to
+// destinations that continue one another: piece j of source i lands at ddst + (i * chunks_per_src + j) * dst_stride.  Packed into
+// the pinned ring and sent as one 2-D copy per slot -- one call and one copy launch for a whole group of frames
+int amtgpu_frames_upload_gather(AmtGpuContext* c, void* ddst, int64_t dst_stride, const void* const* hsrc, int64_t src_stride,
+                                uint64_t chunk_bytes, int chunks_per_src, int nsrc)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (chunk_bytes == 0 || chunks_per_src <= 0 || nsrc <= 0) return;
+        if (!hsrc) throw std::runtime_error("null source list");
+        if (chunk_bytes > kSlotBytes) throw std::runtime_error("chunk larger than a staging slot");
+        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
+        const int64_t total = (int64_t)chunks_per_src * nsrc;
+        const int64_t per_slot = (int64_t)(kSlotBytes / chunk_bytes);
+        for (int64_t i0 = 0; i0 < total; i0 += per_slot) {
+            const int64_t n = std::min(per_slot, total - i0);
+            uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
+            staged_gather(c, stage, (size_t)chunk_bytes, n, [&](int64_t i) {
+                const int64_t q = i0 + i;
+                return (const uint8_t*)hsrc[q / chunks_per_src] + (size_t)(q % chunks_per_src) * src_stride;
+            });
+            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
+                                     hipMemcpyHostToDevice, c->copy_stream));
+        }
+        copies_issued(c);
+    });
+}
+
+int amtgpu_frames_upload_wait(AmtGpuContext* c)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (c->copies_pending) { AMT_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0)); c->copies_pending = false; }
+    });
+}
+
+int amtgpu_download(AmtGpuContext* c, void* hdst, const void* dsrc, uint64_t bytes)
+{
+    return guard(c, [&] {
+        c->bind();
+        AMT_HIP(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
+        AMT_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int amtgpu_download_strided(AmtGpuContext* c, void* hdst, int64_t dst_stride, const void* dsrc, int64_t src_stride, uint64_t chunk_bytes,
+                            int nchunks)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (chunk_bytes == 0 || nchunks <= 0) return;
+        if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
+        AMT_HIP(hipMemcpy2DAsync(hdst, (size_t)dst_stride, dsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyDeviceToHost,
+                                 c->stream));
+        AMT_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+namespace {
+void land_pinned(AmtGpuContext* c, const void* dsrc, uint64_t bytes)
+{
+    if (bytes > c->pinned_down_bytes) {
+        if (c->pinned_down) { (void)hipHostFree(c->pinned_down); c->pinned_down = nullptr; c->pinned_down_bytes = 0; }
+        AMT_HIP(hipHostMalloc(&c->pinned_down, (size_t)bytes, hipHostMallocDefault));
+        c->pinned_down_bytes = (size_t)bytes;
+    }
+    if (bytes) {
+        AMT_HIP(hipMemcpyAsync(c->pinned_down, dsrc, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+        AMT_HIP(hipStreamSynchronize(c->stream));
+    }
+}
+} // namespace
+
+// device -> a pinned landing buffer of the context in ONE asynchronous copy + one wait; *hptr stays valid until the next call ON THIS
+// CONTEXT from any thread -- a context shared by several host threads must use amtgpu_download_scatter instead
+int amtgpu_download_pinned(AmtGpuContext* c, const void* dsrc, uint64_t bytes, const void** hptr)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (!hptr) throw std::runtime_error("null result pointer");
+        land_pinned(c, dsrc, bytes);
+        *hptr = c->pinned_down;
+    });
+}
+
+// `bytes` from the device in one copy, then handed out to host memory piece by piece while the context is still locked: the landing
+// buffer never leaves the library, so several filters on several threads may share one context
+int amtgpu_download_scatter(AmtGpuContext* c, const void* dsrc, uint64_t bytes, const AmtGpuScatter* pieces, int npieces)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (npieces < 0 || (npieces > 0 && !pieces)) throw std::runtime_error("null piece list");
+        for (int i = 0; i < npieces; ++i) {
+            const AmtGpuScatter& p = pieces[i];
+            if (p.nchunks < 0 || (p.nchunks > 0 && (!p.hdst || p.dst_stride < (int64_t)p.chunk_bytes)))
+                throw std::runtime_error("bad scatter piece");
+            if (p.src_offset > bytes || (uint64_t)p.nchunks * p.chunk_bytes > bytes - p.src_offset) throw std::runtime_error("scatter piece outside the downloaded range");
+        }
+        land_pinned(c, dsrc, bytes);
+        const uint8_t* back = (const uint8_t*)c->pinned_down;
+        for (int i = 0; i < npieces; ++i) {
+            const AmtGpuScatter& p = pieces[i];
+            const uint8_t* s = back + p.src_offset;
+            for (int k = 0; k < p.nchunks; ++k) std::memcpy((uint8_t*)p.hdst + (size_t)k * p.dst_stride, s + (size_t)k * p.chunk_bytes, (size_t)p.chunk_bytes);
+        }
+    });
+}
+
+// markers on the compute stream: record(id) after a batch's launches, wait(id) on the host before the batch's device buffer is
+// written again -- what a double-buffered caller needs instead of amtgpu_context_synchronize (which also waits for the NEXT batch)
+int amtgpu_marker_record(AmtGpuContext* c, int id)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (id < 0 || id >= 16) throw std::runtime_error("marker id out of range (0..15)");
+        if (!c->markers[id]) AMT_HIP(hipEventCreateWithFlags(&c->markers[id], hipEventDisableTiming));
+        AMT_HIP(hipEventRecord(c->markers[id], c->stream));
+    });
+}
+int amtgpu_marker_wait(AmtGpuContext* c, int id)
+{
+    return guard(c, [&] {
+        c->bind();
+        if (id < 0 || id >= 16) throw std::runtime_error("marker id out of range (0..15)");
+        if (c->markers[id]) AMT_HIP(hipEventSynchronize(c->markers[id]));          // never recorded: nothing to wait for
+    });
+}
+
+// marker OBJECTS: the same record / wait pair on an event the caller owns, so that two users of a shared context (two LogoFrame
+// scans, a filter and user code) cannot re-record each other's markers; the event remembers the stream it was recorded on
+AmtGpuMarker* amtgpu_marker_create(AmtGpuContext* c)
+{
+    AmtGpuMarker* m = nullptr;
+    guard(c, [&] {
+        if (!c) throw std::runtime_error("no context");
+        c->bind();
+        hipEvent_t e;
+        AMT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m = reinterpret_cast<AmtGpuMarker*>(e);
+    });
+    return m;
+}
+void amtgpu_marker_destroy(AmtGpuContext* c, AmtGpuMarker* m)
+{
+    if (c && m) { (void)hipSetDevice(c->device); (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(m)); }
+}
+int amtgpu_marker_record_on(AmtGpuContext* c, AmtGpuMarker* m)
+{
+    return guard(c, [&] {
+        if (!m) throw std::runtime_error("null marker");
+        c->bind();
+        AMT_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(m), c->stream));
+    });
+}
+int amtgpu_marker_wait_on(AmtGpuContext* c, AmtGpuMarker* m)
+{
+    return guard(c, [&] {
+        if (!m) throw std::runtime_error("null marker");
+        c->bind();
+        AMT_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(m)));             // never recorded: returns at once
+    });
+}
+
+int amtgpu_context_set_keepalive(AmtGpuContext* c, int period_us, int spin_us)
+{
+    return guard(c, [&] {
+        if (!c) throw std::runtime_error("no context");
+        if (period_us < 0 || period_us > 1000000 || spin_us < 0 || spin_us > 100000) throw std::runtime_error("keep-alive period / spin out of range");
+        if (c->keepalive) {
+            c->keepalive->stop.store(true);
+            if (c->keepalive->th.joinable()) c->keepalive->th.join();
+            if (c->keepalive->stream) (void)hipStreamDestroy(c->keepalive->stream);
+            delete c->keepalive;
+            c->keepalive = nullptr;
+        }
+        if (period_us == 0) return;
+        c->bind();
+        std::unique_ptr<AmtGpuContext::KeepAlive> k(new AmtGpuContext::KeepAlive);
+        k->device = c->device; k->period_us = period_us; k->spin_us = spin_us;
+        int lo = 0, hi = 0;
+        AMT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));                          // lo = the numerically largest = lowest priority
+        AMT_HIP(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, lo));
+        AmtGpuContext::KeepAlive* kp = k.get();
+        k->th = std::thread([kp] { kp->loop(); });
+        c->keepalive = k.release();
+    });
+}
+
+} // extern "C"

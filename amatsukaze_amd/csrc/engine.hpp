@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <mutex>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -27,11 +28,22 @@ struct AmtGpuContext {
     hipStream_t copy_stream = nullptr;  // side stream for ingest
     hipEvent_t copy_done = nullptr;
     bool copies_pending = false;
-    void* pinned = nullptr;             // pinned staging ring (2 slots)
+    static constexpr int kRingSlots = 4;
+    void* pinned = nullptr;             // pinned staging ring (kRingSlots slots): the CPU fills slots while the DMA engine drains earlier ones
     size_t pinned_bytes = 0;
-    hipEvent_t slot_free[2] = {nullptr, nullptr};
+    hipEvent_t slot_free[kRingSlots] = {};
     int next_slot = 0;                  // the slot being filled
     size_t slot_fill = 0;               // bytes of it handed out (small uploads share a slot: no event wait per call)
+    // staging copies (pageable host memory -> pinned slot) are shared out over a few worker threads: one core's memcpy is below
+    // what PCIe Gen5 x16 carries (amt_gpu_upload.hip)
+    struct UploadPool;
+    UploadPool* pool = nullptr;
+    int upload_threads = 1;
+    // host ranges the caller has page-locked through amtgpu_frames_register: uploads from inside them skip the staging ring
+    std::vector<std::pair<uintptr_t, size_t>> registered;
+    // optional heartbeat that keeps the device's queues from going idle between the small launches of a frame-by-frame host
+    struct KeepAlive;
+    KeepAlive* keepalive = nullptr;
     void* pinned_down = nullptr;        // pinned landing buffer of amtgpu_download_pinned
     size_t pinned_down_bytes = 0;
     hipEvent_t markers[16] = {};        // amtgpu_marker_record / _wait
@@ -59,6 +71,8 @@ struct AmtGpuContext {
 };
 
 namespace amt {
+void upload_pool_default(AmtGpuContext* c);
+void context_stop_threads(AmtGpuContext* c);
 
 template <typename T> class DevBuf {
     T* p_ = nullptr;

@@ -75,7 +75,6 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         const int w = S.planes.w, h = S.planes.h;
         const int lp = lds_pitch(w);
         if (w > 0xFFFF || h > 0xFFFF || T.count >= (1 << 24) - kTablePad) throw std::runtime_error("logo too large");   // 24-bit table index math
-        if (5 * lp > kPlaneCapMax) throw std::runtime_error("logo too wide for the evaluation kernel");
         const int cpad = std::max(kTablePad, (T.count + kTablePad - 1) / kTablePad * kTablePad);
 
         // run slots: horizontally adjacent mask pixels (same row, x+1: consecutive in raster order) pair up;
@@ -87,22 +86,39 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
             m += n;
         }
         auto slot_m0 = [&](int s) { return (int)(slots[s] & 0x0FFFFFFFu); };
+        auto slot_n = [&](int s) { return (int)(slots[s] >> 28); };
         auto slot_y = [&](int s) { return (int)(T.pos[slot_m0(s)] >> 16); };
-        // bands: up to kEvalThreads consecutive slots whose 5x5 windows fit the LDS plane
+        auto slot_x = [&](int s) { return (int)(T.pos[slot_m0(s)] & 0xFFFF); };
+        // bands: up to kEvalThreads consecutive slots whose 5x5 windows fit the LDS plane.  While five rows of the WHOLE logo width fit
+        // (w <= 576) a band stages whole rows; a wider logo's bands stage only the columns their windows touch -- a band then ends
+        // where the raster order wraps to the next row (its bounding box would span the whole width), so wide logos get more and
+        // smaller bands but no width limit (the reference takes any even w x h, LogoScan.hpp:69)
+        const bool whole_rows = 5 * lp <= kPlaneCapMax;
         const int band0 = (int)bands_.size();
         const int ns = (int)slots.size();
         for (int s = 0; s < ns;) {
             EvalBand B;
             B.logo = i; B.s0 = s;
             const int ytop = slot_y(s) - 2;
+            int minx = slot_x(s), maxx = slot_x(s) + slot_n(s) - 1;
             int e = s;
-            while (e < ns && e - s < kEvalThreads && (slot_y(e) + 2 - ytop + 1) * lp <= kPlaneCapMax) ++e;
+            B.x0 = 0; B.bw = w; B.lp = lp;
+            while (e < ns && e - s < kEvalThreads) {
+                const int mnx = std::min(minx, slot_x(e)), mxx = std::max(maxx, slot_x(e) + slot_n(e) - 1);
+                const int x0 = whole_rows ? 0 : std::max(0, (mnx - 2) & ~3), x1 = whole_rows ? w : std::min(w, mxx + 4);
+                const int lpb = whole_rows ? lp : lds_pitch(x1 - x0);
+                if ((slot_y(e) + 2 - ytop + 1) * lpb > kPlaneCapMax) break;
+                minx = mnx; maxx = mxx;
+                B.x0 = x0; B.bw = x1 - x0; B.lp = lpb;
+                ++e;
+            }
+            if (e == s) throw std::runtime_error("logo too wide for the evaluation kernel");      // (one slot's 5 x 6 window always fits)
             B.nslots = e - s;
             B.y0 = ytop;
             B.nrows = slot_y(e - 1) + 2 - ytop + 1;
             B.m0 = slot_m0(s);
             B.npix = slot_m0(e - 1) + (int)(slots[e - 1] >> 28) - B.m0;
-            plane_cap_ = std::max(plane_cap_, B.nrows * lp);
+            plane_cap_ = std::max(plane_cap_, B.nrows * B.lp);
             bands_.push_back(B);
             s = e;
         }
@@ -121,7 +137,7 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
                 const int m0 = slot_m0(sidx);
                 const int n = (int)(slots[sidx] >> 28);
                 const int x = (int)(T.pos[m0] & 0xFFFF), y = (int)(T.pos[m0] >> 16);
-                slot2[sidx] = uint2{slots[sidx], (uint32_t)((y - 2 - B.y0) * lp + (x - 2))};
+                slot2[sidx] = uint2{slots[sidx], (uint32_t)((y - 2 - B.y0) * B.lp + (x - 2 - B.x0))};
                 const float* k0 = &T.kernels[(size_t)m0 * 25];
                 const float* k1 = n > 1 ? &T.kernels[(size_t)(m0 + 1) * 25] : nullptr;
                 for (int c = 0; c < 5; ++c)
@@ -153,7 +169,7 @@ EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std:
         for (int i = 0; i < nl; ++i)
             fprintf(stderr, "[amtgpu] eval logo %d: %dx%d count=%d bands=%d lp=%d\n", i, hl[i].w, hl[i].h, hl[i].count, hl[i].nbands, hl[i].lp);
         for (const EvalBand& B : bands_)
-            fprintf(stderr, "[amtgpu]   band logo=%d slots=%d npix=%d y0=%d nrows=%d\n", B.logo, B.nslots, B.npix, B.y0, B.nrows);
+            fprintf(stderr, "[amtgpu]   band logo=%d slots=%d npix=%d y0=%d nrows=%d x0=%d bw=%d lp=%d\n", B.logo, B.nslots, B.npix, B.y0, B.nrows, B.x0, B.bw, B.lp);
     }
 #endif
     d_logos_.upload(hl, ctx_->stream);

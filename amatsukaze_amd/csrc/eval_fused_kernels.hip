@@ -123,7 +123,7 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: the staging rows' address math goes to the scalar unit
-    const int w = L.w, lp = L.lp;
+    const int w = L.w;
     constexpr unsigned ES = sizeof(pix_t);
 
     if (tid < G * nfades) accs[tid] = 0.0f;          // G * nfades <= 256 (host)
@@ -140,6 +140,7 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
     int prev_npix = 0, prev_g = 0, prev_rows = 0;    // the iteration waiting to be summed: its band's pixels, first frame, score rows
     for (int bi = 0; bi < L.nbands; ++bi) {
         const EvalBand B = bands[L.band0 + bi];
+        const int lp = B.lp, bx0 = B.x0, bx1 = B.x0 + B.bw;       // the band's LDS row pitch and the logo columns [bx0, bx1) it stages
         // ---- this thread's run slot: kernel taps as packed pairs, resident for all frames and fades of the band ----
         const bool act = tid < B.nslots;
         const unsigned slot = (unsigned)(B.s0 + (act ? tid : 0));
@@ -176,10 +177,10 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
             const int worker = (wave - sumwave + kFusedWaves - 1) & (kFusedWaves - 1);       // 0..2 stage, 3 = sumwave
             for (int rg = worker * kStageRows; rg < ((dbg & 2) || worker == kFusedWaves - 1 ? 0 : B.nrows); rg += kStageRows * (kFusedWaves - 1)) {
                 const int y = B.y0 + rg;                                     // logo row of the group's first row
-                for (int xg = 0; xg < w; xg += 256) {
+                for (int xg = bx0; xg < bx1; xg += 256) {
                     const int x = xg + 4 * lane;
-                    const int nv = min(4, w - x);                            // valid columns of this lane (<= 0: none)
-                    const int xl = nv >= 4 ? x : 0;                          // lanes at a ragged right edge go column by column
+                    const int nv = min(4, bx1 - x);                          // valid columns of this lane (<= 0: none)
+                    const int xl = nv >= 4 ? x : bx0;                        // lanes at a ragged right edge go column by column
                     Raw4<pix_t> raw[FPI][kStageRows + 2];
                     f4 av[kStageRows], bv[kStageRows];
                     // all frames' loads first (one round trip), then the arithmetic and the LDS stores
@@ -221,8 +222,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                                         sv[k] = s1;
                                         gv[k] = unblend_bg(av[j][k], bv[j][k], maxv, s1);
                                     }
-                                    *reinterpret_cast<f4*>(planeS + (rg + j) * lp + x) = sv;
-                                    *reinterpret_cast<f4*>(planeB + (rg + j) * lp + x) = gv;
+                                    *reinterpret_cast<f4*>(planeS + (rg + j) * lp + (x - bx0)) = sv;
+                                    *reinterpret_cast<f4*>(planeB + (rg + j) * lp + (x - bx0)) = gv;
                                 }
                             }
                         } else if (nv > 0) {
@@ -240,8 +241,8 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                                         q1 = gld<pix_t>(src[fr], (unsigned)(yy * L.row_step * pitch + x + k) * ES);
                                     }
                                     const float s1 = blend ? (float)(q0 + 2 * q1 + q2 + 2) / 4.0f : (float)q1;
-                                    planeS[(rg + j) * lp + x + k] = s1;
-                                    planeB[(rg + j) * lp + x + k] = unblend_bg(gld<float>(gA, (unsigned)(yy * w + x + k) * 4u),
+                                    planeS[(rg + j) * lp + (x - bx0) + k] = s1;
+                                    planeB[(rg + j) * lp + (x - bx0) + k] = unblend_bg(gld<float>(gA, (unsigned)(yy * w + x + k) * 4u),
                                                                                gld<float>(gB, (unsigned)(yy * w + x + k) * 4u), maxv, s1);
                                 }
                             }

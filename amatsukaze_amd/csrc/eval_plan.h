@@ -46,6 +46,9 @@ struct EvalBand {
     int s0, nslots;
     int y0, nrows;           // staged logo rows [y0, y0+nrows)
     int m0, npix;            // the band's mask pixels [m0, m0+npix) (raster order)
+    int x0, bw;              // staged logo columns [x0, x0+bw): the whole width while five rows of it fit an LDS plane, else the
+                             // columns the band's windows touch (x0 a multiple of 4) -- logos of any width
+    int lp;                  // LDS row pitch of this band in floats: ((bw+31)&~31)+8
 };
 
 } // namespace amt

@@ -1208,82 +1208,11 @@ def measure_boundary(ctx, logos, device, frames=6144):
     return out
 
 
-# --------------------------------------------------------------------------------------------------------------------
-# frames that are NOT resident: pageable host -> pinned ring -> hipMemcpyAsync on the side stream, overlapped with the
-# analysis of the previous batch.  Never `value`; reported beside it.
-# --------------------------------------------------------------------------------------------------------------------
-def measure_ingest(ctx, logos, alpha, alphaUV, dev, B=256, batches=10):
-    import torch
-    import amt_synth as S
-    from amatsukaze_amd import AMTAnalyzeLogo, FrameStats, LogoFrame
-    g = S.make_clip_torch(B, W, H, 0x5EED0002, alpha, alphaUV, IMGX, IMGY, dev, pitchY=PITCH_Y, pitchUV=PITCH_UV, chroma=False)
-    hY = g["Y"].cpu().numpy().copy()                                  # the "decoder output": pageable host memory
-    del g
-    ybytes = hY.nbytes
-    # rectangle-only variant for the logo passes: the rows [IMGY, IMGY+LH) of the Y plane at full pitch (the kernels address
-    # (imgx, imgy) inside a frame, so the upload keeps the pitch and drops the rows nobody reads): LH*pitch bytes per frame
-    hR = np.ascontiguousarray(hY[:, IMGY:IMGY + LH, :])
-    rbytes = hR.nbytes
-    dbuf = [torch.empty((B, H, PITCH_Y), dtype=torch.uint8, device=dev) for _ in range(2)]
-    lf = LogoFrame(ctx, [logos[0]], MASKRATIO)
-    lf.begin(W, H, 8, B * batches)
-    an = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO)
-    fs = FrameStats(ctx, W, H, 8)
-    d_an = torch.empty((B, 33), dtype=torch.float32, device=dev)
-    d_st = torch.empty((B, 8), dtype=torch.int64, device=dev)
-
-    def upload(k, rect):
-        if rect:   # rows [IMGY, IMGY+LH) of every frame: B pieces of LH*pitch bytes, one frame stride apart on the device
-            ctx.check(ctx.lib.amtgpu_frames_upload_strided(ctx.h, dbuf[k & 1].data_ptr() + IMGY * PITCH_Y, H * PITCH_Y, hR.ctypes.data,
-                                                           LH * PITCH_Y, LH * PITCH_Y, B))
-        else:
-            ctx.check(ctx.lib.amtgpu_frames_upload(ctx.h, dbuf[k & 1].data_ptr(), hY.ctypes.data, ybytes))
-
-    def compute(k, rect):
-        ctx.check(ctx.lib.amtgpu_frames_upload_wait(ctx.h))          # compute stream waits for the copies issued so far
-        lf.scan_batch(dbuf[k & 1], 8, k * B, B)
-        an.analyze_device(dbuf[k & 1], 8, d_an)
-        if not rect:
-            fs.run_device(dbuf[k & 1], d_st)
-
-    def timed(fn, *a):
-        fn(*a)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fn(*a)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
-
-    def ingest_only(rect):
-        for k in range(batches):
-            upload(k, rect)
-        ctx.check(ctx.lib.amtgpu_frames_upload_wait(ctx.h))
-
-    def compute_only(rect):
-        for k in range(batches):
-            compute(k, rect)
-
-    def pipelined(rect):
-        done = [torch.cuda.Event(), torch.cuda.Event()]
-        upload(0, rect)
-        for k in range(batches):
-            compute(k, rect)
-            done[k & 1].record()
-            if k + 1 < batches:
-                if k >= 1:
-                    done[(k + 1) & 1].synchronize()                   # batch k-1 has released the buffer batch k+1 goes into
-                upload(k + 1, rect)
-
-    n = B * batches
-    ti, tc, tp = timed(ingest_only, False), timed(compute_only, False), timed(pipelined, False)
-    ri, rc, rp = timed(ingest_only, True), timed(compute_only, True), timed(pipelined, True)
-    return {"what": "PCIe-inclusive rates: frames start in pageable host memory (amtgpu_frames_upload: pinned double-buffered ring, "
-                    "hipMemcpyAsync on the side stream) and the previous batch is analysed meanwhile; never `value`",
-            "batch_frames": B, "batches": batches,
-            "y_plane": {"bytes_per_frame": ybytes // B, "ingest_only_fps": n / ti, "ingest_GBs": ybytes * batches / ti / 1e9,
-                        "compute_only_fps": n / tc, "pipelined_fps": n / tp, "passes": "scan 1 logo + analysis + frame metrics"},
-            "logo_rectangle_rows": {"bytes_per_frame": rbytes // B, "ingest_only_fps": n / ri, "ingest_GBs": rbytes * batches / ri / 1e9,
-                                    "compute_only_fps": n / rc, "pipelined_fps": n / rp, "passes": "scan 1 logo + analysis (logo passes only)"}}
+def measure_ingest(ctx, logos, alpha, alphaUV, dev):
+    """frames that are NOT resident (PCIe inclusive; never `value`): tools/bench_ingest.py"""
+    import bench_ingest
+    return bench_ingest.measure(ctx, logos, alpha, alphaUV, dev, dict(W=W, H=H, PITCH_Y=PITCH_Y, PITCH_UV=PITCH_UV, IMGX=IMGX, IMGY=IMGY, LH=LH,
+                                                                      MASKRATIO=MASKRATIO, ROOT=ROOT))
 
 
 if __name__ == "__main__":

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "amt_gpu.h"
@@ -61,9 +62,12 @@ constexpr int kUploadGroup = 64;   /* host frames whose logo rectangles share on
 class Context {
     AmtGpuContext* g_;
 public:
-    explicit Context(int device = 0) : g_(amtgpu_context_create(device))
+    /* keepalive_us > 0: amtgpu_context_set_keepalive(keepalive_us, keepalive_us) -- for hosts that pull frames one small block at a
+     * time and would otherwise leave the device's queues idle between blocks (see amt_gpu.h) */
+    explicit Context(int device = 0, int keepalive_us = 0) : g_(amtgpu_context_create(device))
     {
         if (!g_) throw std::runtime_error("amtgpu: no HIP device (there is no CPU path)");
+        if (keepalive_us > 0) amtgpu_context_set_keepalive(g_, keepalive_us, keepalive_us);
     }
     ~Context() { amtgpu_context_destroy(g_); }
     Context(const Context&) = delete;
@@ -211,31 +215,49 @@ class AMTEraseLogo : public GenericVideoFilter {
     int cache_first_ = -1;
     std::vector<PVideoFrame> cache_;              /* the erased frames of the current block */
 
-    void need_analysis(int lo, int hi, IScriptEnvironment* env)
-    {
-        lo = std::max(0, lo);
-        hi = std::min(vi.num_frames - 1, hi);
-        for (int j = lo >> 3; j <= (hi >> 3); ++j) {
-            if (have_[j]) continue;
-            PVideoFrame f = analyzeclip_->GetFrame(j, env);
-            const float* rec = reinterpret_cast<const float*>(f->GetReadPtr());
-            const int cnt = std::min(8, vi.num_frames - j * 8);
-            std::memcpy(&analysis_[(size_t)j * 8 * AMTGPU_ANALYZE_FLOATS], rec, sizeof(float) * AMTGPU_ANALYZE_FLOATS * cnt);
-            have_[j] = 1;
-        }
-    }
+    /* what one block needs from upstream, fetched WITHOUT the filter's lock (under Prefetch the child clip's work -- AMTSource decode,
+     * the analysis filter -- then runs on as many threads as the host gives this filter, as with the reference's per-frame filter) */
+    struct Fetched {
+        int first = 0, nb = 0;
+        std::vector<PVideoFrame> frames;
+        std::vector<std::pair<int, PVideoFrame>> analysis;      /* (analysis frame number, frame) */
+    };
 
-    /* frames [first, first + nb): fetched, their logo rectangles uploaded together, ONE Delogo launch (LogoScan.hpp:1248-1261,
-     * 1374-1397), one copy back.  Delogo rewrites the rectangle and nothing else: w*h luma and 2 * w/2*h/2 chroma samples per frame
-     * cross PCIe each way, and a frame whose fades are both 0 does not travel at all when the reference's arithmetic is the
-     * identity there (amtgpu_erase_get_rect). */
-    void fill(int first, IScriptEnvironment* env)
+    Fetched fetch(int first, IScriptEnvironment* env)
     {
-        const int es = vi.ComponentSize();
-        const int nb = std::min(block_, vi.num_frames - first);
+        Fetched f;
+        f.first = first;
+        f.nb = std::min(block_, vi.num_frames - first);
         /* CalcFade2 reads the analysis of source frames n-8 .. n+8; a logoframe transition can widen that by maxfade/2 */
         const int reach = 8 + (maxFadeLength_ >> 1) + 1;
-        need_analysis(first - reach, first + nb - 1 + reach, env);
+        const int lo = std::max(0, first - reach), hi = std::min(vi.num_frames - 1, first + f.nb - 1 + reach);
+        std::vector<int> missing;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            for (int j = lo >> 3; j <= (hi >> 3); ++j) if (!have_[j]) missing.push_back(j);
+        }
+        for (int j : missing) f.analysis.emplace_back(j, analyzeclip_->GetFrame(j, env));
+        f.frames.resize(f.nb);
+        for (int i = 0; i < f.nb; ++i) f.frames[i] = child->GetFrame(first + i, env);
+        return f;
+    }
+
+    /* frames [first, first + nb): their logo rectangles uploaded together, ONE Delogo launch (LogoScan.hpp:1248-1261, 1374-1397), one
+     * copy back.  Delogo rewrites the rectangle and nothing else: w*h luma and 2 * w/2*h/2 chroma samples per frame cross PCIe each
+     * way, and a frame whose fades are both 0 does not travel at all when the reference's arithmetic is the identity there
+     * (amtgpu_erase_get_rect).  Called with mu_ held. */
+    void process(Fetched& in, IScriptEnvironment* env)
+    {
+        for (auto& a : in.analysis) {
+            if (have_[a.first]) continue;
+            const float* rec = reinterpret_cast<const float*>(a.second->GetReadPtr());
+            const int cnt = std::min(8, vi.num_frames - a.first * 8);
+            std::memcpy(&analysis_[(size_t)a.first * 8 * AMTGPU_ANALYZE_FLOATS], rec, sizeof(float) * AMTGPU_ANALYZE_FLOATS * cnt);
+            have_[a.first] = 1;
+        }
+        in.analysis.clear();
+        const int first = in.first, nb = in.nb;
+        const int es = vi.ComponentSize();
         std::vector<float> fades((size_t)nb * 2);
         if (!amtgpu_erase_calc_fades(er_, analysis_.data(), vi.num_frames, first, nb, fades.data())) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
         int rc[5];
@@ -244,13 +266,12 @@ class AMTEraseLogo : public GenericVideoFilter {
         if (imgx < 0 || imgy < 0 || imgx + w > vi.width || imgy + h > vi.height) env->ThrowError("[AMTEraseLogo] logo rectangle outside the frame");
         const int wUV = w >> 1, hUV = h >> 1, cx = imgx >> 1, cy = imgy >> 1;
         const uint64_t by = (uint64_t)w * h * es, buv = (uint64_t)wUV * hUV * es, per = by + 2 * buv;
-        std::vector<PVideoFrame> frames(nb);
+        std::vector<PVideoFrame>& frames = in.frames;
         std::vector<int> slot(nb, -1);                /* position of the frame's rectangle in the device batch, -1: untouched */
         std::vector<float> bf;
         AmtGpuContext* g = ctx_->get();
         int m = 0;
         for (int i = 0; i < nb; ++i) {
-            frames[i] = child->GetFrame(first + i, env);
             /* both fades 0: the reference's arithmetic is the identity -- for samples <= maxv, i.e. at 8 and 16 bits (at 10 / 12 bits
              * its clamp still rewrites out-of-range container values, LogoScan.hpp:1258): the frame is returned as it came */
             const int bpc = vi.BitsPerComponent();
@@ -263,36 +284,54 @@ class AMTEraseLogo : public GenericVideoFilter {
             dbuf_.reserve(per * m);
             /* device layout: Y [m][h][w], then U [m][hUV][wUV], then V */
             uint8_t *dY = dbuf_.at(0), *dU = dbuf_.at(by * m), *dV = dbuf_.at(by * m + buv * m);
+            /* frames of one clip share their pitches (AviSynth allocates them alike): the rectangles of the whole block then leave in
+             * three gather uploads (Y, U, V) instead of three calls per frame */
+            std::vector<const void*> sY, sU, sV;
+            int pY0 = 0, pUV0 = 0;
+            bool same_pitch = true;
             for (int i = 0; i < nb; ++i) {
                 if (slot[i] < 0) continue;
                 const int pY = frames[i]->GetPitch(PLANAR_Y), pUV = frames[i]->GetPitch(PLANAR_U);
-                const uint8_t* hY = frames[i]->GetReadPtr(PLANAR_Y) + (size_t)imgy * pY + (size_t)imgx * es;
-                const uint8_t* hU = frames[i]->GetReadPtr(PLANAR_U) + (size_t)cy * pUV + (size_t)cx * es;
-                const uint8_t* hV = frames[i]->GetReadPtr(PLANAR_V) + (size_t)cy * pUV + (size_t)cx * es;
-                if (!amtgpu_frames_upload_strided(g, dY + by * slot[i], (int64_t)w * es, hY, pY, (uint64_t)w * es, h) ||
-                    !amtgpu_frames_upload_strided(g, dU + buv * slot[i], (int64_t)wUV * es, hU, pUV, (uint64_t)wUV * es, hUV) ||
-                    !amtgpu_frames_upload_strided(g, dV + buv * slot[i], (int64_t)wUV * es, hV, pUV, (uint64_t)wUV * es, hUV))
+                if (sY.empty()) { pY0 = pY; pUV0 = pUV; }
+                same_pitch = same_pitch && pY == pY0 && pUV == pUV0 && frames[i]->GetPitch(PLANAR_V) == pUV0;
+                sY.push_back(frames[i]->GetReadPtr(PLANAR_Y) + (size_t)imgy * pY + (size_t)imgx * es);
+                sU.push_back(frames[i]->GetReadPtr(PLANAR_U) + (size_t)cy * pUV + (size_t)cx * es);
+                sV.push_back(frames[i]->GetReadPtr(PLANAR_V) + (size_t)cy * pUV + (size_t)cx * es);
+            }
+            if (same_pitch) {
+                if (!amtgpu_frames_upload_gather(g, dY, (int64_t)w * es, sY.data(), pY0, (uint64_t)w * es, h, m) ||
+                    !amtgpu_frames_upload_gather(g, dU, (int64_t)wUV * es, sU.data(), pUV0, (uint64_t)wUV * es, hUV, m) ||
+                    !amtgpu_frames_upload_gather(g, dV, (int64_t)wUV * es, sV.data(), pUV0, (uint64_t)wUV * es, hUV, m))
                     env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+            } else {
+                for (int i = 0, k = 0; i < nb; ++i) {
+                    if (slot[i] < 0) continue;
+                    const int pY = frames[i]->GetPitch(PLANAR_Y), pUV = frames[i]->GetPitch(PLANAR_U);
+                    if (!amtgpu_frames_upload_strided(g, dY + by * k, (int64_t)w * es, sY[k], pY, (uint64_t)w * es, h) ||
+                        !amtgpu_frames_upload_strided(g, dU + buv * k, (int64_t)wUV * es, sU[k], pUV, (uint64_t)wUV * es, hUV) ||
+                        !amtgpu_frames_upload_strided(g, dV + buv * k, (int64_t)wUV * es, sV[k], pUV, (uint64_t)wUV * es, hUV))
+                        env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
+                    ++k;
+                }
             }
             if (!amtgpu_frames_upload_wait(g)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
             if (!amtgpu_erase_rect_batch(er_, dY, dU, dV, (int64_t)by, (int64_t)buv, w, wUV, vi.BitsPerComponent(), m, bf.data()))
                 env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-            const void* hp = nullptr;
-            if (!amtgpu_download_pinned(g, dbuf_.at(0), per * m, &hp)) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
-            const uint8_t* back = static_cast<const uint8_t*>(hp);
+            /* one copy back; the library scatters the rows into the frames while it still holds the context's lock (the landing buffer
+             * belongs to the context, which other filters on other threads share) */
+            std::vector<AmtGpuScatter> pieces;
+            pieces.reserve((size_t)m * 3);
             for (int i = 0; i < nb; ++i) {
                 if (slot[i] < 0) continue;
                 const int pY = frames[i]->GetPitch(PLANAR_Y), pUV = frames[i]->GetPitch(PLANAR_U);
                 uint8_t* hY = frames[i]->GetWritePtr(PLANAR_Y) + (size_t)imgy * pY + (size_t)imgx * es;
                 uint8_t* hU = frames[i]->GetWritePtr(PLANAR_U) + (size_t)cy * pUV + (size_t)cx * es;
                 uint8_t* hV = frames[i]->GetWritePtr(PLANAR_V) + (size_t)cy * pUV + (size_t)cx * es;
-                const uint8_t *sY = back + by * slot[i], *sU = back + by * m + buv * slot[i], *sV = back + by * m + buv * m + buv * slot[i];
-                for (int y = 0; y < h; ++y) std::memcpy(hY + (size_t)y * pY, sY + (size_t)y * w * es, (size_t)w * es);
-                for (int y = 0; y < hUV; ++y) {
-                    std::memcpy(hU + (size_t)y * pUV, sU + (size_t)y * wUV * es, (size_t)wUV * es);
-                    std::memcpy(hV + (size_t)y * pUV, sV + (size_t)y * wUV * es, (size_t)wUV * es);
-                }
+                pieces.push_back(AmtGpuScatter{hY, pY, by * slot[i], (uint64_t)w * es, h});
+                pieces.push_back(AmtGpuScatter{hU, pUV, by * m + buv * slot[i], (uint64_t)wUV * es, hUV});
+                pieces.push_back(AmtGpuScatter{hV, pUV, by * m + buv * m + buv * slot[i], (uint64_t)wUV * es, hUV});
             }
+            if (!amtgpu_download_scatter(g, dbuf_.at(0), per * m, pieces.data(), (int)pieces.size())) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
         }
         cache_.swap(frames);
         cache_first_ = first;
@@ -319,9 +358,15 @@ public:
     {
         const int es = vi.ComponentSize();
         if (es != 1 && es != 2) env->ThrowError("[AMTEraseLogo] Unsupported pixel format");
-        std::lock_guard<std::mutex> lock(mu_);
         n = std::max(0, std::min(vi.num_frames - 1, n));
-        if (cache_first_ < 0 || n < cache_first_ || n >= cache_first_ + (int)cache_.size()) fill(n - n % block_, env);
+        auto cached = [&]() { return cache_first_ >= 0 && n >= cache_first_ && n < cache_first_ + (int)cache_.size(); };
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            if (cached()) return cache_[n - cache_first_];
+        }
+        Fetched f = fetch(n - n % block_, env);           /* upstream work: not under the lock */
+        std::lock_guard<std::mutex> lock(mu_);
+        if (!cached()) process(f, env);                   /* (another thread may have served the same block meanwhile) */
         return cache_[n - cache_first_];
     }
     int SetCacheHints(int cachehints, int) override { return cachehints == AMT_AVS_NS CACHE_GET_MTMODE ? AMT_AVS_NS MT_NICE_FILTER : 0; }
@@ -338,8 +383,15 @@ class LogoFrame {
     int numFrames_ = 0;
     int framesPerLaunch_;
     DeviceBuffer dY_[2];                          /* the two batches in flight */
+    AmtGpuMarker* done_[2] = {nullptr, nullptr};  /* "the scan of the batch in this buffer has finished": this object's own markers */
 
     void check(int ok) const { if (!ok) throw std::runtime_error(ctx_->error()); }
+    void release()
+    {
+        for (auto& m : done_) { if (m) amtgpu_marker_destroy(ctx_->get(), m); m = nullptr; }
+        if (lf_) amtgpu_logoframe_destroy(lf_);
+        lf_ = nullptr;
+    }
 
 public:
     LogoFrame(PContext ctx, const std::vector<std::string>& logofiles, float maskratio, int framesPerLaunch = 2048)
@@ -349,8 +401,12 @@ public:
         for (const auto& s : logofiles) paths.push_back(s.c_str());
         lf_ = amtgpu_logoframe_create(ctx_->get(), paths.data(), numLogos_, maskratio);
         if (!lf_) throw std::runtime_error(ctx_->error());
+        for (auto& m : done_) {
+            m = amtgpu_marker_create(ctx_->get());
+            if (!m) { const std::string why = ctx_->error(); release(); throw std::runtime_error(why); }
+        }
     }
-    ~LogoFrame() { if (lf_) amtgpu_logoframe_destroy(lf_); }
+    ~LogoFrame() { release(); }
     LogoFrame(const LogoFrame&) = delete;
     LogoFrame& operator=(const LogoFrame&) = delete;
 
@@ -375,7 +431,7 @@ public:
         for (int n0 = 0; n0 < vi.num_frames; n0 += framesPerLaunch_, ++k) {
             const int nb = std::min(framesPerLaunch_, vi.num_frames - n0);
             DeviceBuffer& buf = dY_[k & 1];
-            check(amtgpu_marker_wait(ctx_->get(), k & 1));            /* the scan of batch k - 2 has left this buffer */
+            check(amtgpu_marker_wait_on(ctx_->get(), done_[k & 1]));  /* the scan of batch k - 2 has left this buffer */
             /* frames leave in groups: one upload call (one copy launch) per kUploadGroup frames -- per frame, the API overhead of a
              * copy is several times the time its 32 KB take */
             std::vector<PVideoFrame> held;
@@ -397,7 +453,7 @@ public:
                 } else if (f->GetPitch(PLANAR_Y) != pitch) {
                     throw std::runtime_error("[LogoFrame] frames of one clip must share a pitch");
                 }
-                if (i == 0) buf.reserve(part * std::min(framesPerLaunch_, vi.num_frames));
+                if (i == 0) buf.reserve(part * std::min(framesPerLaunch_, vi.num_frames) + 64);   /* (+ tail slack of the virtual-row addressing) */
                 if (srcs.empty()) group_first = i;
                 srcs.push_back(f->GetReadPtr(PLANAR_Y) + (uint64_t)r0 * pitch + (uint64_t)c0 * es);
                 held.push_back(std::move(f));
@@ -407,7 +463,7 @@ public:
             check(amtgpu_frames_upload_wait(ctx_->get()));
             /* frame i of the batch: rows r0.. at buf + part * i, i.e. its (virtual) row 0 sits r0 * pitch bytes before that */
             check(amtgpu_logoframe_scan_batch(lf_, buf.at(0) - (uint64_t)r0 * pitch, (int64_t)part, pitch / es, n0, nb));
-            check(amtgpu_marker_record(ctx_->get(), k & 1));
+            check(amtgpu_marker_record_on(ctx_->get(), done_[k & 1]));
         }
         check(amtgpu_context_synchronize(ctx_->get()));
     }

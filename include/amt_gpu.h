@@ -84,6 +84,17 @@ int   amtgpu_frames_upload_strided(AmtGpuContext* ctx, void* ddst, int64_t dst_s
 int   amtgpu_frames_upload_gather(AmtGpuContext* ctx, void* ddst, int64_t dst_stride, const void* const* hsrc, int64_t src_stride,
                                   uint64_t chunk_bytes, int chunks_per_src, int nsrc);
 int   amtgpu_frames_upload_wait(AmtGpuContext* ctx);   /* make the compute stream wait for pending uploads */
+/* Uploads from pageable host memory are staged through a ring of four pinned 16 MiB slots; the staging memcpy of a large upload is
+ * shared out over `nthreads` threads (the caller's included; default min(8, cores / 4)) because one core's memcpy is below what
+ * PCIe Gen5 x16 carries.  1 = the calling thread alone. */
+int   amtgpu_context_set_upload_threads(AmtGpuContext* ctx, int nthreads);
+/* Page-lock a host range in place (hipHostRegister) -- a decoder's frame pool, the buffers AMTSource keeps its frames in
+ * (AMTSource.hpp:428-442): amtgpu_frames_upload / _upload_strided whose source lies inside a registered range skip the staging ring
+ * and go out as one DMA copy straight from the caller's memory, which must stay untouched until amtgpu_frames_upload_wait's
+ * consumer has run (or amtgpu_context_synchronize).  Registration costs about as much as touching every page once: register pools,
+ * not frames.  unregister waits for the side stream first. */
+int   amtgpu_frames_register(AmtGpuContext* ctx, void* hptr, uint64_t bytes);
+int   amtgpu_frames_unregister(AmtGpuContext* ctx, void* hptr);
 int   amtgpu_download(AmtGpuContext* ctx, void* hdst, const void* dsrc, uint64_t bytes);        /* synchronous */
 /* nchunks pieces of chunk_bytes, src_stride apart on the device, dst_stride apart on the host (an erased rectangle back into
  * the rows of a host frame).  synchronous */
@@ -93,12 +104,38 @@ int   amtgpu_download_strided(AmtGpuContext* ctx, void* hdst, int64_t dst_stride
  * the next call.  For callers that scatter the bytes into several host frames themselves (a block of erased rectangles back into
  * the frames AMTEraseLogo::GetFrame serves, LogoScan.hpp:1343-1400). */
 int   amtgpu_download_pinned(AmtGpuContext* ctx, const void* dsrc, uint64_t bytes, const void** hptr);
+/* The same single copy, with the scatter done by the library while the context is still locked -- the form to use when several host
+ * threads share one context (several filters of one script under Prefetch): piece i is nchunks runs of chunk_bytes that sit back to
+ * back at dsrc + src_offset and go to hdst, dst_stride apart (an erased rectangle's rows back into the rows of a host frame). */
+typedef struct AmtGpuScatter {
+    void*    hdst;
+    int64_t  dst_stride;
+    uint64_t src_offset;
+    uint64_t chunk_bytes;
+    int      nchunks;
+} AmtGpuScatter;
+int   amtgpu_download_scatter(AmtGpuContext* ctx, const void* dsrc, uint64_t bytes, const AmtGpuScatter* pieces, int npieces);
 /* Markers on the compute stream, ids 0..15: record(id) behind a batch's launches, wait(id) on the host before that batch's device
  * buffer is written again.  What a double-buffered caller (LogoFrame::scanFrames, LogoScan.hpp:1570-1589, over AMTSource::GetFrame)
  * needs instead of amtgpu_context_synchronize, which would also wait for the batch in flight.  wait on a never recorded id returns
  * at once. */
 int   amtgpu_marker_record(AmtGpuContext* ctx, int id);
 int   amtgpu_marker_wait(AmtGpuContext* ctx, int id);
+/* The same pair on a marker the caller owns: users of a shared context (two LogoFrame scans, a filter next to user code) cannot
+ * re-record each other's markers, whatever ids they would have picked. */
+typedef struct AmtGpuMarker AmtGpuMarker;
+AmtGpuMarker* amtgpu_marker_create(AmtGpuContext* ctx);
+void  amtgpu_marker_destroy(AmtGpuContext* ctx, AmtGpuMarker* m);
+int   amtgpu_marker_record_on(AmtGpuContext* ctx, AmtGpuMarker* m);
+int   amtgpu_marker_wait_on(AmtGpuContext* ctx, AmtGpuMarker* m);     /* never recorded: returns at once */
+/* Keep-alive for frame-by-frame hosts.  A host that pulls one small block at a time (GetFrame by GetFrame through
+ * include/amt_filters.hpp) leaves the device's queues idle for milliseconds between launches, and on some hosts an idle queue is
+ * picked up again late (measured: completions at multiples of 10 ms, profiles/r03_notes.md "Boundary", profiles/r04_notes.md).  With
+ * period_us > 0 a helper thread launches a one-wave kernel on a lowest-priority side stream every period_us microseconds (skipping a
+ * beat while the previous one is still running); spin_us > 0 makes each beat keep its wave resident for that long (constant-clock
+ * timed s_sleep loop), so that with spin_us >= period_us the device never goes idle at all.  0, 0 stops it.  Every beat ends by
+ * itself: device-wide synchronisation (hipDeviceSynchronize, hipFree) is delayed by at most spin_us.  Off by default. */
+int   amtgpu_context_set_keepalive(AmtGpuContext* ctx, int period_us, int spin_us);
 
 /* ---- frame assembly: replaces AMTSource::MakeFrame -> MergeField / Copy1 / Copy2 (AMTSource.hpp:291-366) on decoded
  *      pictures already in HBM (uploaded with amtgpu_frames_upload): output frame i takes its even rows from picture

@@ -173,6 +173,11 @@ static int run_bench(int argc, char** argv)
     const std::string l1 = argv[5], l2 = argv[6], l3 = argc > 7 ? argv[7] : argv[6];
     IScriptEnvironment env;
     auto ctx = std::make_shared<amtgpu::Context>(argc > 8 ? std::atoi(argv[8]) : 0);
+    int ka_period = 0, ka_spin = 0;
+    if (const char* ka = std::getenv("AMT_KEEPALIVE")) {            // "period_us,spin_us": amtgpu_context_set_keepalive (diagnostic / tuning)
+        std::sscanf(ka, "%d,%d", &ka_period, &ka_spin);
+        if (!amtgpu_context_set_keepalive(ctx->get(), ka_period, ka_spin)) { std::fprintf(stderr, "keepalive: %s\n", ctx->error()); return 1; }
+    }
     PClip src = std::make_shared<SynthClip>(W, H, N, l1);
     auto secs = [](auto&& fn) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -189,6 +194,7 @@ static int run_bench(int argc, char** argv)
         t_scan = secs([&] { lf.scanFrames(src, &env); });
     }
     double t_an[2] = {0, 0}, t_er[2] = {0, 0};
+    std::map<int, int> blk_hist[2];
     uint64_t sum[2] = {0, 0};
     const bool swap_order = std::getenv("AMT_BENCH_SWAP") != nullptr;      // (diagnostic: the fast mode first)
     for (int pass = 0; pass < 2; ++pass) {
@@ -209,7 +215,14 @@ static int run_bench(int argc, char** argv)
             if (amtgpu_profile_report(ctx->get(), rep, sizeof rep) >= 0) std::fprintf(stderr, "kernel times (name calls total_ms):\n%s\n", rep);
             amtgpu_profile_enable(ctx->get(), 0);
         }
-        t_an[mode] = secs([&] { for (int n = 0; n < na; ++n) an2->GetFrame(n, &env); });
+        // per-call latency of the calls that launch a block (the others are served from the filter's cache): histogram in whole ms
+        std::map<int, int>& hist = blk_hist[mode];
+        t_an[mode] = secs([&] {
+            for (int n = 0; n < na; ++n) {
+                const double t = secs([&] { an2->GetFrame(n, &env); });
+                if (t > 2e-4) hist[(int)(t * 1e3 + 0.5)] += 1;
+            }
+        });
         // the MakeSource graph: AMTEraseLogo(src, AMTAnalyzeLogo(src, logo), logo) pulled in order, as the encoder does
         PClip an3 = std::make_shared<amtgpu::AMTAnalyzeLogo>(src, l1, 0.35f, &env, ctx, 32, mode ? AMTGPU_ANALYZE_LINEAR_GUARDED : AMTGPU_ANALYZE_EXACT);
         PClip er = std::make_shared<amtgpu::AMTEraseLogo>(src, an3, l1, "", 0, 16, &env, ctx);
@@ -223,8 +236,14 @@ static int run_bench(int argc, char** argv)
     std::printf("{\"what\": \"frames/s through include/amt_filters.hpp (GetFrame by GetFrame, frames in host memory, PCIe inclusive)\", "
                 "\"frame\": \"%dx%d 8-bit\", \"frames\": %d, \"source_alone_fps\": %.0f, \"logoframe_scan_3_logos_fps\": %.0f, "
                 "\"analyze_exact_fps\": %.0f, \"analyze_linear_guarded_fps\": %.0f, \"erase_graph_exact_fps\": %.0f, "
-                "\"erase_graph_linear_guarded_fps\": %.0f, \"erased_frames_identical_in_both_modes\": %s}\n",
-                W, H, N, N / t_src, N / t_scan, N / t_an[0], N / t_an[1], N / t_er[0], N / t_er[1], sum[0] == sum[1] ? "true" : "false");
+                "\"erase_graph_linear_guarded_fps\": %.0f, \"erased_frames_identical_in_both_modes\": %s, \"keepalive_us\": [%d, %d], ",
+                W, H, N, N / t_src, N / t_scan, N / t_an[0], N / t_an[1], N / t_er[0], N / t_er[1], sum[0] == sum[1] ? "true" : "false", ka_period, ka_spin);
+    for (int mode = 0; mode < 2; ++mode) {
+        std::printf("\"analyze_%s_block_ms_hist\": {", mode ? "linear" : "exact");
+        bool firstk = true;
+        for (const auto& kv : blk_hist[mode]) { std::printf("%s\"%d\": %d", firstk ? "" : ", ", kv.first, kv.second); firstk = false; }
+        std::printf("}%s", mode ? "}\n" : ", ");
+    }
     return 0;
 }
 

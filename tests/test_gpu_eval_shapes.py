@@ -162,23 +162,34 @@ def test_logo_without_mask_pixels(gpu):
         assert got.shape == (cfg["N"], 33) and np.isnan(got).all()
 
 
-def test_widest_supported_logo_and_too_wide(gpu):
-    """A band must hold the 5 rows of a window in its LDS plane (3072 floats): 576 columns is the widest logo that fits (row
-    pitch 584, one mask row per band, three 256-column staging groups); wider logos are refused, not mis-evaluated."""
-    from amatsukaze_amd import AMTAnalyzeLogo, AmtError
-    W, H, LW, LH, X, Y0, N = 704, 96, 576, 24, 100, 30, 5
+@pytest.mark.parametrize("case", ["w576_whole_rows", "w680_column_bands", "w1200_maskratio1", "w680_10bit", "w900_scan"])
+def test_logos_of_any_width(gpu, case):
+    """The exact kernel's bands hold the 5 rows of a window in an LDS plane of 3072 floats: up to 576 columns a band stages whole
+    rows (row pitch 584, three 256-column staging groups); wider logos -- the reference takes any even w x h (LogoScan.hpp:69) -- get
+    bands that stage only the columns their windows touch.  Bytes against the oracle, for AMTAnalyzeLogo (exact, the library default)
+    and for the generic kernel on the scan (field logos / fades other than {0, 1} take it)."""
+    import ctypes as C
+    from amatsukaze_amd import AMTAnalyzeLogo, LogoFrame
+    W, H, LW, LH, X, Y0, N, bits, ratio = {"w576_whole_rows": (704, 96, 576, 24, 100, 30, 5, 8, 0.35),
+                                           "w680_column_bands": (800, 96, 680, 24, 60, 30, 4, 8, 0.35),
+                                           "w1200_maskratio1": (1440, 64, 1200, 16, 120, 20, 3, 8, 1.0),
+                                           "w680_10bit": (800, 96, 680, 24, 62, 30, 3, 10, 0.35),
+                                           "w900_scan": (1024, 80, 900, 20, 64, 28, 4, 8, 0.35)}[case]
     cfg = dict(W=W, H=H, LW=LW, LH=LH, IMGX=X, IMGY=Y0, N=N, period=4, fade=2, flat=3)
-    cs = make_case(gpu, cfg, bits=8, pitch_pad=0)
-    got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(cs["dclip"])
-    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"])
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=0)
     Y = cs["clip"]["Y"]
+    d, t, b = oracle_eval_logos(cs["orc"], cs["lo"], ratio)
+    if case == "w900_scan":
+        lf = LogoFrame(gpu["ctx"], [cs["logo"]], ratio)
+        lf.scanFrames(cs["dclip"])
+        want = np.zeros(N * 2, np.float32)
+        cs["orc"].lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], Y.shape[2], bits, W, H, N, _ptr(want))
+        assert lf.evalResults.reshape(-1).tobytes() == want.tobytes()
+        return
+    got = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], ratio).analyze(cs["dclip"])
     want = np.zeros(N * 33, np.float32)
-    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], 8, N, _ptr(want))
+    cs["orc"].lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], bits, N, _ptr(want))
     assert got.reshape(-1).tobytes() == want.tobytes()
-    cfg2 = dict(W=800, H=96, LW=680, LH=24, IMGX=60, IMGY=30, N=2, period=4, fade=2, flat=3)
-    cs2 = make_case(gpu, cfg2, bits=8, pitch_pad=0)
-    with pytest.raises(AmtError, match="too wide"):
-        AMTAnalyzeLogo(gpu["ctx"], cs2["logo"], 0.35)
 
 
 @pytest.mark.parametrize("maskratio", [0.02, 1.0])

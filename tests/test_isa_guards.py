@@ -1,0 +1,173 @@
+"""ISA guards (CPU side: hipcc cross-compiles gfx950 without a GPU).  The evaluation kernels are bit-exact only while a few
+properties of their machine code hold that no runtime test pins down directly; a compiler update that breaks one of them should
+fail HERE, not as a corrupted score somewhere:
+
+  * no scratch and no spills (a spilled tap or window register costs the fade loop 2-3x, and the ablation notes in profiles/ assume none),
+  * VGPRs within the occupancy each kernel is designed for,
+  * no MFMA (these are per-pixel private 25-tap kernels in a prescribed summation order),
+  * and the one that can corrupt silently: eval_tile_stage.h places `s_waitcnt lgkmcnt(N)` with N > 0 by hand to consume LDS reads in
+    issue order while later ones are still in flight.  LDS operations of a wave return in order, scalar memory loads do NOT, and both
+    count in lgkmcnt -- a partial wait is only meaningful while no s_load / s_buffer_load is outstanding.  The check walks the
+    control-flow graph of every kernel: "a scalar load may be outstanding" is propagated from block to block to a fixed point, and no
+    partial lgkmcnt wait may be reached in that state.
+"""
+import hashlib
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "amatsukaze_amd", "csrc")
+CACHE = os.path.join("/tmp", "amt_isa_cache")
+
+# file -> (extra flags, {kernel-name substring: max VGPRs})   budgets: 512 VGPRs per SIMD lane / waves per SIMD, rounded to the allocation granule of 8
+FILES = {
+    "eval_linear_kernels.hip": ([], {"logo_eval_linear_kernel16": 256, "logo_eval_linear_kernel": 168}),
+    "eval_pair_kernels.hip": ([], {"logo_eval_pair_kernel": 168}),
+    "eval_fused_kernels.hip": (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], {"logo_eval_fused_kernel": 256}),
+    "stats_kernels.hip": ([], {"frame_stats_kernel": 256}),
+    "erase_scan_kernels.hip": ([], {"delogo_kernel": 128, "calc_fades_kernel": 128}),
+}
+
+
+def compile_asm(name):
+    from amatsukaze_amd import build as B
+    src = os.path.join(CSRC, name)
+    flags = [f for f in B.FLAGS if f not in ("-fPIC",)] + FILES[name][0]
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    h = hashlib.sha256(" ".join(flags).encode())
+    for d in sorted(deps):
+        h.update(open(d, "rb").read())
+    os.makedirs(CACHE, exist_ok=True)
+    out = os.path.join(CACHE, f"{name}.{h.hexdigest()[:16]}.s")
+    if not os.path.exists(out):
+        subprocess.check_call([B.hipcc()] + flags + ["-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def kernels_of(asm):
+    """{mangled kernel name: {'body': [instruction / label lines], 'meta': {...}}}"""
+    meta = {}
+    for m in re.finditer(r"- \.agpr_count:.*?\n(?=  - \.agpr_count:|\.\.\.|amdhsa\.target)", asm, re.S):
+        blk = m.group(0)
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1)) for k in
+                      ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "agpr_count")}
+    out = {}
+    for name in meta:
+        m = re.search(rf"^{re.escape(name)}:[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M)
+        assert m, f"no body for {name}"
+        body = [l.split(";")[0].rstrip() for l in m.group(1).splitlines()]
+        out[name] = {"meta": meta[name], "body": [l for l in body if l.strip()]}
+    return out
+
+
+def partial_waits_with_smem_outstanding(body):
+    """CFG walk: returns the partial lgkmcnt waits that can be reached with a scalar load outstanding"""
+    # basic blocks: split at labels and after branches
+    blocks, cur, label_of = [], {"label": None, "ins": []}, {}
+    for l in body:
+        t = l.strip()
+        if re.match(r"^\.?[A-Za-z_][\w$.]*:$", t):
+            if cur["ins"] or cur["label"] is not None:
+                blocks.append(cur)
+            cur = {"label": t[:-1], "ins": []}
+            continue
+        if t.startswith("."):            # directives
+            continue
+        cur["ins"].append(t)
+        if re.match(r"^s_(c?branch|endpgm|setpc|swappc)", t):
+            blocks.append(cur)
+            cur = {"label": None, "ins": []}
+    if cur["ins"] or cur["label"] is not None:
+        blocks.append(cur)
+    for i, b in enumerate(blocks):
+        if b["label"]:
+            label_of[b["label"]] = i
+    succ = []
+    for i, b in enumerate(blocks):
+        last = b["ins"][-1] if b["ins"] else ""
+        s = []
+        m = re.match(r"^s_(branch|cbranch_\w+)\s+(\S+)", last)
+        if m:
+            assert m.group(2) in label_of, f"branch to unknown label {m.group(2)}"
+            s.append(label_of[m.group(2)])
+            if m.group(1) != "branch" and i + 1 < len(blocks):
+                s.append(i + 1)
+        elif re.match(r"^s_(endpgm|setpc|swappc)", last):
+            pass
+        elif i + 1 < len(blocks):
+            s.append(i + 1)
+        succ.append(s)
+
+    def transfer(state, ins, hits=None):
+        for t in ins:
+            if re.match(r"^s_(load|buffer_load|scratch_load|atomic|buffer_atomic|dcache|memtime|memrealtime|getreg_b32 .*HW_REG_SHADER_CYCLES)", t):
+                state = True
+            m = re.match(r"^s_waitcnt\b(.*)", t)
+            if m:
+                lg = re.search(r"lgkmcnt\((\d+)\)", m.group(1))
+                if lg and int(lg.group(1)) == 0:
+                    state = False
+                elif lg and state and hits is not None:
+                    hits.append(t)
+                elif not lg and re.search(r"^\s*(0x[0-9a-fA-F]+|\d+)\s*$", m.group(1)):      # raw immediate: decode lgkmcnt (bits 11:8)
+                    v = int(m.group(1).strip(), 0)
+                    n = (v >> 8) & 0xF
+                    if n == 0:
+                        state = False
+                    elif n < 15 and state and hits is not None:
+                        hits.append(t)
+        return state
+
+    entry = [False] * len(blocks)
+    changed = True
+    while changed:
+        changed = False
+        for i, b in enumerate(blocks):
+            o = transfer(entry[i], b["ins"])
+            for j in succ[i]:
+                if o and not entry[j]:
+                    entry[j] = True
+                    changed = True
+    hits = []
+    for i, b in enumerate(blocks):
+        transfer(entry[i], b["ins"], hits)
+    return hits, len(blocks)
+
+
+def test_cfg_walker_sees_a_planted_violation():
+    bad = ["s_load_dword s0, s[2:3], 0x0", "ds_read_b64 v[0:1], v2", "s_waitcnt lgkmcnt(1)", "s_endpgm"]
+    ok = ["s_load_dword s0, s[2:3], 0x0", "s_waitcnt lgkmcnt(0)", "ds_read_b64 v[0:1], v2", "ds_read_b64 v[2:3], v2", "s_waitcnt lgkmcnt(1)", "s_endpgm"]
+    loop = [".LBB0_1:", "ds_read_b64 v[0:1], v2", "ds_read_b64 v[2:3], v2", "s_waitcnt lgkmcnt(1)", "s_load_dword s0, s[2:3], 0x0",
+            "s_cbranch_scc1 .LBB0_1", "s_endpgm"]          # the load of iteration i is outstanding at the partial wait of iteration i + 1
+    assert partial_waits_with_smem_outstanding(bad)[0] and not partial_waits_with_smem_outstanding(ok)[0]
+    assert partial_waits_with_smem_outstanding(loop)[0]
+
+
+@pytest.mark.parametrize("name", sorted(FILES))
+def test_kernel_isa_properties(name):
+    asm = compile_asm(name)
+    ks = kernels_of(asm)
+    budgets = FILES[name][1]
+    seen = set()
+    for kname, k in ks.items():
+        m = k["meta"]
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{kname}: scratch / spills {m}"
+        # (delogo_kernel and the staging / prologue blocks of the generic fused kernel park scalars in VGPR lanes -- v_writelane, no
+        # memory, none inside the fade loop: tolerated there; the tile kernels and the frame metrics must have none)
+        if name not in ("erase_scan_kernels.hip", "eval_fused_kernels.hip"):
+            assert m["sgpr_spill_count"] == 0, f"{kname}: scalar spills {m}"
+        assert not any(re.match(r"^\s*v_(mfma|smfmac)", l) for l in k["body"]), f"{kname}: MFMA in a kernel that must not have any"
+        assert not any("scratch_" in l for l in k["body"]), f"{kname}: scratch instructions"
+        for sub in sorted(budgets, key=len, reverse=True):          # the longest matching name decides (kernel16 before kernel)
+            if sub in kname:
+                assert m["vgpr_count"] + m["agpr_count"] <= budgets[sub], f"{kname}: {m['vgpr_count']} VGPRs (+{m['agpr_count']} AGPRs) > {budgets[sub]}"
+                seen.add(sub)
+                break
+        hits, nblocks = partial_waits_with_smem_outstanding(k["body"])
+        assert nblocks > 0
+        assert not hits, f"{kname}: partial lgkmcnt wait with a scalar load possibly outstanding: {hits[:3]}"
+    assert seen == set(budgets), f"kernels not found in {name}: {set(budgets) - seen}"
