@@ -295,9 +295,7 @@ static void logoframe_sync_results(AmtGpuLogoFrame* lf)
 {
     if (lf->hostValid) return;
     lf->ctx->bind();
-    if (!lf->results.empty())
-        AMT_HIP(hipMemcpyAsync(lf->results.data(), lf->dResults.get(), lf->results.size() * sizeof(float), hipMemcpyDeviceToHost, lf->ctx->stream));
-    AMT_HIP(hipStreamSynchronize(lf->ctx->stream));
+    download_via_pinned(lf->ctx, lf->results.data(), lf->dResults.get(), lf->results.size() * sizeof(float));
     lf->hostValid = true;
 }
 
@@ -525,8 +523,7 @@ int amtgpu_analyze_last_refined(AmtGpuAnalyze* an)
     guard(an->ctx, [&] {
         if (an->mode != AMTGPU_ANALYZE_LINEAR_GUARDED || an->dCount.size() < 1) { n = 0; return; }
         an->ctx->bind();
-        AMT_HIP(hipMemcpyAsync(&n, an->dCount.get(), sizeof(int), hipMemcpyDeviceToHost, an->ctx->stream));
-        AMT_HIP(hipStreamSynchronize(an->ctx->stream));
+        download_via_pinned(an->ctx, &n, an->dCount.get(), sizeof(int));
     });
     return n;
 }
@@ -554,10 +551,10 @@ int amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_s
         if (bits < 8 || bits > 16) throw std::runtime_error("[AMTAnalyzeLogo] Unsupported pixel format");
         const size_t n = (size_t)nframes * AMTGPU_ANALYZE_FLOATS;
         if (an->dTmp.size() < n) an->dTmp.alloc(n);
-        analyze_run(an, dY, frame_stride, pitch, bits, nframes, an->dTmp.get());
+        { AMT_TRACE_SCOPE("analyze_batch_host.launches"); analyze_run(an, dY, frame_stride, pitch, bits, nframes, an->dTmp.get()); }
         an->ctx->bind();
-        if (n) AMT_HIP(hipMemcpyAsync(hout, an->dTmp.get(), n * sizeof(float), hipMemcpyDeviceToHost, an->ctx->stream));
-        AMT_HIP(hipStreamSynchronize(an->ctx->stream));
+        AMT_TRACE_SCOPE("analyze_batch_host.download_via_pinned");
+        download_via_pinned(an->ctx, hout, an->dTmp.get(), n * sizeof(float));
     });
 }
 

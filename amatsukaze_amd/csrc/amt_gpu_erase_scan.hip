@@ -268,8 +268,7 @@ static void logoscan_pull(AmtGpuLogoScan* s)
 {
     if (!s->accDirty) return;
     s->ctx->bind();
-    AMT_HIP(hipMemcpyAsync(s->sums.px.data(), s->dAcc.get(), s->sums.px.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s->ctx->stream));
-    AMT_HIP(hipStreamSynchronize(s->ctx->stream));
+    download_via_pinned(s->ctx, s->sums.px.data(), s->dAcc.get(), s->sums.px.size() * sizeof(int64_t));
     s->accDirty = false;
 }
 
@@ -296,8 +295,7 @@ static int logoscan_add(AmtGpuLogoScan* s, const void* dY, const void* dU, const
                                    S.w, S.h, wUV, hUV, s->thy, nframes, s->dVerdict.get()));
         s->ctx->prof_end(spb);
         v.resize(nframes);
-        AMT_HIP(hipMemcpyAsync(v.data(), s->dVerdict.get(), (size_t)nframes * sizeof(int4), hipMemcpyDeviceToHost, s->ctx->stream));
-        AMT_HIP(hipStreamSynchronize(s->ctx->stream));
+        download_via_pinned(s->ctx, v.data(), s->dVerdict.get(), (size_t)nframes * sizeof(int4));
     }
     std::vector<int4>& acc = s->accHost;
     if (s->accUploaded) AMT_HIP(hipEventSynchronize(s->accUploaded));
@@ -492,8 +490,7 @@ std::unique_ptr<AmtGpuLogo> remake_rounds(AmtGpuContext* c, ShardGuard& sg, AmtG
             std::vector<uint8_t> use(numFrames, 0);
             if (numFrames) {
                 eng.run(dY, strideY, pitchY, bits, numFrames, dEval.get(), dMap.get());
-                AMT_HIP(hipMemcpyAsync(hEval.data(), dEval.get(), hEval.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-                AMT_HIP(hipStreamSynchronize(c->stream));
+                download_via_pinned(c, hEval.data(), dEval.get(), hEval.size() * sizeof(float));
             }
             for (int i = 0; i < numFrames; ++i) {
                 float best = FLT_MAX;

@@ -119,8 +119,7 @@ int amtgpu_framestats_sharded(AmtGpuFrameStats* fs, const AmtGpuCollectives* col
                                            nlocal, fs->dShard.get()));
                 fs->ctx->prof_end(sp);
                 local.resize(n);
-                AMT_HIP(hipMemcpyAsync(local.data(), fs->dShard.get(), n * sizeof(uint64_t), hipMemcpyDeviceToHost, fs->ctx->stream));
-                AMT_HIP(hipStreamSynchronize(fs->ctx->stream));
+                download_via_pinned(fs->ctx, local.data(), fs->dShard.get(), n * sizeof(uint64_t));
             }
         } catch (const std::exception& e) { err = e.what(); }
         gather_frame_metrics(coll, local.data(), first, nlocal, num_frames, metrics_out, err);

@@ -10,6 +10,8 @@
 // uploads from inside a registered range skip the ring altogether.
 #include "../../include/amt_gpu.h"
 
+#include <emmintrin.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -25,13 +27,22 @@ using namespace amt;
 // staging workers: a fixed set of threads that run slices of one job at a time (the caller takes a slice itself)
 // ---------------------------------------------------------------------------------------------
 struct AmtGpuContext::UploadPool {
+    // Jobs arrive in bursts -- one per ring slot of a large upload, a fraction of a millisecond apart -- and last ~0.1 ms each, so a
+    // worker that went to sleep on a condition variable after every job would spend the next one waking up (measured: the calling
+    // thread then does most slices itself and the upload stays at one core's memcpy rate).  Workers therefore keep watching the job
+    // counter for kSpinUs after a job before they block.
+    static constexpr int kSpinUs = 1000;
     std::vector<std::thread> workers;
     std::mutex m;
-    std::condition_variable cv_work, cv_done;
-    const std::function<void(int)>* job = nullptr;      // job(slice)
-    int nslices = 0, next = 0, pending = 0;
-    uint64_t generation = 0;
-    bool stop = false;
+    std::condition_variable cv_work;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<int> sleepers{0};
+    const std::function<void(int)>* job = nullptr;      // job(slice); published by the release store of `claim`
+    // [job number : 24][slices of the job : 20][next slice to hand out : 20] in ONE word, so that a claim is self-describing: a worker
+    // that comes late cannot take a stale index for a slice of the job that has started meanwhile
+    std::atomic<uint64_t> claim{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> stop{false};
 
     explicit UploadPool(int nworkers)
     {
@@ -39,43 +50,59 @@ struct AmtGpuContext::UploadPool {
     }
     ~UploadPool()
     {
-        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        stop.store(true);
+        { std::lock_guard<std::mutex> lk(m); }
         cv_work.notify_all();
         for (auto& t : workers) t.join();
     }
-    void loop()
+    void work()
     {
-        std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            cv_work.wait(lk, [&] { return stop || (job && next < nslices); });
-            if (stop) return;
-            while (job && next < nslices) {
-                const int s = next++;
-                const std::function<void(int)>* j = job;
-                lk.unlock();
-                (*j)(s);
-                lk.lock();
-                if (--pending == 0) cv_done.notify_all();
-            }
+            const uint64_t v = claim.fetch_add(1, std::memory_order_acq_rel);
+            const int s = (int)(v & 0xFFFFF), n = (int)((v >> 20) & 0xFFFFF);
+            if (s >= n) return;
+            (*job)(s);                       // a valid claim keeps its job alive: run() returns only when pending reaches 0
+            pending.fetch_sub(1, std::memory_order_release);
         }
     }
-    // runs fn(0..n-1), the calling thread included; returns when all slices are done
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            // wait for a job newer than `seen`: spin for a while, then block
+            const auto t0 = std::chrono::steady_clock::now();
+            uint64_t g;
+            int polls = 0;
+            while ((g = generation.load(std::memory_order_acquire)) == seen && !stop.load(std::memory_order_relaxed)) {
+                if ((++polls & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) {
+                    std::unique_lock<std::mutex> lk(m);
+                    sleepers.fetch_add(1);
+                    cv_work.wait(lk, [&] { return generation.load(std::memory_order_acquire) != seen || stop.load(); });
+                    sleepers.fetch_sub(1);
+                } else {
+                    __builtin_ia32_pause();
+                }
+            }
+            if (stop.load(std::memory_order_relaxed)) return;
+            seen = g;
+            work();
+        }
+    }
+    // runs fn(0..n-1), the calling thread included; returns when all slices are done.  One job at a time (callers hold the
+    // context's lock).
     void run(int n, const std::function<void(int)>& fn)
     {
         if (n <= 0) return;
-        std::unique_lock<std::mutex> lk(m);
-        job = &fn; nslices = n; next = 0; pending = n;
-        ++generation;
-        cv_work.notify_all();
-        while (next < nslices) {
-            const int s = next++;
-            lk.unlock();
-            fn(s);
-            lk.lock();
-            --pending;
-        }
-        cv_done.wait(lk, [&] { return pending == 0; });
-        job = nullptr;
+        if (n >= (1 << 20) - 4096) throw std::runtime_error("too many slices for one staging job");
+        job = &fn;
+        pending.store(n, std::memory_order_relaxed);
+        const uint64_t g = generation.load(std::memory_order_relaxed) + 1;
+        claim.store(((g & 0xFFFFFF) << 40) | ((uint64_t)n << 20), std::memory_order_release);
+        generation.store(g, std::memory_order_release);
+        if (sleepers.load() > 0) { { std::lock_guard<std::mutex> lk(m); } cv_work.notify_all(); }
+        work();
+        while (pending.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+        // (a worker that wakes late finds no slice left in `claim` and leaves `job` alone: it is only dereferenced for a claimed slice)
     }
 };
 
@@ -120,7 +147,7 @@ void upload_pool_default(AmtGpuContext* c)
     // staging threads: enough to pass PCIe Gen5 x16 with headroom, never more than a quarter of the host's cores.  The pool itself
     // is created on the first large upload.
     const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
-    c->upload_threads = (int)std::max(1u, std::min(8u, hc / 4));
+    c->upload_threads = (int)std::max(1u, std::min(4u, hc / 4));      // measured (profiles/r04_notes.md): 4 threads carry the link, more only contend
 }
 
 void context_stop_threads(AmtGpuContext* c)
@@ -139,7 +166,7 @@ void context_stop_threads(AmtGpuContext* c)
 } // namespace amt
 
 namespace {
-constexpr size_t kSlotBytes = 16u << 20;
+constexpr size_t kSlotBytes = 32u << 20;
 constexpr size_t kParallelMin = 1u << 20;          // staging copies below this stay on the calling thread
 constexpr size_t kSliceBytes = 512u << 10;
 
@@ -155,7 +182,7 @@ uint8_t* stage_acquire(AmtGpuContext* c, size_t n)
     if (c->slot_fill + n > kSlotBytes) {
         AMT_HIP(hipEventRecord(c->slot_free[c->next_slot], c->copy_stream));
         c->next_slot = (c->next_slot + 1) % AmtGpuContext::kRingSlots;
-        AMT_HIP(hipEventSynchronize(c->slot_free[c->next_slot]));
+        { AMT_TRACE_SCOPE("stage_acquire.event_wait"); AMT_HIP(hipEventSynchronize(c->slot_free[c->next_slot])); }
         c->slot_fill = 0;
     }
     uint8_t* p = (uint8_t*)c->pinned + (size_t)c->next_slot * kSlotBytes + c->slot_fill;
@@ -174,15 +201,35 @@ AmtGpuContext::UploadPool* pool_of(AmtGpuContext* c)
     return c->pool;
 }
 
+// The staging copy proper.  The destination is a pinned slot that the CPU never reads again (the DMA engine does): non-temporal
+// stores skip the read-for-ownership of every destination line -- a third of the copy's memory traffic -- and keep the slot out of
+// the caches.  dst is 16-byte aligned for every piece this file hands out whose size is a multiple of 16; anything else (ragged
+// heads and tails, small pieces) goes through memcpy.
+inline void stream_copy(uint8_t* dst, const uint8_t* src, size_t n)
+{
+    if (n < 4096 || ((uintptr_t)dst & 15)) { std::memcpy(dst, src, n); return; }
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 32)), d = _mm_loadu_si128((const __m128i*)(src + i + 48));
+        _mm_stream_si128((__m128i*)(dst + i), a);
+        _mm_stream_si128((__m128i*)(dst + i + 16), b);
+        _mm_stream_si128((__m128i*)(dst + i + 32), c);
+        _mm_stream_si128((__m128i*)(dst + i + 48), d);
+    }
+    _mm_sfence();
+    if (i < n) std::memcpy(dst + i, src + i, n - i);
+}
+
 // dst <- src, n bytes, shared out over the staging threads in kSliceBytes pieces
 void staged_copy(AmtGpuContext* c, uint8_t* dst, const uint8_t* src, size_t n)
 {
     AmtGpuContext::UploadPool* P = n >= kParallelMin ? pool_of(c) : nullptr;
-    if (!P) { std::memcpy(dst, src, n); return; }
+    if (!P) { stream_copy(dst, src, n); return; }
     const int slices = (int)((n + kSliceBytes - 1) / kSliceBytes);
     const std::function<void(int)> fn = [&](int s) {
         const size_t o = (size_t)s * kSliceBytes;
-        std::memcpy(dst + o, src + o, std::min(kSliceBytes, n - o));
+        stream_copy(dst + o, src + o, std::min(kSliceBytes, n - o));
     };
     P->run(slices, fn);
 }
@@ -219,6 +266,33 @@ void copies_issued(AmtGpuContext* c)
     c->copies_pending = true;
 }
 } // namespace
+
+namespace {
+void land_pinned(AmtGpuContext* c, const void* dsrc, uint64_t bytes);
+}
+namespace amt {
+void download_via_pinned(AmtGpuContext* c, void* hdst, const void* dsrc, size_t bytes)
+{
+    if (!bytes) { AMT_HIP(hipStreamSynchronize(c->stream)); return; }
+    land_pinned(c, dsrc, bytes);
+    std::memcpy(hdst, c->pinned_down, bytes);
+}
+} // namespace amt
+namespace {
+void land_pinned(AmtGpuContext* c, const void* dsrc, uint64_t bytes)
+{
+    if (bytes > c->pinned_down_bytes) {
+        if (c->pinned_down) { (void)hipHostFree(c->pinned_down); c->pinned_down = nullptr; c->pinned_down_bytes = 0; }
+        AMT_HIP(hipHostMalloc(&c->pinned_down, (size_t)bytes, hipHostMallocDefault));
+        c->pinned_down_bytes = (size_t)bytes;
+    }
+    if (bytes) {
+        AMT_HIP(hipMemcpyAsync(c->pinned_down, dsrc, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+        AMT_HIP(hipStreamSynchronize(c->stream));
+    }
+}
+} // namespace
+
 
 extern "C" {
 
@@ -337,10 +411,14 @@ int amtgpu_frames_upload_gather(AmtGpuContext* c, void* ddst, int64_t dst_stride
         for (int64_t i0 = 0; i0 < total; i0 += per_slot) {
             const int64_t n = std::min(per_slot, total - i0);
             uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
-            staged_gather(c, stage, (size_t)chunk_bytes, n, [&](int64_t i) {
-                const int64_t q = i0 + i;
-                return (const uint8_t*)hsrc[q / chunks_per_src] + (size_t)(q % chunks_per_src) * src_stride;
-            });
+            {
+                AMT_TRACE_SCOPE("upload_gather.staging_copy");
+                staged_gather(c, stage, (size_t)chunk_bytes, n, [&](int64_t i) {
+                    const int64_t q = i0 + i;
+                    return (const uint8_t*)hsrc[q / chunks_per_src] + (size_t)(q % chunks_per_src) * src_stride;
+                });
+            }
+            AMT_TRACE_SCOPE("upload_gather.memcpy2d_async");
             AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
                                      hipMemcpyHostToDevice, c->copy_stream));
         }
@@ -360,8 +438,7 @@ int amtgpu_download(AmtGpuContext* c, void* hdst, const void* dsrc, uint64_t byt
 {
     return guard(c, [&] {
         c->bind();
-        AMT_HIP(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
-        AMT_HIP(hipStreamSynchronize(c->stream));
+        download_via_pinned(c, hdst, dsrc, (size_t)bytes);
     });
 }
 
@@ -372,26 +449,20 @@ int amtgpu_download_strided(AmtGpuContext* c, void* hdst, int64_t dst_stride, co
         c->bind();
         if (chunk_bytes == 0 || nchunks <= 0) return;
         if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
-        AMT_HIP(hipMemcpy2DAsync(hdst, (size_t)dst_stride, dsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyDeviceToHost,
+        // packed into the pinned landing buffer by one 2-D copy, handed out to the (pageable) rows from there
+        const size_t total = (size_t)chunk_bytes * (size_t)nchunks;
+        if (total > c->pinned_down_bytes) {
+            if (c->pinned_down) { (void)hipHostFree(c->pinned_down); c->pinned_down = nullptr; c->pinned_down_bytes = 0; }
+            AMT_HIP(hipHostMalloc(&c->pinned_down, total, hipHostMallocDefault));
+            c->pinned_down_bytes = total;
+        }
+        AMT_HIP(hipMemcpy2DAsync(c->pinned_down, (size_t)chunk_bytes, dsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyDeviceToHost,
                                  c->stream));
         AMT_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < nchunks; ++i)
+            std::memcpy((uint8_t*)hdst + (size_t)i * dst_stride, (const uint8_t*)c->pinned_down + (size_t)i * chunk_bytes, (size_t)chunk_bytes);
     });
 }
-
-namespace {
-void land_pinned(AmtGpuContext* c, const void* dsrc, uint64_t bytes)
-{
-    if (bytes > c->pinned_down_bytes) {
-        if (c->pinned_down) { (void)hipHostFree(c->pinned_down); c->pinned_down = nullptr; c->pinned_down_bytes = 0; }
-        AMT_HIP(hipHostMalloc(&c->pinned_down, (size_t)bytes, hipHostMallocDefault));
-        c->pinned_down_bytes = (size_t)bytes;
-    }
-    if (bytes) {
-        AMT_HIP(hipMemcpyAsync(c->pinned_down, dsrc, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
-        AMT_HIP(hipStreamSynchronize(c->stream));
-    }
-}
-} // namespace
 
 // device -> a pinned landing buffer of the context in ONE asynchronous copy + one wait; *hptr stays valid until the next call ON THIS
 // CONTEXT from any thread -- a context shared by several host threads must use amtgpu_download_scatter instead

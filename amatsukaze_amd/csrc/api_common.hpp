@@ -47,8 +47,10 @@ inline std::string amt_utf8_from_utf16z(const uint16_t* s)
 }
 
 // run f(); on any exception keep the message on the context and return 0 (no exceptions cross the ABI)
-template <typename F> inline int guard(AmtGpuContext* c, F&& f)
+template <typename F> inline int guard(AmtGpuContext* c, F&& f, const char* caller = __builtin_FUNCTION())
 {
+    AMT_TRACE_SCOPE(caller);
+    (void)caller;
     // calls on one context are serialised: its stream, staging ring, error string and timing spans are shared state
     std::unique_lock<std::recursive_mutex> lk;
     if (c) lk = std::unique_lock<std::recursive_mutex>(c->mu);

@@ -21,6 +21,32 @@
             throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+// Instrumented builds only (-DAMT_TRACE_CALLS, build.py build_variant): host-side begin / duration of every C ABI call and of the
+// waits inside them, written to stderr at exit as "amt_trace <name> <begin_us> <dur_us>" (tools/boundary_calls.py).
+#ifdef AMT_TRACE_CALLS
+#include <chrono>
+#include <cstdio>
+#include <vector>
+struct AmtTrace {
+    struct Rec { const char* name; double t0, dur; };
+    std::vector<Rec> recs;
+    std::mutex m;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    ~AmtTrace() { for (const Rec& r : recs) std::fprintf(stderr, "amt_trace %s %.1f %.1f\n", r.name, r.t0 - (recs.empty() ? 0 : recs[0].t0), r.dur); }
+    static AmtTrace& get() { static AmtTrace t; return t; }
+};
+struct AmtTraceScope {
+    const char* name; double t0;
+    explicit AmtTraceScope(const char* n) : name(n), t0(AmtTrace::now()) {}
+    ~AmtTraceScope() { AmtTrace& t = AmtTrace::get(); std::lock_guard<std::mutex> lk(t.m); t.recs.push_back({name, t0, AmtTrace::now() - t0}); }
+};
+#define AMT_TRACE_CAT2(a, b) a##b
+#define AMT_TRACE_CAT(a, b) AMT_TRACE_CAT2(a, b)
+#define AMT_TRACE_SCOPE(n) AmtTraceScope AMT_TRACE_CAT(amt_trace_scope_, __LINE__)(n)
+#else
+#define AMT_TRACE_SCOPE(n) do { } while (0)
+#endif
+
 struct AmtGpuContext {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream (own or borrowed)
@@ -73,6 +99,10 @@ struct AmtGpuContext {
 namespace amt {
 void upload_pool_default(AmtGpuContext* c);
 void context_stop_threads(AmtGpuContext* c);
+// `bytes` from the device to ANY host memory, synchronously, on the context's stream: lands in the context's pinned buffer and is
+// copied out from there.  Device-to-host copies never get a pageable destination: hipMemcpyAsync into unpinned memory waits for the
+// stream inside the runtime, and on some hosts that wait is served at a 10 ms tick (profiles/r04_notes.md, "Boundary").
+void download_via_pinned(AmtGpuContext* c, void* hdst, const void* dsrc, size_t bytes);
 
 template <typename T> class DevBuf {
     T* p_ = nullptr;
@@ -87,7 +117,14 @@ public:
     ~DevBuf() { release(); }
     void alloc(size_t n) { release(); if (n) { AMT_HIP(hipMalloc((void**)&p_, n * sizeof(T))); n_ = n; } }
     void release() { if (p_) { (void)hipFree(p_); p_ = nullptr; n_ = 0; } }
-    void upload(const T* h, size_t n, hipStream_t st) { if (n > n_) alloc(n); if (n) { AMT_HIP(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, st)); AMT_HIP(hipStreamSynchronize(st)); } }
+    void upload(const T* h, size_t n, hipStream_t st)
+    {
+        if (n > n_) alloc(n);
+        if (n) {
+            { AMT_TRACE_SCOPE("devbuf.upload.memcpy_h2d_pageable"); AMT_HIP(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, st)); }
+            { AMT_TRACE_SCOPE("devbuf.upload.sync"); AMT_HIP(hipStreamSynchronize(st)); }
+        }
+    }
     void upload(const std::vector<T>& h, hipStream_t st) { upload(h.data(), h.size(), st); }
     T* get() const { return p_; }
     size_t size() const { return n_; }

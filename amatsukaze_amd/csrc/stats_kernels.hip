@@ -18,9 +18,23 @@
 
 namespace amt {
 
-constexpr int kStatThreads = 128;
-constexpr int kStatTileRows = 16;
-constexpr int kStatRun = 32;          // frames a workgroup walks through (the frame before a run is its one re-read: 1/32)
+#ifndef AMT_STATS_VG
+#define AMT_STATS_VG 4
+#endif
+// Waves of a workgroup that sit on top of one another: wave w of a workgroup owns tile (4 * supertile + w) of the SAME 16-byte columns, so
+// the two halo rows a tile re-reads are rows that a sibling wave of the same workgroup -- same CU, same moment -- reads as its own: the
+// second request merges with the first in the CU's vector cache / the XCD's L2 instead of going to HBM again (kStatVG = 1: round 3's
+// mapping, every wave an unrelated (tile, column) range; measured traffic 1.146x the algorithmic bytes)
+constexpr int kStatVG = AMT_STATS_VG;
+constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
+#ifndef AMT_STATS_ROWS
+#define AMT_STATS_ROWS 16
+#endif
+#ifndef AMT_STATS_RUN
+#define AMT_STATS_RUN 32
+#endif
+constexpr int kStatTileRows = AMT_STATS_ROWS;
+constexpr int kStatRun = AMT_STATS_RUN;          // frames a workgroup walks through (the frame before a run is its one re-read: 1/32)
 constexpr int kStatXcds = 8;          // MI355X: 8 XCDs, workgroups are dealt to them round-robin by linear workgroup id
 constexpr int kStatWords = 8;
 
@@ -38,24 +52,47 @@ template <> struct Px<2> {
     }
 };
 
-__device__ __forceinline__ uint4 load_chunk(const uint8_t* p, int nvalid)
+#ifndef AMT_STATS_COLB
+#define AMT_STATS_COLB 16
+#endif
+constexpr int kStatColBytes = AMT_STATS_COLB;      // bytes of a row one lane owns: 16 (one dwordx4 load) or 8 (dwordx2: half the registers per row)
+constexpr int kStatColWords = kStatColBytes / 4;
+struct alignas(kStatColBytes) Chunk { unsigned w[kStatColWords]; };
+
+__device__ __forceinline__ Chunk chunk_zero()
 {
-    if (nvalid >= 16) return *reinterpret_cast<const uint4*>(p);
-    uint32_t w[4] = {0, 0, 0, 0};
+    Chunk c;
+#pragma unroll
+    for (int i = 0; i < kStatColWords; ++i) c.w[i] = 0;
+    return c;
+}
+__device__ __forceinline__ Chunk load_chunk(const uint8_t* p, int nvalid)
+{
+    if (nvalid >= kStatColBytes) return *reinterpret_cast<const Chunk*>(p);
+    // (the ragged last column: byte by byte into a scratch array that never escapes -- a dynamically indexed member of the Chunk that
+    // is returned would keep every row set out of registers: the compiler then parks them in LDS, measured 2x slower)
+    uint32_t w[kStatColWords];
+#pragma unroll
+    for (int i = 0; i < kStatColWords; ++i) w[i] = 0;
     for (int i = 0; i < nvalid; ++i) w[i >> 2] |= (uint32_t)p[i] << ((i & 3) * 8);
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    Chunk c;
+#pragma unroll
+    for (int i = 0; i < kStatColWords; ++i) c.w[i] = w[i];
+    return c;
 }
 
-template <int ES> __device__ __forceinline__ unsigned sad16(const uint4& a, const uint4& b, unsigned acc)
+template <int ES> __device__ __forceinline__ unsigned sad16(const Chunk& a, const Chunk& b, unsigned acc)
 {
-    acc = Px<ES>::sad(a.x, b.x, acc);
-    acc = Px<ES>::sad(a.y, b.y, acc);
-    acc = Px<ES>::sad(a.z, b.z, acc);
-    return Px<ES>::sad(a.w, b.w, acc);
+#pragma unroll
+    for (int i = 0; i < kStatColWords; ++i) acc = Px<ES>::sad(a.w[i], b.w[i], acc);
+    return acc;
 }
-template <int ES> __device__ __forceinline__ uint4 avg16(const uint4& a, const uint4& c)
+template <int ES> __device__ __forceinline__ Chunk avg16(const Chunk& a, const Chunk& c)
 {
-    return make_uint4(Px<ES>::avg(a.x, c.x), Px<ES>::avg(a.y, c.y), Px<ES>::avg(a.z, c.z), Px<ES>::avg(a.w, c.w));
+    Chunk r;
+#pragma unroll
+    for (int i = 0; i < kStatColWords; ++i) r.w[i] = Px<ES>::avg(a.w[i], c.w[i]);
+    return r;
 }
 
 template <int ES>
@@ -74,24 +111,33 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     // (each XCD has a private L2; adjacent blockIdx.x would put every halo on a different one).
     const int per = gridDim.x / kStatXcds;
     const int wg = (blockIdx.x % kStatXcds) * per + blockIdx.x / kStatXcds;
-    const int gid = wg * kStatThreads + threadIdx.x;
-    const int tile = gid / cols;
+    int tile, xb;
+    if (kStatVG > 1) {
+        // (supertile, column) pairs are dealt densely to the 64 lanes of a workgroup's waves; wave w takes tile kStatVG * supertile + w
+        const int gid = wg * 64 + (threadIdx.x & 63);
+        const int st = gid / cols;
+        tile = st * kStatVG + (threadIdx.x >> 6);
+        xb = (gid - st * cols) * kStatColBytes;
+    } else {
+        const int gid = wg * kStatThreads + threadIdx.x;
+        tile = gid / cols;
+        xb = (gid - tile * cols) * kStatColBytes;                 // byte column of this thread
+    }
     const int y0 = tile * kStatTileRows;
-    const int xb = (gid - tile * cols) * 16;                      // byte column of this thread
-    const int nvalid = y0 < H ? min(16, row_bytes - xb) : 0;      // <= 0: thread has no pixels
+    const int nvalid = y0 < H ? min(kStatColBytes, row_bytes - xb) : 0;      // <= 0: thread has no pixels
     const int n0 = blockIdx.y * kStatRun;
     const int n1 = min(nframes, n0 + kStatRun);
 
-    auto load_rows = [&](const uint8_t* frame, uint4* rows) {
+    auto load_rows = [&](const uint8_t* frame, Chunk* rows) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int y = y0 - 1 + r;
             rows[r] = (nvalid > 0 && y >= 0 && y < H) ? load_chunk(frame + (long long)y * pitch_bytes + xb, nvalid)
-                                                     : make_uint4(0, 0, 0, 0);
+                                                     : chunk_zero();
         }
     };
 
-    uint4 prev[R], cur[R];
+    Chunk prev[R], cur[R];
     {
         const uint8_t* p = n0 > 0 ? Y + (long long)(n0 - 1) * frame_stride : (prevY ? prevY : Y);
         load_rows(p, prev);
@@ -99,7 +145,7 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     for (int n = n0; n < n1; ++n) {
         load_rows(Y + (long long)n * frame_stride, cur);
         unsigned acc[7] = {0, 0, 0, 0, 0, 0, 0};
-        const uint4 zero = make_uint4(0, 0, 0, 0);
+        const Chunk zero = chunk_zero();
 #pragma unroll
         for (int r = 1; r <= kStatTileRows; ++r) {
             const int y = y0 - 1 + r;                  // rows >= H were loaded as zeros and add nothing
@@ -107,14 +153,14 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
             acc[odd ? 1 : 0] = sad16<ES>(cur[r], prev[r], acc[odd ? 1 : 0]);
             acc[5] = sad16<ES>(cur[r], zero, acc[5]);
             if (y >= 1 && y <= H - 2) {
-                const uint4 mc = avg16<ES>(cur[r - 1], cur[r + 1]);
+                const Chunk mc = avg16<ES>(cur[r - 1], cur[r + 1]);
                 acc[2] = sad16<ES>(cur[r - 1], cur[r + 1], acc[2]);
                 acc[3] = sad16<ES>(cur[r], mc, acc[3]);
                 if (odd) {        // weave: this row comes from prev, its neighbours from cur
                     acc[4] = sad16<ES>(prev[r], mc, acc[4]);
                     acc[6] = sad16<ES>(cur[r - 1], cur[r + 1], acc[6]);
                 } else {          // this row from cur, neighbours from prev
-                    const uint4 mp = avg16<ES>(prev[r - 1], prev[r + 1]);
+                    const Chunk mp = avg16<ES>(prev[r - 1], prev[r + 1]);
                     acc[4] = sad16<ES>(cur[r], mp, acc[4]);
                     acc[6] = sad16<ES>(prev[r - 1], prev[r + 1], acc[6]);
                 }
@@ -144,11 +190,11 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     if (nframes <= 0) return hipSuccess;
     const int es = bits <= 8 ? 1 : 2;
     const int row_bytes = W * es;
-    const int col_groups = (row_bytes + 15) / 16;                 // 16-byte columns per row
+    const int col_groups = (row_bytes + kStatColBytes - 1) / kStatColBytes;     // lane columns per row
     const int tiles = (H + kStatTileRows - 1) / kStatTileRows;
     hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
-    const int wgs = (tiles * col_groups + kStatThreads - 1) / kStatThreads;
+    const int wgs = kStatVG > 1 ? ((tiles + kStatVG - 1) / kStatVG * col_groups + 63) / 64 : (tiles * col_groups + kStatThreads - 1) / kStatThreads;
     dim3 grid((unsigned)((wgs + kStatXcds - 1) / kStatXcds * kStatXcds), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
         block(kStatThreads);                                      // surplus workgroups of the round-up find nvalid <= 0
     if (es == 1)

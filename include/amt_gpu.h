@@ -84,8 +84,8 @@ int   amtgpu_frames_upload_strided(AmtGpuContext* ctx, void* ddst, int64_t dst_s
 int   amtgpu_frames_upload_gather(AmtGpuContext* ctx, void* ddst, int64_t dst_stride, const void* const* hsrc, int64_t src_stride,
                                   uint64_t chunk_bytes, int chunks_per_src, int nsrc);
 int   amtgpu_frames_upload_wait(AmtGpuContext* ctx);   /* make the compute stream wait for pending uploads */
-/* Uploads from pageable host memory are staged through a ring of four pinned 16 MiB slots; the staging memcpy of a large upload is
- * shared out over `nthreads` threads (the caller's included; default min(8, cores / 4)) because one core's memcpy is below what
+/* Uploads from pageable host memory are staged through a ring of four pinned 32 MiB slots; the staging copy of a large upload is
+ * shared out over `nthreads` threads (the caller's included; default min(4, cores / 4)) because one core's memcpy is below what
  * PCIe Gen5 x16 carries.  1 = the calling thread alone. */
 int   amtgpu_context_set_upload_threads(AmtGpuContext* ctx, int nthreads);
 /* Page-lock a host range in place (hipHostRegister) -- a decoder's frame pool, the buffers AMTSource keeps its frames in

@@ -167,6 +167,9 @@ def test_kernel_isa_properties(name):
                 assert m["vgpr_count"] + m["agpr_count"] <= budgets[sub], f"{kname}: {m['vgpr_count']} VGPRs (+{m['agpr_count']} AGPRs) > {budgets[sub]}"
                 seen.add(sub)
                 break
+        if name == "stats_kernels.hip":
+            # the row sets must live in registers: a dynamically indexed member once made the compiler park them in LDS (2x slower)
+            assert not any(re.match(r"^\s*ds_(read|write)", l) for l in k["body"]), f"{kname}: LDS traffic in the frame metrics"
         hits, nblocks = partial_waits_with_smem_outstanding(k["body"])
         assert nblocks > 0
         assert not hits, f"{kname}: partial lgkmcnt wait with a scalar load possibly outstanding: {hits[:3]}"

@@ -15,6 +15,7 @@ for i in range(3):
 del ctx
 subprocess.check_call(["make", "-C", "tests/cpp", "filters_host_test"], stdout=subprocess.DEVNULL)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
+only = set(sys.argv[2:])
 VARIANTS = [("baseline", {}), ("baseline_again", {}), ("swap_order", {"AMT_BENCH_SWAP": "1"}),
             ("keepalive_1000_0", {"AMT_KEEPALIVE": "1000,0"}), ("keepalive_200_0", {"AMT_KEEPALIVE": "200,0"}),
             ("keepalive_1000_1000", {"AMT_KEEPALIVE": "1000,1000"}), ("keepalive_5000_5000", {"AMT_KEEPALIVE": "5000,5000"}),
@@ -23,6 +24,8 @@ VARIANTS = [("baseline", {}), ("baseline_again", {}), ("swap_order", {"AMT_BENCH
             ("no_interrupt", {"HSA_ENABLE_INTERRUPT": "0"})]
 out = {}
 for name, env in VARIANTS:
+    if only and name not in only:
+        continue
     e = dict(os.environ); e.update(env)
     r = subprocess.run(["tests/cpp/filters_host_test", "--bench", "1440", "1080", str(n)] + paths + ["0"], capture_output=True, text=True, env=e, timeout=300)
     try:

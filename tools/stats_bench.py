@@ -1,0 +1,57 @@
+"""frame_stats_kernel variants (amatsukaze_amd/build.py build_variant: -DAMT_STATS_VG / _ROWS / _RUN) on the bench's shapes: time per
+10 000-frame launch and equality of every record with the default build's.  Build where hipcc is (`--build`), run on the GPU box:
+    python tools/stats_bench.py > gpurun_out/stats_bench.json"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+VARIANTS = {"vg1_r16": ["AMT_STATS_VG=1"], "vg4_r16": ["AMT_STATS_VG=4"], "vg8_r8": ["AMT_STATS_VG=8", "AMT_STATS_ROWS=8"],
+            "vg4_r8": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=8"], "vg4_r16_run64": ["AMT_STATS_VG=4", "AMT_STATS_RUN=64"],
+            "vg2_r16": ["AMT_STATS_VG=2"], "vg4_r32x8B": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"], "vg4_r16x8B": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=16", "AMT_STATS_COLB=8"],
+            "vg2_r16x8B": ["AMT_STATS_VG=2", "AMT_STATS_ROWS=16", "AMT_STATS_COLB=8"]}
+if "--build" in sys.argv:
+    from amatsukaze_amd import build as B
+    for name, defs in VARIANTS.items():
+        if os.path.exists(os.path.join(ROOT, "amatsukaze_amd", f"libamt_gpu_stats_{name}.so")) and "--force" not in sys.argv:
+            continue
+        print(name, B.build_variant("stats_" + name, defs))
+    sys.exit(0)
+if "--child" in sys.argv:
+    import hashlib, time
+    import torch
+    import amt_synth as S
+    from amatsukaze_amd import Context, FrameStats
+    ctx = Context(0)
+    dev = torch.device("cuda:0")
+    out = {}
+    for tag, (W, H, bits, pitch, N) in {"1440x1080_8bit": (1440, 1080, 8, 1472, 10000), "1920x1080_10bit": (1920, 1080, 10, 1920, 3000)}.items():
+        Y = S.make_clip_torch(N, W, H, 0x5EED0002, None, None, 0, 0, dev, bits=bits, pitchY=pitch, chroma=False)["Y"]
+        fs = FrameStats(ctx, W, H, bits)
+        o = torch.zeros((N, 8), dtype=torch.int64, device=dev)
+        fs.run_device(Y, o)
+        torch.cuda.synchronize()
+        ctx.profile(True)
+        for _ in range(8):
+            fs.run_device(Y, o)
+        torch.cuda.synchronize()
+        c, ms = ctx.profile_report()["frame_stats_kernel"]
+        ctx.profile(False)
+        es = 1 if bits <= 8 else 2
+        out[tag] = {"ms": ms / c, "alg_TBs": W * H * es * N / (ms / c * 1e-3) / 1e12, "sha": hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest()[:16]}
+        del Y
+    print(json.dumps(out))
+    sys.exit(0)
+res = {}
+for name in ["default"] + list(VARIANTS):
+    env = dict(os.environ)
+    if name != "default":
+        so = os.path.join(ROOT, "amatsukaze_amd", f"libamt_gpu_stats_{name}.so")
+        if not os.path.exists(so):
+            continue
+        env["AMTGPU_LIB"] = so
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=600)
+    try:
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        res[name] = {"error": (r.stderr or r.stdout)[-300:]}
+    print(name, json.dumps(res[name]), file=sys.stderr, flush=True)
+print(json.dumps(res))
