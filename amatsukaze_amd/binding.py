@@ -55,7 +55,6 @@ SIGNATURES = {
     "amtgpu_marker_destroy": (None, [c_p, c_p]),
     "amtgpu_marker_record_on": (c_i, [c_p, c_p]),
     "amtgpu_marker_wait_on": (c_i, [c_p, c_p]),
-    "amtgpu_context_set_keepalive": (c_i, [c_p, c_i, c_i]),
     "amtgpu_marker_record": (c_i, [c_p, c_i]),
     "amtgpu_marker_wait": (c_i, [c_p, c_i]),
     "amtgpu_logo_loadW": (c_p, [c_p, c_p]),

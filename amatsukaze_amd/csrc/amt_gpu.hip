@@ -3,6 +3,7 @@
 #include "../../include/amt_gpu.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -10,6 +11,9 @@
 #include "api_common.hpp"
 
 using namespace amt;
+#ifdef AMT_TRACE_CALLS
+namespace amt { void trace_stamp(AmtGpuContext* c, hipStream_t st, int slot); }
+#endif
 
 extern "C" {
 
@@ -32,6 +36,12 @@ AmtGpuContext* amtgpu_context_create(int device)
         for (auto& e : c->slot_free) AMT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         amt::upload_pool_default(c);
         c->stream = c->own_stream;
+#ifdef AMT_TRACE_CALLS
+        if (std::getenv("AMT_SAME_STREAM")) {                 // instrumented builds: uploads on the compute stream (no cross-stream wait)
+            (void)hipStreamDestroy(c->copy_stream);
+            c->copy_stream = c->own_stream;
+        }
+#endif
     } catch (const std::exception&) {
         amtgpu_context_destroy(c);
         return nullptr;
@@ -52,7 +62,7 @@ void amtgpu_context_destroy(AmtGpuContext* c)
     for (auto& e : c->markers) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->slot_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream && c->copy_stream != c->own_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -551,10 +561,48 @@ int amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_s
         if (bits < 8 || bits > 16) throw std::runtime_error("[AMTAnalyzeLogo] Unsupported pixel format");
         const size_t n = (size_t)nframes * AMTGPU_ANALYZE_FLOATS;
         if (an->dTmp.size() < n) an->dTmp.alloc(n);
+#ifdef AMT_TRACE_CALLS
+        static const bool no_kernel = std::getenv("AMT_TRACE_NO_ANALYSIS_KERNEL") != nullptr;
+        if (!no_kernel)
+#endif
         { AMT_TRACE_SCOPE("analyze_batch_host.launches"); analyze_run(an, dY, frame_stride, pitch, bits, nframes, an->dTmp.get()); }
         an->ctx->bind();
-        AMT_TRACE_SCOPE("analyze_batch_host.download_via_pinned");
-        download_via_pinned(an->ctx, hout, an->dTmp.get(), n * sizeof(float));
+#ifdef AMT_TRACE_CALLS
+        AmtGpuContext* c = an->ctx;
+        if (!c->tr_kernels) { AMT_HIP(hipEventCreate(&c->tr_kernels)); AMT_HIP(hipEventCreate(&c->tr_landed)); }
+        AMT_HIP(hipEventRecord(c->tr_kernels, c->stream));
+        const double h_launched = AmtTrace::now();
+        if (c->tr_block_open) amt::trace_stamp(c, c->stream, 3);
+#endif
+        {
+            AMT_TRACE_SCOPE("analyze_batch_host.download_via_pinned");
+            download_via_pinned(an->ctx, hout, an->dTmp.get(), n * sizeof(float));
+        }
+#ifdef AMT_TRACE_CALLS
+        AMT_HIP(hipEventRecord(c->tr_landed, c->stream));
+        AMT_HIP(hipEventSynchronize(c->tr_landed));
+        if (c->tr_block_open && c->tr_first_copy && c->tr_copies_done && c->tr_released) {
+            float a = 0, b = 0, k = 0;
+            (void)hipEventElapsedTime(&a, c->tr_first_copy, c->tr_copies_done);
+            (void)hipEventElapsedTime(&b, c->tr_copies_done, c->tr_released);
+            (void)hipEventElapsedTime(&k, c->tr_released, c->tr_kernels);
+            AmtTrace& t = AmtTrace::get();
+            std::lock_guard<std::mutex> lk(t.m);
+            const double now = AmtTrace::now();
+            t.recs.push_back({"gpu.first_copy_to_copies_done", now, a * 1e3});
+            t.recs.push_back({"gpu.copies_done_to_wait_released", now, b * 1e3});
+            t.recs.push_back({"gpu.wait_released_to_kernels_done", now, k * 1e3});
+            // the block on ONE clock (us after the host began the block): device stamps mapped onto the host's clock
+            auto g = [&](int i) { return (double)c->tr_stamps[i] / 100.0 + c->tr_offset_us - c->tr_host_block_begin; };
+            t.recs.push_back({"blk.1_gpu_copy_stream_reached_block", now, g(0)});
+            t.recs.push_back({"blk.2_gpu_copies_done", now, g(1)});
+            t.recs.push_back({"blk.3_gpu_compute_wait_released", now, g(2)});
+            t.recs.push_back({"blk.4_host_all_enqueued", now, h_launched - c->tr_host_block_begin});
+            t.recs.push_back({"blk.5_gpu_kernels_done", now, g(3)});
+            t.recs.push_back({"blk.6_host_woke_up", now, now - c->tr_host_block_begin});
+        }
+        c->tr_block_open = false;
+#endif
     });
 }
 

@@ -19,6 +19,8 @@ struct EraseGeom {
 };
 hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
                          int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades, int zero_identity);
+hipError_t launch_ingest_rows(hipStream_t st, const void* src, long long src_stride, void* dst, long long dst_stride, unsigned long long chunk,
+                              long long nchunks);
 hipError_t launch_calc_fades(hipStream_t st, const float* danalysis, int analysis_first, int analysis_count, int num_frames, int first,
                              int nframes, const uint8_t* dstate, int half, float2* dout);
 hipError_t launch_scan_border(hipStream_t st, int bits, const void* dY, const void* dU, const void* dV, long long strideY,
@@ -652,12 +654,12 @@ int amtgpu_scanlogo_file(AmtGpuContext* c, const char* srcpath, int serviceid, c
                          nullptr, nullptr);
             for (int i = 0; i < n; ++i) {
                 if (!valid[i]) continue;
-                AMT_HIP(hipMemcpy2DAsync(cropY.get() + (size_t)nkept * w * h, w, dY + ysz * i + (size_t)imgy * W + imgx, W, w, h,
-                                         hipMemcpyDeviceToDevice, c->stream));
-                AMT_HIP(hipMemcpy2DAsync(cropU.get() + (size_t)nkept * wUV * hUV, wUV, dU + csz * i + (size_t)(imgy / 2) * (W / 2) + imgx / 2, W / 2,
-                                         wUV, hUV, hipMemcpyDeviceToDevice, c->stream));
-                AMT_HIP(hipMemcpy2DAsync(cropV.get() + (size_t)nkept * wUV * hUV, wUV, dV + csz * i + (size_t)(imgy / 2) * (W / 2) + imgx / 2, W / 2,
-                                         wUV, hUV, hipMemcpyDeviceToDevice, c->stream));
+                // (the library's own row kernel, not the runtime's 2-D copy: amt_gpu_upload.hip)
+                AMT_HIP(launch_ingest_rows(c->stream, dY + ysz * i + (size_t)imgy * W + imgx, W, cropY.get() + (size_t)nkept * w * h, w, (unsigned long long)w, h));
+                AMT_HIP(launch_ingest_rows(c->stream, dU + csz * i + (size_t)(imgy / 2) * (W / 2) + imgx / 2, W / 2, cropU.get() + (size_t)nkept * wUV * hUV, wUV,
+                                           (unsigned long long)wUV, hUV));
+                AMT_HIP(launch_ingest_rows(c->stream, dV + csz * i + (size_t)(imgy / 2) * (W / 2) + imgx / 2, W / 2, cropV.get() + (size_t)nkept * wUV * hUV, wUV,
+                                           (unsigned long long)wUV, hUV));
                 keptVerdict.push_back(scan->lastVerdicts[i]);
                 ++nkept;
             }

@@ -1,6 +1,6 @@
 // amt_gpu_upload.hip -- C ABI part 5: frames between host and HBM (the step AMTSource::GetFrame feeds, AMTSource.hpp:721-780,
 // 428-442): device allocation, the pinned staging ring with its worker threads, registered (page-locked in place) host frames,
-// downloads, stream markers, and the optional queue keep-alive.
+// downloads, stream markers.
 //
 // Ingest path.  A decoder's frames normally sit in pageable memory, which the DMA engines cannot read: they are staged through
 // a ring of pinned slots on the way -- host memcpy into a slot, hipMemcpyAsync out of it on the side stream.  One core's memcpy
@@ -15,12 +15,17 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
 
 #include "api_common.hpp"
 
+namespace amt {
+hipError_t launch_ingest_rows(hipStream_t st, const void* src_host_mapped, long long src_stride, void* dst, long long dst_stride,
+                              unsigned long long chunk, long long nchunks);
+}
 using namespace amt;
 
 // ---------------------------------------------------------------------------------------------
@@ -106,40 +111,6 @@ struct AmtGpuContext::UploadPool {
     }
 };
 
-// ---------------------------------------------------------------------------------------------
-// keep-alive: see amtgpu_context_set_keepalive in amt_gpu.h
-// ---------------------------------------------------------------------------------------------
-namespace {
-__global__ void keepalive_kernel(long long spin_ticks)
-{
-    // wall_clock64: the constant 100 MHz counter.  spin_ticks == 0: an empty launch
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(64);
-}
-} // namespace
-
-struct AmtGpuContext::KeepAlive {
-    std::thread th;
-    std::atomic<bool> stop{false};
-    hipStream_t stream = nullptr;
-    int device = 0, period_us = 0, spin_us = 0;
-    std::atomic<long long> beats{0};
-
-    void loop()
-    {
-        if (hipSetDevice(device) != hipSuccess) return;
-        while (!stop.load(std::memory_order_relaxed)) {
-            // never let launches pile up: a beat is skipped while the previous one has not finished
-            if (hipStreamQuery(stream) == hipSuccess) {
-                hipLaunchKernelGGL(keepalive_kernel, dim3(1), dim3(64), 0, stream, (long long)spin_us * 100);
-                beats.fetch_add(1, std::memory_order_relaxed);
-            }
-            std::this_thread::sleep_for(std::chrono::microseconds(period_us));
-        }
-        (void)hipStreamSynchronize(stream);
-    }
-};
-
 namespace amt {
 
 void upload_pool_default(AmtGpuContext* c)
@@ -152,18 +123,35 @@ void upload_pool_default(AmtGpuContext* c)
 
 void context_stop_threads(AmtGpuContext* c)
 {
-    if (c->keepalive) {
-        c->keepalive->stop.store(true);
-        if (c->keepalive->th.joinable()) c->keepalive->th.join();
-        if (c->keepalive->stream) (void)hipStreamDestroy(c->keepalive->stream);
-        delete c->keepalive;
-        c->keepalive = nullptr;
-    }
     delete c->pool;
     c->pool = nullptr;
 }
 
 } // namespace amt
+
+#ifdef AMT_TRACE_CALLS
+__global__ void trace_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+namespace amt {
+void trace_stamp(AmtGpuContext* c, hipStream_t st, int slot)
+{
+    if (!c->tr_stamps) {
+        AMT_HIP(hipHostMalloc((void**)&c->tr_stamps, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+        for (int i = 0; i < 8; ++i) c->tr_stamps[i] = 0;
+        // calibration: the stamp of a kernel that is known to run between two host clock readings (best of 20)
+        double best = 1e30;
+        for (int i = 0; i < 20; ++i) {
+            AMT_HIP(hipStreamSynchronize(c->stream));
+            const double h0 = AmtTrace::now();
+            hipLaunchKernelGGL(trace_stamp_kernel, dim3(1), dim3(1), 0, c->stream, c->tr_stamps + 7);
+            AMT_HIP(hipStreamSynchronize(c->stream));
+            const double h1 = AmtTrace::now();
+            if (h1 - h0 < best) { best = h1 - h0; c->tr_offset_us = 0.5 * (h0 + h1) - (double)c->tr_stamps[7] / 100.0; }
+        }
+    }
+    hipLaunchKernelGGL(trace_stamp_kernel, dim3(1), dim3(1), 0, st, c->tr_stamps + slot);
+}
+}
+#endif
 
 namespace {
 constexpr size_t kSlotBytes = 32u << 20;
@@ -260,11 +248,42 @@ bool is_registered(const AmtGpuContext* c, const void* p, size_t n)
     return false;
 }
 
+// the address a kernel reads page-locked host memory at (the ring, or a registered range)
+const void* device_view(const void* host_pinned)
+{
+    void* d = nullptr;
+    AMT_HIP(hipHostGetDevicePointer(&d, const_cast<void*>(host_pinned), 0));
+    return d;
+}
+
 void copies_issued(AmtGpuContext* c)
 {
+#ifdef AMT_TRACE_CALLS
+    static const bool no_events = std::getenv("AMT_TRACE_NO_EVENTS") != nullptr;     // (with AMT_SAME_STREAM: no event is needed)
+    if (no_events) return;
+#endif
     AMT_HIP(hipEventRecord(c->copy_done, c->copy_stream));
     c->copies_pending = true;
+#ifdef AMT_TRACE_CALLS
+    if (!c->tr_copies_done) AMT_HIP(hipEventCreate(&c->tr_copies_done));
+    AMT_HIP(hipEventRecord(c->tr_copies_done, c->copy_stream));
+    if (c->tr_block_open) amt::trace_stamp(c, c->copy_stream, 1);
+#endif
 }
+#ifdef AMT_TRACE_CALLS
+void trace_block_begin(AmtGpuContext* c)
+{
+    if (c->tr_block_open) return;
+    c->tr_host_block_begin = AmtTrace::now();
+    amt::trace_stamp(c, c->copy_stream, 0);
+    if (!c->tr_first_copy) AMT_HIP(hipEventCreate(&c->tr_first_copy));
+    AMT_HIP(hipEventRecord(c->tr_first_copy, c->copy_stream));
+    c->tr_block_open = true;
+}
+#define AMT_TRACE_BLOCK_BEGIN(c) trace_block_begin(c)
+#else
+#define AMT_TRACE_BLOCK_BEGIN(c) do { } while (0)
+#endif
 } // namespace
 
 namespace {
@@ -377,8 +396,7 @@ int amtgpu_frames_upload_strided(AmtGpuContext* c, void* ddst, int64_t dst_strid
         if (chunk_bytes > kSlotBytes) throw std::runtime_error("chunk larger than a staging slot");
         if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
         if (is_registered(c, hsrc, (size_t)(nchunks - 1) * (size_t)src_stride + (size_t)chunk_bytes)) {
-            AMT_HIP(hipMemcpy2DAsync(ddst, (size_t)dst_stride, hsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyHostToDevice,
-                                     c->copy_stream));
+            AMT_HIP(launch_ingest_rows(c->copy_stream, device_view(hsrc), src_stride, ddst, dst_stride, chunk_bytes, nchunks));
             copies_issued(c);
             return;
         }
@@ -387,8 +405,12 @@ int amtgpu_frames_upload_strided(AmtGpuContext* c, void* ddst, int64_t dst_strid
             const int n = std::min(per_slot, nchunks - i0);
             uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
             staged_gather(c, stage, (size_t)chunk_bytes, n, [&](int64_t i) { return (const uint8_t*)hsrc + (size_t)(i0 + i) * src_stride; });
-            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
-                                     hipMemcpyHostToDevice, c->copy_stream));
+            // (rows as wide as their destination pitch are one contiguous run: the copy engine at full rate; narrow rows go by kernel)
+            if (dst_stride == (int64_t)chunk_bytes)
+                AMT_HIP(hipMemcpyAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, stage, (size_t)n * chunk_bytes, hipMemcpyHostToDevice, c->copy_stream));
+            else
+                AMT_HIP(launch_ingest_rows(c->copy_stream, device_view(stage), (long long)chunk_bytes, (uint8_t*)ddst + (size_t)i0 * dst_stride, dst_stride,
+                                           chunk_bytes, n));
         }
         copies_issued(c);
     });
@@ -408,6 +430,7 @@ int amtgpu_frames_upload_gather(AmtGpuContext* c, void* ddst, int64_t dst_stride
         if (dst_stride < (int64_t)chunk_bytes || src_stride < (int64_t)chunk_bytes) throw std::runtime_error("stride smaller than the chunk");
         const int64_t total = (int64_t)chunks_per_src * nsrc;
         const int64_t per_slot = (int64_t)(kSlotBytes / chunk_bytes);
+        AMT_TRACE_BLOCK_BEGIN(c);
         for (int64_t i0 = 0; i0 < total; i0 += per_slot) {
             const int64_t n = std::min(per_slot, total - i0);
             uint8_t* stage = stage_acquire(c, (size_t)n * chunk_bytes);
@@ -418,9 +441,16 @@ int amtgpu_frames_upload_gather(AmtGpuContext* c, void* ddst, int64_t dst_stride
                     return (const uint8_t*)hsrc[q / chunks_per_src] + (size_t)(q % chunks_per_src) * src_stride;
                 });
             }
-            AMT_TRACE_SCOPE("upload_gather.memcpy2d_async");
-            AMT_HIP(hipMemcpy2DAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, (size_t)dst_stride, stage, chunk_bytes, chunk_bytes, (size_t)n,
-                                     hipMemcpyHostToDevice, c->copy_stream));
+            AMT_TRACE_SCOPE("upload_gather.rows_to_device");
+#ifdef AMT_TRACE_CALLS
+            static const bool no_ingest = std::getenv("AMT_TRACE_NO_INGEST") != nullptr;
+            if (no_ingest) continue;
+#endif
+            if (dst_stride == (int64_t)chunk_bytes)
+                AMT_HIP(hipMemcpyAsync((uint8_t*)ddst + (size_t)i0 * dst_stride, stage, (size_t)n * chunk_bytes, hipMemcpyHostToDevice, c->copy_stream));
+            else
+                AMT_HIP(launch_ingest_rows(c->copy_stream, device_view(stage), (long long)chunk_bytes, (uint8_t*)ddst + (size_t)i0 * dst_stride, dst_stride,
+                                           chunk_bytes, n));
         }
         copies_issued(c);
     });
@@ -431,6 +461,11 @@ int amtgpu_frames_upload_wait(AmtGpuContext* c)
     return guard(c, [&] {
         c->bind();
         if (c->copies_pending) { AMT_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0)); c->copies_pending = false; }
+#ifdef AMT_TRACE_CALLS
+        if (!c->tr_released) AMT_HIP(hipEventCreate(&c->tr_released));
+        AMT_HIP(hipEventRecord(c->tr_released, c->stream));
+        if (c->tr_block_open) amt::trace_stamp(c, c->stream, 2);
+#endif
     });
 }
 
@@ -456,8 +491,8 @@ int amtgpu_download_strided(AmtGpuContext* c, void* hdst, int64_t dst_stride, co
             AMT_HIP(hipHostMalloc(&c->pinned_down, total, hipHostMallocDefault));
             c->pinned_down_bytes = total;
         }
-        AMT_HIP(hipMemcpy2DAsync(c->pinned_down, (size_t)chunk_bytes, dsrc, (size_t)src_stride, chunk_bytes, (size_t)nchunks, hipMemcpyDeviceToHost,
-                                 c->stream));
+        // packed on the device side by the library's row kernel writing the pinned buffer directly (no 2-D copy of the runtime)
+        AMT_HIP(launch_ingest_rows(c->stream, dsrc, src_stride, const_cast<void*>(device_view(c->pinned_down)), (long long)chunk_bytes, chunk_bytes, nchunks));
         AMT_HIP(hipStreamSynchronize(c->stream));
         for (int i = 0; i < nchunks; ++i)
             std::memcpy((uint8_t*)hdst + (size_t)i * dst_stride, (const uint8_t*)c->pinned_down + (size_t)i * chunk_bytes, (size_t)chunk_bytes);
@@ -551,31 +586,6 @@ int amtgpu_marker_wait_on(AmtGpuContext* c, AmtGpuMarker* m)
         if (!m) throw std::runtime_error("null marker");
         c->bind();
         AMT_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(m)));             // never recorded: returns at once
-    });
-}
-
-int amtgpu_context_set_keepalive(AmtGpuContext* c, int period_us, int spin_us)
-{
-    return guard(c, [&] {
-        if (!c) throw std::runtime_error("no context");
-        if (period_us < 0 || period_us > 1000000 || spin_us < 0 || spin_us > 100000) throw std::runtime_error("keep-alive period / spin out of range");
-        if (c->keepalive) {
-            c->keepalive->stop.store(true);
-            if (c->keepalive->th.joinable()) c->keepalive->th.join();
-            if (c->keepalive->stream) (void)hipStreamDestroy(c->keepalive->stream);
-            delete c->keepalive;
-            c->keepalive = nullptr;
-        }
-        if (period_us == 0) return;
-        c->bind();
-        std::unique_ptr<AmtGpuContext::KeepAlive> k(new AmtGpuContext::KeepAlive);
-        k->device = c->device; k->period_us = period_us; k->spin_us = spin_us;
-        int lo = 0, hi = 0;
-        AMT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));                          // lo = the numerically largest = lowest priority
-        AMT_HIP(hipStreamCreateWithPriority(&k->stream, hipStreamNonBlocking, lo));
-        AmtGpuContext::KeepAlive* kp = k.get();
-        k->th = std::thread([kp] { kp->loop(); });
-        c->keepalive = k.release();
     });
 }
 

@@ -67,9 +67,17 @@ struct AmtGpuContext {
     int upload_threads = 1;
     // host ranges the caller has page-locked through amtgpu_frames_register: uploads from inside them skip the staging ring
     std::vector<std::pair<uintptr_t, size_t>> registered;
-    // optional heartbeat that keeps the device's queues from going idle between the small launches of a frame-by-frame host
-    struct KeepAlive;
-    KeepAlive* keepalive = nullptr;
+#ifdef AMT_TRACE_CALLS
+    // instrumented builds: timing events that bracket a block's GPU-side stages (first copy issued -> copies done -> the compute
+    // stream's wait released -> kernels done -> results landed), read out in amtgpu_analyze_batch_host
+    hipEvent_t tr_first_copy = nullptr, tr_copies_done = nullptr, tr_released = nullptr, tr_kernels = nullptr, tr_landed = nullptr;
+    bool tr_block_open = false;
+    // ... and GPU wall-clock stamps (100 MHz constant counter, written to pinned memory by one-thread kernels) mapped onto the host's
+    // clock by a calibration at first use: when did the device START and FINISH each stage, against when the host enqueued / noticed
+    unsigned long long* tr_stamps = nullptr;      // [8] pinned
+    double tr_offset_us = 0;                      // host_us = gpu_ticks / 100 + tr_offset_us
+    double tr_host_block_begin = 0;
+#endif
     void* pinned_down = nullptr;        // pinned landing buffer of amtgpu_download_pinned
     size_t pinned_down_bytes = 0;
     hipEvent_t markers[16] = {};        // amtgpu_marker_record / _wait

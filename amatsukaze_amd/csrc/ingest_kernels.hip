@@ -7,6 +7,7 @@
 // A pure HBM copy: one wave per output row, 16 bytes per lane when rows are 16-byte aligned (AVFrame lines are 32/64-byte
 // aligned, AviSynth's 64), element by element otherwise.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 
 namespace amt {
@@ -65,6 +66,46 @@ void weave_fields_kernel(WeaveArgs a, const int* __restrict__ top_index, const i
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Rows that arrive in pinned host memory (a slot of the staging ring, or a registered frame pool) to their pitched place in HBM:
+// `nchunks` pieces of `chunk` bytes, src_stride apart in host memory, dst_stride apart on the device.  The kernel reads the
+// host memory itself, over PCIe -- no copy engine: the runtime's 2-D copy took 3-5 ms per call for narrow rows on this stack
+// (8192 rows of 256 bytes; profiles/r04_notes.md "Boundary"), 40x what the bytes cost.  One lane moves 16 bytes (4 or 1 when the
+// geometry is not 16-byte aligned); a row's lanes are consecutive, so the PCIe reads of a wave are 1 KiB contiguous where rows allow.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename V>
+__global__ __launch_bounds__(256)
+void ingest_rows_kernel(const uint8_t* __restrict__ src, long long src_stride, uint8_t* __restrict__ dst, long long dst_stride,
+                        int vecs_per_chunk, long long total_vecs)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vecs; i += (long long)gridDim.x * blockDim.x) {
+        const long long c = i / vecs_per_chunk;
+        const int v = (int)(i - c * vecs_per_chunk);
+        reinterpret_cast<V*>(dst + c * dst_stride)[v] = reinterpret_cast<const V*>(src + c * src_stride)[v];
+    }
+}
+
+hipError_t launch_ingest_rows(hipStream_t st, const void* src_host_mapped, long long src_stride, void* dst, long long dst_stride,
+                              unsigned long long chunk, long long nchunks)
+{
+    if (!chunk || nchunks <= 0) return hipSuccess;
+    const uintptr_t a = (uintptr_t)src_host_mapped | (uintptr_t)dst | (uintptr_t)src_stride | (uintptr_t)dst_stride | (uintptr_t)chunk;
+    const int vb = (a % 16 == 0) ? 16 : (a % 4 == 0) ? 4 : 1;
+    const long long total = (long long)(chunk / vb) * nchunks;
+    // enough lanes in flight to cover the PCIe round trip (a few microseconds) at the link's rate, never more than the work
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 2048);
+    if (vb == 16)
+        hipLaunchKernelGGL(ingest_rows_kernel<uint4>, dim3(grid), dim3(256), 0, st, (const uint8_t*)src_host_mapped, src_stride, (uint8_t*)dst, dst_stride,
+                           (int)(chunk / 16), total);
+    else if (vb == 4)
+        hipLaunchKernelGGL(ingest_rows_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, (const uint8_t*)src_host_mapped, src_stride, (uint8_t*)dst, dst_stride,
+                           (int)(chunk / 4), total);
+    else
+        hipLaunchKernelGGL(ingest_rows_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, (const uint8_t*)src_host_mapped, src_stride, (uint8_t*)dst, dst_stride,
+                           (int)chunk, total);
+    return hipGetLastError();
 }
 
 hipError_t launch_weave_fields(hipStream_t st, const WeaveArgs& a, const int* dtop_index, const int* dbottom_index, int nframes)

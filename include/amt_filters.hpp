@@ -62,12 +62,9 @@ constexpr int kUploadGroup = 64;   /* host frames whose logo rectangles share on
 class Context {
     AmtGpuContext* g_;
 public:
-    /* keepalive_us > 0: amtgpu_context_set_keepalive(keepalive_us, keepalive_us) -- for hosts that pull frames one small block at a
-     * time and would otherwise leave the device's queues idle between blocks (see amt_gpu.h) */
-    explicit Context(int device = 0, int keepalive_us = 0) : g_(amtgpu_context_create(device))
+    explicit Context(int device = 0) : g_(amtgpu_context_create(device))
     {
         if (!g_) throw std::runtime_error("amtgpu: no HIP device (there is no CPU path)");
-        if (keepalive_us > 0) amtgpu_context_set_keepalive(g_, keepalive_us, keepalive_us);
     }
     ~Context() { amtgpu_context_destroy(g_); }
     Context(const Context&) = delete;

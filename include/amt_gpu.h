@@ -30,7 +30,7 @@ extern "C" {
 #define AMTGPU_ABI_VERSION 3      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers
                                    * 3: additions only -- device-side CalcFade (amtgpu_erase_calc_fades_device, *_dfades), sharded frame
                                    *    metrics (amtgpu_framestats_allgather / _sharded), registered host frames (amtgpu_frames_register),
-                                   *    amtgpu_download_scatter */
+                                   *    amtgpu_download_scatter, owned markers */
 #define AMTGPU_NUM_FADE 11            /* LogoAnalyzeFrame p/t/b[11]  (LogoScan.hpp:1100-1103) */
 #define AMTGPU_ANALYZE_FLOATS 33      /* floats per source frame in an analysis record */
 
@@ -128,14 +128,7 @@ AmtGpuMarker* amtgpu_marker_create(AmtGpuContext* ctx);
 void  amtgpu_marker_destroy(AmtGpuContext* ctx, AmtGpuMarker* m);
 int   amtgpu_marker_record_on(AmtGpuContext* ctx, AmtGpuMarker* m);
 int   amtgpu_marker_wait_on(AmtGpuContext* ctx, AmtGpuMarker* m);     /* never recorded: returns at once */
-/* Keep-alive for frame-by-frame hosts.  A host that pulls one small block at a time (GetFrame by GetFrame through
- * include/amt_filters.hpp) leaves the device's queues idle for milliseconds between launches, and on some hosts an idle queue is
- * picked up again late (measured: completions at multiples of 10 ms, profiles/r03_notes.md "Boundary", profiles/r04_notes.md).  With
- * period_us > 0 a helper thread launches a one-wave kernel on a lowest-priority side stream every period_us microseconds (skipping a
- * beat while the previous one is still running); spin_us > 0 makes each beat keep its wave resident for that long (constant-clock
- * timed s_sleep loop), so that with spin_us >= period_us the device never goes idle at all.  0, 0 stops it.  Every beat ends by
- * itself: device-wide synchronisation (hipDeviceSynchronize, hipFree) is delayed by at most spin_us.  Off by default. */
-int   amtgpu_context_set_keepalive(AmtGpuContext* ctx, int period_us, int spin_us);
+
 
 /* ---- frame assembly: replaces AMTSource::MakeFrame -> MergeField / Copy1 / Copy2 (AMTSource.hpp:291-366) on decoded
  *      pictures already in HBM (uploaded with amtgpu_frames_upload): output frame i takes its even rows from picture

@@ -160,8 +160,22 @@ public:
         const double v = vis(n);
         if (v >= 1.0) return logo_[n & 7];
         if (v <= 0.0) return plain_[n & 7];
-        return blended(n & 7, v);
+        // A partially faded frame exists once per (base picture, fade step) and is handed out by reference like the others -- what a
+        // decoder's frame pool or AviSynth's frame cache does.  Blending a FRESH 2.3 MB frame for every request (round 3's source) made
+        // the measured "filter layer" rates an artefact of the allocator: each such frame is a new mmap whose pages fault in one by one
+        // (slow under virtualisation) and whose munmap shoots down the address space the GPU driver tracks -- blocks then took 20-40 ms
+        // in steps of 10 ms (profiles/r04_notes.md, "Boundary").  AMT_BENCH_FRESH_FADES=1 brings that source back.
+        static const bool fresh = std::getenv("AMT_BENCH_FRESH_FADES") != nullptr;
+        if (fresh) return blended(n & 7, v);
+        const int key = (n & 7) * 1024 + (int)(v * 1000.0 + 0.5);
+        std::lock_guard<std::mutex> lk(fade_mu_);
+        auto it = faded_.find(key);
+        if (it == faded_.end()) it = faded_.emplace(key, blended(n & 7, v)).first;
+        return it->second;
     }
+private:
+    std::mutex fade_mu_;
+    std::map<int, PVideoFrame> faded_;
 };
 
 // --bench: frames per second THROUGH include/amt_filters.hpp -- what a host that pulls frames one GetFrame at a time gets
@@ -173,11 +187,6 @@ static int run_bench(int argc, char** argv)
     const std::string l1 = argv[5], l2 = argv[6], l3 = argc > 7 ? argv[7] : argv[6];
     IScriptEnvironment env;
     auto ctx = std::make_shared<amtgpu::Context>(argc > 8 ? std::atoi(argv[8]) : 0);
-    int ka_period = 0, ka_spin = 0;
-    if (const char* ka = std::getenv("AMT_KEEPALIVE")) {            // "period_us,spin_us": amtgpu_context_set_keepalive (diagnostic / tuning)
-        std::sscanf(ka, "%d,%d", &ka_period, &ka_spin);
-        if (!amtgpu_context_set_keepalive(ctx->get(), ka_period, ka_spin)) { std::fprintf(stderr, "keepalive: %s\n", ctx->error()); return 1; }
-    }
     PClip src = std::make_shared<SynthClip>(W, H, N, l1);
     auto secs = [](auto&& fn) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -187,8 +196,8 @@ static int run_bench(int argc, char** argv)
     // the source alone (frames by reference + what the filters' callers do with them: nothing)
     const double t_src = secs([&] { for (int n = 0; n < N; ++n) src->GetFrame(n, &env); });
     // LogoFrame::scanFrames, 3 logos (CMAnalyze.hpp:291-299)
-    double t_scan = 0;
-    {
+    double t_scan = 1;
+    if (!std::getenv("AMT_BENCH_SKIP_SCAN")) {                         // (diagnostic)
         amtgpu::LogoFrame lf(ctx, {l1, l2, l3}, 0.35f);
         lf.scanFrames(src, &env);                                     // warm-up: tables, buffers, pinned ring
         t_scan = secs([&] { lf.scanFrames(src, &env); });
@@ -236,8 +245,8 @@ static int run_bench(int argc, char** argv)
     std::printf("{\"what\": \"frames/s through include/amt_filters.hpp (GetFrame by GetFrame, frames in host memory, PCIe inclusive)\", "
                 "\"frame\": \"%dx%d 8-bit\", \"frames\": %d, \"source_alone_fps\": %.0f, \"logoframe_scan_3_logos_fps\": %.0f, "
                 "\"analyze_exact_fps\": %.0f, \"analyze_linear_guarded_fps\": %.0f, \"erase_graph_exact_fps\": %.0f, "
-                "\"erase_graph_linear_guarded_fps\": %.0f, \"erased_frames_identical_in_both_modes\": %s, \"keepalive_us\": [%d, %d], ",
-                W, H, N, N / t_src, N / t_scan, N / t_an[0], N / t_an[1], N / t_er[0], N / t_er[1], sum[0] == sum[1] ? "true" : "false", ka_period, ka_spin);
+                "\"erase_graph_linear_guarded_fps\": %.0f, \"erased_frames_identical_in_both_modes\": %s, ",
+                W, H, N, N / t_src, N / t_scan, N / t_an[0], N / t_an[1], N / t_er[0], N / t_er[1], sum[0] == sum[1] ? "true" : "false");
     for (int mode = 0; mode < 2; ++mode) {
         std::printf("\"analyze_%s_block_ms_hist\": {", mode ? "linear" : "exact");
         bool firstk = true;

@@ -111,7 +111,7 @@ def test_download_scatter(env):
     assert b"outside" in lib.amtgpu_last_error(ctx.h)
 
 
-def test_owned_markers_and_keepalive(env):
+def test_owned_markers(env):
     torch, ctx, lib = env["torch"], env["ctx"], env["lib"]
     m1, m2 = lib.amtgpu_marker_create(ctx.h), lib.amtgpu_marker_create(ctx.h)
     assert m1 and m2 and m1 != m2
@@ -121,13 +121,3 @@ def test_owned_markers_and_keepalive(env):
     ctx.check(lib.amtgpu_marker_wait_on(ctx.h, m1))
     lib.amtgpu_marker_destroy(ctx.h, m1)
     lib.amtgpu_marker_destroy(ctx.h, m2)
-    # the heartbeat runs beside ordinary work and stops on request; device-wide synchronisation still completes
-    import time
-    ctx.check(lib.amtgpu_context_set_keepalive(ctx.h, 500, 500))
-    t0 = time.time()
-    for _ in range(20):
-        y = (x * 2).sum().item()
-        torch.cuda.synchronize()
-    assert y == float(2 << 20) and time.time() - t0 < 5.0
-    ctx.check(lib.amtgpu_context_set_keepalive(ctx.h, 0, 0))
-    assert not lib.amtgpu_context_set_keepalive(ctx.h, -1, 0)

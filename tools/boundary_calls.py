@@ -14,15 +14,22 @@ if "--build" in sys.argv:
     print("built", os.path.join(VDIR, "libamt_gpu.so"))
     sys.exit(0)
 import amt_synth as S
-from amatsukaze_amd import Context, Logo
-ctx = Context(0)
+import numpy as np
+from amatsukaze_amd import binding
+# The .lgd files are written WITHOUT touching the GPU (amtgpu_logo_from_planes / _save are host code and take a NULL context): this
+# process must not hold a HIP context while filters_host_test runs -- two processes with queues on one GPU are time-sliced by the
+# driver's scheduler in 10 ms quanta, which is what round 3 read as an "idle-queue pick-up tick" (profiles/r04_notes.md).
+lib = binding.load()
 tmp = tempfile.mkdtemp()
 paths = []
 for i in range(3):
     data = S.make_logo(256, 128, seed=0x10600002 + i, strength=0.5 + 0.1 * i)[0] if i else S.make_logo(256, 128)[0]
-    l = Logo.from_planes(ctx, data, 256, 128, 1440, 1080, 1120, 64)
-    p = os.path.join(tmp, f"logo{i}.lgd"); l.save(p, f"b{i}", 1); paths.append(p)
-del ctx
+    data = np.ascontiguousarray(data, np.float32)
+    h = lib.amtgpu_logo_from_planes(None, 256, 128, 1, 1, 1440, 1080, 1120, 64, data.ctypes.data)
+    p = os.path.join(tmp, f"logo{i}.lgd")
+    assert h and lib.amtgpu_logo_save(None, h, p.encode(), f"b{i}".encode(), 1)
+    lib.amtgpu_logo_destroy(h)
+    paths.append(p)
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "filters_host_test"], stdout=subprocess.DEVNULL)
 args = [a for a in sys.argv[1:] if "=" not in a]
 n = int(args[0]) if args else 2048
@@ -40,6 +47,21 @@ for name, t0, d in recs:
 for name, (c, s, m) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     slow = sum(1 for nm, _, d in recs if nm == name and d > 5000)
     print(f"{name:45s} calls {c:6d}  total {s / 1e3:9.1f} ms  max {m / 1e3:7.2f} ms  calls > 5 ms: {slow}")
+# the blocks of the analysis passes on one clock: microseconds after the host began the block
+blk = collections.defaultdict(list)
+for name, t0, d in recs:
+    if name.startswith("blk."):
+        blk[name].append(d)
+for name in sorted(blk):
+    v = blk[name]
+    print(f"{name:40s} per block (us): " + " ".join(f"{x:8.0f}" for x in v[2:18]))
+# every traced call of two consecutive steady-state blocks of the first analysis pass (records are appended when a call ENDS)
+ends = [i for i, r in enumerate(recs) if r[0] == "amtgpu_analyze_batch_host"]
+if len(ends) > 6:
+    print("--- all calls of blocks 4 and 5 (t = begin, us since the first call) ---")
+    for nm, t, dd in recs[ends[3] + 1:ends[5] + 1]:
+        if not nm.startswith(("blk.", "gpu.")):
+            print(f"   t={t / 1e3:10.3f} ms  {dd / 1e3:8.3f} ms  {nm}")
 # the call sequence around the first few slow calls (> 5 ms)
 shown = 0
 for i, (name, t0, d) in enumerate(recs):
