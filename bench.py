@@ -1200,11 +1200,10 @@ def measure_boundary(ctx, logos, device, frames=6144):
     if r.returncode != 0:
         raise RuntimeError("filters_host_test --bench: " + (r.stderr or r.stdout)[-400:])
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    out["note"] = ("a second process on the same GPU, after the timed region; source frames are handed out by reference (no decoder), so "
-                   "these are the filter layer's own rates: host copies (MakeWritable, pinned staging), PCIe, launches.  A loop whose "
-                   "queue goes idle between blocks can fall into a regime where queued work is picked up at 10 ms ticks on this box "
-                   "(analyze_exact: 0.3 ms of kernel per 256-frame block, 20-30 ms per block; 83 k frames/s under rocprofv3) -- "
-                   "profiles/r03_notes.md")
+    out["note"] = ("a second process on the same GPU, after the timed region; source frames are handed out by reference (no decoder) and frame "
+                   "memory is recycled like AviSynth's frame buffers, so these are the filter layer's own rates: host copies (MakeWritable, "
+                   "pinned staging), PCIe, launches.  Round 3's 8-13 k frames/s and its '10 ms tick' were the test source allocating a fresh "
+                   "2.3 MB frame per faded picture (profiles/r04_notes.md)")
     return out
 
 

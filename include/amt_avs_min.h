@@ -15,7 +15,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,12 +53,65 @@ struct VideoInfo {
     bool IsPlanar() const { return pixel_type != CS_BGR32; }
 };
 
+/* Frame memory is recycled, as AviSynth recycles its VideoFrameBuffers (a released buffer of the right size serves the next
+ * NewVideoFrame / MakeWritable): a host that maps and unmaps megabytes per frame measures its allocator, not its filters. */
+class FrameBufferPool {
+    std::mutex mu_;
+    std::multimap<size_t, std::vector<uint8_t>> free_;
+    size_t held_ = 0;
+    static constexpr size_t kMaxHeld = (size_t)2 << 30;
+public:
+    static FrameBufferPool& get() { static FrameBufferPool p; return p; }
+    std::vector<uint8_t> acquire(size_t n)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = free_.find(n);
+            if (it != free_.end()) {
+                std::vector<uint8_t> v = std::move(it->second);
+                free_.erase(it);
+                held_ -= n;
+                if (n <= 65536) std::memset(v.data(), 0, n);      /* (small frames -- the analysis clip's -- come back clean) */
+                return v;
+            }
+        }
+        return std::vector<uint8_t>(n, 0);
+    }
+    void release(std::vector<uint8_t>&& v)
+    {
+        const size_t n = v.size();
+        if (!n) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        if (held_ + n > kMaxHeld) return;          /* (the vector frees itself) */
+        held_ += n;
+        free_.emplace(n, std::move(v));
+    }
+};
+
 /* planes are 64-byte aligned like AviSynth's (include/avs/config.h:45 FRAME_ALIGN) */
 class VideoFrame {
     std::vector<uint8_t> buf_;
     int off_[3] = {0, 0, 0}, pitch_[3] = {0, 0, 0}, row_[3] = {0, 0, 0}, rows_[3] = {0, 0, 0};
     static int idx(int plane) { return plane == PLANAR_U ? 1 : plane == PLANAR_V ? 2 : 0; }
+    void place(size_t total)
+    {
+        buf_ = FrameBufferPool::get().acquire(total + 64);
+        const int shift = (int)((64 - (reinterpret_cast<uintptr_t>(buf_.data()) & 63)) & 63);
+        for (int p = 0; p < 3; ++p) off_[p] += shift;
+    }
 public:
+    ~VideoFrame() { FrameBufferPool::get().release(std::move(buf_)); }
+    VideoFrame& operator=(const VideoFrame&) = delete;
+    VideoFrame(const VideoFrame& o)
+    {
+        size_t total = 0;
+        int o0 = 0;
+        for (int p = 0; p < 3; ++p) { pitch_[p] = o.pitch_[p]; row_[p] = o.row_[p]; rows_[p] = o.rows_[p]; off_[p] = o0; o0 += pitch_[p] * rows_[p]; }
+        total = (size_t)o0;
+        place(total);
+        for (int p = 0; p < 3; ++p)
+            if (rows_[p]) std::memcpy(buf_.data() + off_[p], o.buf_.data() + o.off_[p], (size_t)pitch_[p] * rows_[p]);
+    }
     explicit VideoFrame(const VideoInfo& vi)
     {
         auto al = [](int v) { return (v + 63) & ~63; };
@@ -69,9 +124,7 @@ public:
         }
         int o = 0;
         for (int p = 0; p < 3; ++p) { pitch_[p] = row_[p] ? al(row_[p]) : 0; off_[p] = o; o += pitch_[p] * rows_[p]; }
-        buf_.assign((size_t)o + 64, 0);
-        const int shift = (int)((64 - (reinterpret_cast<uintptr_t>(buf_.data()) & 63)) & 63);
-        for (int p = 0; p < 3; ++p) off_[p] += shift;
+        place((size_t)o);
     }
     const uint8_t* GetReadPtr(int plane = PLANAR_Y) const { return buf_.data() + off_[idx(plane)]; }
     uint8_t* GetWritePtr(int plane = PLANAR_Y) { return buf_.data() + off_[idx(plane)]; }
