@@ -55,6 +55,9 @@ template <> struct Px<2> {
 #ifndef AMT_STATS_COLB
 #define AMT_STATS_COLB 16
 #endif
+#ifndef AMT_STATS_PREFETCH
+#define AMT_STATS_PREFETCH 0
+#endif
 constexpr int kStatColBytes = AMT_STATS_COLB;      // bytes of a row one lane owns: 16 (one dwordx4 load) or 8 (dwordx2: half the registers per row)
 constexpr int kStatColWords = kStatColBytes / 4;
 struct alignas(kStatColBytes) Chunk { unsigned w[kStatColWords]; };
@@ -95,8 +98,13 @@ template <int ES> __device__ __forceinline__ Chunk avg16(const Chunk& a, const C
     return r;
 }
 
+#ifdef AMT_STATS_WAVES
+#define AMT_STATS_OCC __attribute__((amdgpu_waves_per_eu(AMT_STATS_WAVES, AMT_STATS_WAVES)))
+#else
+#define AMT_STATS_OCC
+#endif
 template <int ES>
-__global__ __launch_bounds__(kStatThreads)
+__global__ __launch_bounds__(kStatThreads) AMT_STATS_OCC
 void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*bytes*/, int pitch_bytes, int row_bytes, int H,
                         const uint8_t* __restrict__ prevY /* frame before the batch or null */, int nframes, int col_groups,
                         unsigned long long* __restrict__ out)
@@ -137,13 +145,8 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         }
     };
 
-    Chunk prev[R], cur[R];
-    {
-        const uint8_t* p = n0 > 0 ? Y + (long long)(n0 - 1) * frame_stride : (prevY ? prevY : Y);
-        load_rows(p, prev);
-    }
-    for (int n = n0; n < n1; ++n) {
-        load_rows(Y + (long long)n * frame_stride, cur);
+    // one frame of this thread's tile against the frame before it; wave reduction, one atomic per word per wave
+    auto compute = [&](const Chunk* cur, const Chunk* prev, int n) {
         unsigned acc[7] = {0, 0, 0, 0, 0, 0, 0};
         const Chunk zero = chunk_zero();
 #pragma unroll
@@ -166,7 +169,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
                 }
             }
         }
-        // workgroup reduction: wave shuffles, then one atomic per word per wave
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             unsigned v = acc[k];
@@ -179,9 +181,36 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
             for (int k = 0; k < 7; ++k)
                 if (acc[k]) atomicAdd(&out[(long long)n * kStatWords + k], (unsigned long long)acc[k]);
         }
+    };
+    const uint8_t* const before = n0 > 0 ? Y + (long long)(n0 - 1) * frame_stride : (prevY ? prevY : Y);
+#if AMT_STATS_PREFETCH
+    // three row sets in rotation: the loads of frame n + 1 are issued BEFORE frame n is evaluated, so that every wave always has a
+    // whole tile in flight -- the kernel's rate is set by the bytes a CU keeps in flight (measured: it scales with the CUs it is
+    // given, ~29 GB/s per CU for the two-set form), not by HBM, as soon as it does not own the whole device
+    Chunk A[R], B[R], D[R];
+    load_rows(before, A);
+    load_rows(Y + (long long)n0 * frame_stride, B);
+    for (int n = n0;;) {
+        if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, D);
+        compute(B, A, n);
+        if (++n >= n1) break;
+        if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, A);
+        compute(D, B, n);
+        if (++n >= n1) break;
+        if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, B);
+        compute(A, D, n);
+        if (++n >= n1) break;
+    }
+#else
+    Chunk prev[R], cur[R];
+    load_rows(before, prev);
+    for (int n = n0; n < n1; ++n) {
+        load_rows(Y + (long long)n * frame_stride, cur);
+        compute(cur, prev, n);
 #pragma unroll
         for (int r = 0; r < R; ++r) prev[r] = cur[r];
     }
+#endif
 }
 
 hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long long frame_stride_bytes, int pitch_elems, int W,

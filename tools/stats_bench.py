@@ -4,7 +4,11 @@
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
-VARIANTS = {"vg1_r16": ["AMT_STATS_VG=1"], "vg4_r16": ["AMT_STATS_VG=4"], "vg8_r8": ["AMT_STATS_VG=8", "AMT_STATS_ROWS=8"],
+VARIANTS = {"pf_vg1_x8B": ["AMT_STATS_VG=1", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"], "pf_vg4_x8B": ["AMT_STATS_VG=4", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"],
+            "pf_vg1_r8": ["AMT_STATS_VG=1", "AMT_STATS_ROWS=8", "AMT_STATS_PREFETCH=1"], "pf_vg1_r8_x8B": ["AMT_STATS_VG=1", "AMT_STATS_ROWS=8", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"],
+            "pf_vg1_x16B": ["AMT_STATS_VG=1", "AMT_STATS_PREFETCH=1"],
+            "pf_vg1_r8_x8B_w3": ["AMT_STATS_VG=1", "AMT_STATS_ROWS=8", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1", "AMT_STATS_WAVES=3"],
+            "vg1_r16": ["AMT_STATS_VG=1"], "vg4_r16": ["AMT_STATS_VG=4"], "vg8_r8": ["AMT_STATS_VG=8", "AMT_STATS_ROWS=8"],
             "vg4_r8": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=8"], "vg4_r16_run64": ["AMT_STATS_VG=4", "AMT_STATS_RUN=64"],
             "vg2_r16": ["AMT_STATS_VG=2"], "vg4_r32x8B": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"], "vg4_r16x8B": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=16", "AMT_STATS_COLB=8"],
             "vg2_r16x8B": ["AMT_STATS_VG=2", "AMT_STATS_ROWS=16", "AMT_STATS_COLB=8"]}
@@ -22,6 +26,16 @@ if "--child" in sys.argv:
     from amatsukaze_amd import Context, FrameStats
     ctx = Context(0)
     dev = torch.device("cuda:0")
+    ncu = int(os.environ.get("AMT_STATS_MASK_CUS", "0"))
+    if ncu:                                  # the kernel on the first `ncu` CUs only (hipExtStreamCreateWithCUMask, contiguous bits)
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        words = (C.c_uint32 * 8)()
+        for i in range(ncu):
+            words[i // 32] |= 1 << (i % 32)
+        st = C.c_void_p()
+        assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, words) == 0
+        ctx.check(ctx.lib.amtgpu_context_set_stream(ctx.h, st))
     out = {}
     for tag, (W, H, bits, pitch, N) in {"1440x1080_8bit": (1440, 1080, 8, 1472, 10000), "1920x1080_10bit": (1920, 1080, 10, 1920, 3000)}.items():
         Y = S.make_clip_torch(N, W, H, 0x5EED0002, None, None, 0, 0, dev, bits=bits, pitchY=pitch, chroma=False)["Y"]
@@ -36,7 +50,10 @@ if "--child" in sys.argv:
         c, ms = ctx.profile_report()["frame_stats_kernel"]
         ctx.profile(False)
         es = 1 if bits <= 8 else 2
+        torch.cuda.synchronize()
         out[tag] = {"ms": ms / c, "alg_TBs": W * H * es * N / (ms / c * 1e-3) / 1e12, "sha": hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest()[:16]}
+        if ncu:
+            out[tag]["GBs_per_cu"] = W * H * es * N / (ms / c * 1e-3) / 1e9 / ncu
         del Y
     print(json.dumps(out))
     sys.exit(0)
