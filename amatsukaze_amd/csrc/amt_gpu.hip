@@ -439,6 +439,7 @@ struct AmtGpuAnalyze {
     DevBuf<float> dTmp;
     int mode = AMTGPU_ANALYZE_EXACT;
     DevBuf<int> dList, dCount;          // decision guard of the linear mode: frames to re-evaluate exactly
+    DevBuf<uint8_t> dForce;             // ... and the frames that carry samples above maxv (9..15-bit clips in 16-bit containers)
 };
 
 // one batch in the selected mode.  Linear mode: all fades from one window evaluation of s and of bg, then the decision guard --
@@ -458,8 +459,17 @@ static void analyze_run(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride,
     if (an->mode == AMTGPU_ANALYZE_LINEAR_UNGUARDED) return;
     float eps[3];
     for (int k = 0; k < 3; ++k) eps[k] = 2.0f * an->engine->linear_error_bound(k, bits);
+    const uint8_t* force = nullptr;
+    if (bits > 8 && bits < 16) {        // container values above maxv are outside the bound's assumption: such frames go to the exact kernel
+        if (an->dForce.size() < (size_t)nframes) an->dForce.alloc(nframes);
+        const int spf = an->ctx->prof_begin("rect_range_flag_kernel");
+        AMT_HIP(launch_rect_range_flag(an->ctx->stream, dY, frame_stride / 2, pitch, an->logo.imgx, an->logo.imgy, an->logo.w, an->logo.h, bits, nframes,
+                                       an->dForce.get()));
+        an->ctx->prof_end(spf);
+        force = an->dForce.get();
+    }
     const int sp = an->ctx->prof_begin("analysis_mark_kernel");
-    AMT_HIP(launch_analysis_mark(an->ctx->stream, dout, AMTGPU_ANALYZE_FLOATS, nframes, 3, AMTGPU_NUM_FADE, eps, an->dList.get(), an->dCount.get()));
+    AMT_HIP(launch_analysis_mark(an->ctx->stream, dout, AMTGPU_ANALYZE_FLOATS, nframes, 3, AMTGPU_NUM_FADE, eps, an->dList.get(), an->dCount.get(), force));
     an->ctx->prof_end(sp);
     an->engine->run_listed(dY, frame_stride, pitch, bits, nframes, an->dList.get(), an->dCount.get(), dout);
 }

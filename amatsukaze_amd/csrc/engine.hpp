@@ -239,6 +239,8 @@ hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dl
                                  const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,
                                  int nframes, int G, float* dout, int out_frame_stride, int take_abs);
 hipError_t launch_analysis_mark(hipStream_t st, const float* drec, int stride, int nframes, int ngroups, int nfades, const float* eps3,
-                                int* dlist, int* dcount);
+                                int* dlist, int* dcount, const uint8_t* dforce = nullptr);
+hipError_t launch_rect_range_flag(hipStream_t st, const void* dY, long long frame_stride_elems, int pitch, int imgx, int imgy, int w, int h, int bits,
+                                  int nframes, uint8_t* dflag);
 
 } // namespace amt

@@ -313,12 +313,16 @@ void EvalEngine::ensure_linear()
         // linear path: corr = sum k_i w_i - mean * sum k_i as two 13-deep FMA chains (<= 14 u sum|k_i w_i| + 2u for the add and the
         //              mean term, whose own error 7 u v is multiplied by |sum k_i| <= sum|k_i|): 23 u v sum|k|, for s and for bg with
         //              weights 1-f and f; 3 roundings to combine:  26
-        //  => |corr_lin - corr_exact| <= 53 u v sum|k_i| (58 below); the clamp is 1-Lipschitz, so a term moves by <= scale*scale2 times that (+ 2u|t|);
+        //  => |corr_lin - corr_exact| <= 53 u v sum|k_i| (58 below, + 24 for the tap sum formed on the host); the clamp is 1-Lipschitz, so a term moves by <= scale*scale2 times that (+ 2u|t|);
         // two summation orders of the count terms (the reference's sequential one, this kernel's lanes / tiles / waves) differ by
         // <= (count + 32) u sum|t|, and |t| <= scale2.
         const float* a = S.planes.A(0);
         const float* b = S.planes.B(0);
-        for (int p = 0; p < w * h; ++p) vunit = std::max(vunit, (double)std::fabs(a[p]) + std::fabs(b[p]));
+        for (int p = 0; p < w * h; ++p) {
+            const double ab = (double)std::fabs(a[p]) + std::fabs(b[p]);
+            if (!(ab < 1e30)) throw std::runtime_error("logo coefficients are not finite: the linear mode has no error bound for them");   // (NaN fails the comparison)
+            vunit = std::max(vunit, ab);
+        }
         double ecorr = 0, tsum = 0;
         for (int m = 0; m < T.count; ++m) {
             double sk = 0;
@@ -329,7 +333,9 @@ void EvalEngine::ensure_linear()
                 smax = std::max(smax, sc * s2);
                 s2max = std::max(s2max, s2);
             }
-            ecorr += smax * sk * 58.0;
+            // (+ 24 u v sum|k|: the host's fp32 sum of the 25 taps that multiplies the mean, kp[12].y in ensure_tiles, carries up to
+            // 24 roundings of partial sums <= sum|k|, times a mean <= v)
+            ecorr += smax * sk * (58.0 + 24.0);
             tsum += s2max;
         }
         const double black = std::max(1e-30, (double)std::fabs(T.blackScore));

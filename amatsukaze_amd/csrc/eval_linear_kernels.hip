@@ -399,11 +399,11 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void analysis_mark_kernel(const float* __restrict__ rec, int stride, int nframes, int ngroups, int nfades, float eps0, float eps1, float eps2,
-                          int* __restrict__ list, int* __restrict__ count)
+                          int* __restrict__ list, int* __restrict__ count, const uint8_t* __restrict__ force)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nframes) return;
-    bool amb = false;
+    bool amb = force != nullptr && force[n] != 0;          // frames the error bound does not cover (out-of-range samples): always exact
     for (int k = 0; k < ngroups; ++k) {
         const float eps = k == 0 ? eps0 : (k == 1 ? eps1 : eps2);
         const float* p = rec + (long long)n * stride + k * nfades;
@@ -421,13 +421,46 @@ void analysis_mark_kernel(const float* __restrict__ rec, int stride, int nframes
 }
 
 hipError_t launch_analysis_mark(hipStream_t st, const float* drec, int stride, int nframes, int ngroups, int nfades, const float* eps3,
-                                int* dlist, int* dcount)
+                                int* dlist, int* dcount, const uint8_t* dforce)
 {
     if (nframes <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(dcount, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(analysis_mark_kernel, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, st, drec, stride, nframes, ngroups, nfades,
-                       eps3[0], eps3[1], eps3[2], dlist, dcount);
+                       eps3[0], eps3[1], eps3[2], dlist, dcount, dforce);
+    return hipGetLastError();
+}
+
+// The linear mode's error bound (and with it the margin of the bin test and of the decision guard) assumes every sample <= maxv.  A 10-
+// or 12-bit clip lives in 16-bit containers and may carry larger values (the erase path clamps them, LogoScan.hpp:1258; the analysis does
+// not): one workgroup per frame looks at the logo rectangle -- all the analysis reads, 64 KB at the bench shape -- and flags the frame
+// when a sample exceeds maxv; analysis_mark_kernel then hands it to the exact kernel whatever its scores say.  Not launched at 8 and
+// 16 bits, where every container value is in range.
+__global__ __launch_bounds__(256)
+void rect_range_flag_kernel(const uint16_t* __restrict__ Y, long long frame_stride, int pitch, int imgx, int imgy, int w, int h, unsigned maxv,
+                            uint8_t* __restrict__ flag)
+{
+    const uint16_t* p = Y + (long long)blockIdx.x * frame_stride + (long long)imgy * pitch + imgx;
+    unsigned m = 0;
+    // rectangle origin and width are even (LogoScan.hpp:69): two samples per 32-bit load
+    const int pairs = w >> 1;
+    for (int i = threadIdx.x; i < pairs * h; i += 256) {
+        const int y = i / pairs, x = i - y * pairs;
+        const unsigned v = *reinterpret_cast<const unsigned __attribute__((aligned(2)))*>(p + (long long)y * pitch + 2 * x);
+        m = max(m, max(v & 0xFFFFu, v >> 16));
+    }
+    if (w & 1)
+        for (int y = threadIdx.x; y < h; y += 256) m = max(m, (unsigned)p[(long long)y * pitch + w - 1]);
+    const int any = __syncthreads_or(m > maxv);
+    if (threadIdx.x == 0) flag[blockIdx.x] = any ? 1 : 0;
+}
+
+hipError_t launch_rect_range_flag(hipStream_t st, const void* dY, long long frame_stride_elems, int pitch, int imgx, int imgy, int w, int h, int bits,
+                                  int nframes, uint8_t* dflag)
+{
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rect_range_flag_kernel, dim3((unsigned)nframes), dim3(256), 0, st, (const uint16_t*)dY, frame_stride_elems, pitch, imgx, imgy, w, h,
+                       (unsigned)((1 << bits) - 1), dflag);
     return hipGetLastError();
 }
 

@@ -248,3 +248,32 @@ def test_linear_mode_takes_wide_logos(gpu):
     assert got.shape == want.shape == (N, 33)
     for k in range(3):
         assert np.abs(got - want)[:, 11 * k:11 * k + 11].max() <= an.error_bound(k, 8) * max(1.0, float(np.abs(want).max()))
+
+
+def test_linear_mode_hands_out_of_range_samples_to_the_exact_kernel(gpu):
+    """A 10-bit clip in 16-bit containers may carry values above 1023; the linear mode's error bound (and the margins of its bin test and
+    decision guard) assume samples <= maxv, so frames whose logo rectangle holds such a sample are re-evaluated by the exact kernel
+    whatever their scores say: their records are the exact mode's bytes, and the guard counts them."""
+    from amatsukaze_amd import AMTAnalyzeLogo, DeviceClip
+    torch = gpu["torch"]
+    cfg = dict(W=352, H=240, LW=96, LH=48, IMGX=224, IMGY=18, N=24, period=6, fade=3, flat=3)
+    cs = make_case(gpu, cfg, bits=10, pitch_pad=32)
+    dc = cs["dclip"]
+    Y = dc.Y.clone()
+    dirty = [3, 4, 11, 23]
+    for n in dirty:                                   # one sample inside the rectangle above maxv (and one outside it, which nothing reads)
+        Y[n, cfg["IMGY"] + 5 + n % 7, cfg["IMGX"] + 9 + 2 * n] = 3000 + n
+    Y[7, 2, 3] = 4000
+    clip = DeviceClip(Y, dc.U, dc.V, dc.width, dc.height, 10)
+    exact = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35).analyze(clip)
+    an = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35, mode="linear")
+    got = an.analyze(clip)
+    assert an.last_refined() >= len(dirty)
+    for n in dirty:
+        assert got[n].tobytes() == exact[n].tobytes(), n
+    clean = [n for n in range(cfg["N"]) if n not in dirty]
+    assert np.abs(got[clean] - exact[clean]).max() <= 1e-4
+    # an 8-bit clip never pays for the pre-pass and a clean 10-bit clip is not sent to the exact kernel wholesale
+    an2 = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35, mode="linear")
+    an2.analyze(cs["dclip"])
+    assert an2.last_refined() < cfg["N"] // 2
