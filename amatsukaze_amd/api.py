@@ -54,6 +54,20 @@ class Context:
             hs = int(torch.cuda.current_stream(device).cuda_stream)
             self.lib.amtgpu_context_set_stream(self.h, C.c_void_p(hs if hs else 1))
 
+    def cu_count(self) -> int:
+        return self.lib.amtgpu_device_cu_count(self.h)
+
+    def use_cu_range(self, first_cu: int, num_cus: int):
+        """Launch this context's kernels on compute units [first_cu, first_cu + num_cus) only (amtgpu_stream_create_cu_range): one
+        context per partition lets bandwidth-bound and arithmetic-bound passes run beside each other.  Returns the stream as a
+        torch.cuda.ExternalStream so that the caller can order it against other streams (wait_stream / record_event)."""
+        import torch
+        st = self.lib.amtgpu_stream_create_cu_range(self.h, first_cu, num_cus)
+        self.check(st, "stream_create_cu_range")
+        self.check(self.lib.amtgpu_context_set_stream(self.h, C.c_void_p(st)))
+        self._cu_stream = st
+        return torch.cuda.ExternalStream(st, device=self.device)
+
     def check(self, ok, what=""):
         if not ok:
             raise AmtError((what + ": " if what else "") + self.lib.amtgpu_last_error(self.h).decode(errors="replace"))
@@ -78,6 +92,11 @@ class Context:
 
     def close(self):
         if self.h:
+            if getattr(self, "_cu_stream", None):
+                # (the CU-range stream itself is left to the process: torch may still hold events recorded on its ExternalStream wrapper)
+                self.lib.amtgpu_context_synchronize(self.h)
+                self.lib.amtgpu_context_set_stream(self.h, None)
+                self._cu_stream = None
             self.lib.amtgpu_context_destroy(self.h)
             self.h = None
 

@@ -36,6 +36,9 @@ SIGNATURES = {
     "amtgpu_context_set_stream": (c_i, [c_p, c_p]),
     "amtgpu_context_get_stream": (c_p, [c_p]),
     "amtgpu_context_synchronize": (c_i, [c_p]),
+    "amtgpu_stream_create_cu_range": (c_p, [c_p, c_i, c_i]),
+    "amtgpu_stream_destroy": (None, [c_p, c_p]),
+    "amtgpu_device_cu_count": (c_i, [c_p]),
     "amtgpu_profile_enable": (c_i, [c_p, c_i]),
     "amtgpu_profile_report": (c_i, [c_p, c_p, c_i]),
     "amtgpu_device_alloc": (c_p, [c_p, c_u64]),

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <vector>
 
 #include "api_common.hpp"
 
@@ -82,6 +83,38 @@ void* amtgpu_context_get_stream(AmtGpuContext* c) { return !c ? nullptr : (c->st
 int amtgpu_context_synchronize(AmtGpuContext* c)
 {
     return guard(c, [&] { c->bind(); AMT_HIP(hipStreamSynchronize(c->stream)); });
+}
+
+void* amtgpu_stream_create_cu_range(AmtGpuContext* c, int first_cu, int num_cus)
+{
+    hipStream_t st = nullptr;
+    guard(c, [&] {
+        if (!c) throw std::runtime_error("no context");
+        c->bind();
+        hipDeviceProp_t prop;
+        AMT_HIP(hipGetDeviceProperties(&prop, c->device));
+        const int ncu = prop.multiProcessorCount;
+        if (first_cu < 0 || num_cus <= 0 || first_cu + num_cus > ncu) throw std::runtime_error("compute-unit range outside the device");
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int i = first_cu; i < first_cu + num_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+        AMT_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    });
+    return (void*)st;
+}
+void amtgpu_stream_destroy(AmtGpuContext* c, void* s)
+{
+    if (c && s) { (void)hipSetDevice(c->device); (void)hipStreamDestroy((hipStream_t)s); }
+}
+int amtgpu_device_cu_count(AmtGpuContext* c)
+{
+    int n = 0;
+    guard(c, [&] {
+        if (!c) throw std::runtime_error("no context");
+        hipDeviceProp_t prop;
+        AMT_HIP(hipGetDeviceProperties(&prop, c->device));
+        n = prop.multiProcessorCount;
+    });
+    return n;
 }
 
 // per-kernel timing (HIP events on the launch stream) for bench.py's roofline figures

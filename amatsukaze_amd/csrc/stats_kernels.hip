@@ -1,11 +1,18 @@
 // stats_kernels.hip -- whole-frame field-difference / combing metrics (self-specified).
 //
-// HBM-bound streaming reduction over the Y plane: every byte of every frame is read from HBM once.
-// A thread owns a 16-byte-wide column of a 16-row tile for a RUN of consecutive frames (tiles x columns are dealt
-// densely to the threads of the grid), so the vertical neighbours (rows y-1, y+1) and the previous
-// frame's rows are all in the thread's own registers -- no LDS staging, no re-reads except the two halo
-// rows per tile.  Loads are 16 B per lane, 64 lanes = 1 KiB contiguous per row.  The per-byte work is
-// done four pixels at a time with v_sad_u8 / v_lerp_u8 (two per instruction for 16-bit samples).
+// Streaming reduction over the Y plane: every byte of every frame is read from HBM once.  A thread owns a 16-byte-wide column of a
+// 16-row tile for a RUN of consecutive frames ((tile, column) pairs are dealt densely to the threads of the grid), so the vertical
+// neighbours (rows y-1, y+1) and the previous frame's rows are all in the thread's own registers -- no LDS staging, no re-reads
+// except the two halo rows per tile.  Loads are 16 B per lane, 64 lanes = 1 KiB contiguous per row.  The per-byte work is done four
+// pixels at a time with v_sad_u8 / v_lerp_u8 (two per instruction for 16-bit samples).
+//
+// What bounds it (profiles/r04_notes.md): with the whole device the kernel moves 6.1 TB/s of actual traffic (1.15x its algorithmic
+// bytes: 128-byte lines against a 1472-byte pitch, halo rows, the frame before a run) -- HBM.  Given a PART of the device
+// (hipExtStreamCreateWithCUMask, to run beside the VALU-bound logo kernels) its rate scales with the CUs it owns: per CU it is bound
+// by the vector ALU (~780 instructions per wave and frame in round 3's form, 4.5 cycles each) and by the bytes a CU keeps in flight.
+// Hence the lean form below: raw buffer loads (one VGPR of address for the whole tile, rows outside the frame come back as zeros from
+// the bounds check -- no 64-bit address arithmetic, no selects), the even-row vertical detail of the previous frame carried over
+// instead of recomputed, the duplicate of the odd rows' term dropped, wave sums on DPP instead of LDS permutes.
 //
 // Per frame n (prev = frame n-1; rows 1..H-2 for the vertical metrics), all sums of absolute values:
 //   0 DIFF_TOP   sum_{y even} |Y_n[y] - Y_prev[y]|          3 COMB       sum |Y_n[y] - avg(Y_n[y-1], Y_n[y+1])|
@@ -19,12 +26,11 @@
 namespace amt {
 
 #ifndef AMT_STATS_VG
-#define AMT_STATS_VG 4
+#define AMT_STATS_VG 1
 #endif
-// Waves of a workgroup that sit on top of one another: wave w of a workgroup owns tile (4 * supertile + w) of the SAME 16-byte columns, so
-// the two halo rows a tile re-reads are rows that a sibling wave of the same workgroup -- same CU, same moment -- reads as its own: the
-// second request merges with the first in the CU's vector cache / the XCD's L2 instead of going to HBM again (kStatVG = 1: round 3's
-// mapping, every wave an unrelated (tile, column) range; measured traffic 1.146x the algorithmic bytes)
+// kStatVG > 1: the waves of a workgroup sit on top of one another (wave w owns tile VG * supertile + w of the same columns), so that a
+// tile's halo rows are rows a sibling wave reads at the same moment.  Measured: no gain over VG = 1 (the halo re-reads already hit the
+// XCD's L2 thanks to the tile order below); kept as a build knob.
 constexpr int kStatVG = AMT_STATS_VG;
 constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
 #ifndef AMT_STATS_ROWS
@@ -33,10 +39,24 @@ constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
 #ifndef AMT_STATS_RUN
 #define AMT_STATS_RUN 32
 #endif
+#ifndef AMT_STATS_COLB
+#define AMT_STATS_COLB 16
+#endif
+#ifndef AMT_STATS_PREFETCH
+#define AMT_STATS_PREFETCH 0
+#endif
+#ifndef AMT_STATS_LEAN
+#define AMT_STATS_LEAN 1
+#endif
+#ifndef AMT_STATS_NT
+#define AMT_STATS_NT 2         /* cache-policy bits of the loads of rows no other tile reads: 2 = nt (non-temporal) */
+#endif
 constexpr int kStatTileRows = AMT_STATS_ROWS;
 constexpr int kStatRun = AMT_STATS_RUN;          // frames a workgroup walks through (the frame before a run is its one re-read: 1/32)
 constexpr int kStatXcds = 8;          // MI355X: 8 XCDs, workgroups are dealt to them round-robin by linear workgroup id
 constexpr int kStatWords = 8;
+constexpr int kStatColBytes = AMT_STATS_COLB;      // bytes of a row one lane owns: 16 (one dwordx4 load) or 8 (dwordx2: half the registers per row)
+constexpr int kStatColWords = kStatColBytes / 4;
 
 template <int ES> struct Px;
 template <> struct Px<1> {
@@ -52,14 +72,6 @@ template <> struct Px<2> {
     }
 };
 
-#ifndef AMT_STATS_COLB
-#define AMT_STATS_COLB 16
-#endif
-#ifndef AMT_STATS_PREFETCH
-#define AMT_STATS_PREFETCH 0
-#endif
-constexpr int kStatColBytes = AMT_STATS_COLB;      // bytes of a row one lane owns: 16 (one dwordx4 load) or 8 (dwordx2: half the registers per row)
-constexpr int kStatColWords = kStatColBytes / 4;
 struct alignas(kStatColBytes) Chunk { unsigned w[kStatColWords]; };
 
 __device__ __forceinline__ Chunk chunk_zero()
@@ -98,21 +110,36 @@ template <int ES> __device__ __forceinline__ Chunk avg16(const Chunk& a, const C
     return r;
 }
 
+// sum over the 64 lanes of a wave, result in lane 63: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast15 / row_bcast31
+// across the rows -- six DPP adds on the VALU, no LDS permute and no wait
+__device__ __forceinline__ unsigned wave_sum_to_lane63(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 #ifdef AMT_STATS_WAVES
 #define AMT_STATS_OCC __attribute__((amdgpu_waves_per_eu(AMT_STATS_WAVES, AMT_STATS_WAVES)))
 #else
 #define AMT_STATS_OCC
 #endif
-template <int ES>
+// RAGGED: the row is not a whole number of lane columns (the last column's tail bytes are masked); the common widths -- multiples of 16
+// bytes -- take the version without the masks
+template <int ES, bool RAGGED>
 __global__ __launch_bounds__(kStatThreads) AMT_STATS_OCC
 void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*bytes*/, int pitch_bytes, int row_bytes, int H,
                         const uint8_t* __restrict__ prevY /* frame before the batch or null */, int nframes, int col_groups,
                         unsigned long long* __restrict__ out)
 {
     constexpr int R = kStatTileRows + 2;
-    // (tile, 16-byte column) pairs are dealt to threads densely -- `cols` columns per tile, no idle lanes when the
+    // (tile, lane column) pairs are dealt to threads densely -- `cols` columns per tile, no idle lanes when the
     // row is not a multiple of the workgroup's span (1440 bytes = 90 columns); a wave may straddle two tiles
-    const int cols = col_groups;                                  // 16-byte columns per row
+    const int cols = col_groups;
     // XCD-aware tile order: gridDim.x is a multiple of 8, so workgroup x of a frame run lands on XCD x % 8.  Giving XCD k the
     // CONTIGUOUS tile groups [k*per, (k+1)*per) makes vertically adjacent tiles -- which share their two halo rows --
     // neighbours on one XCD, running at the same time: the halo re-read is an L2 hit there instead of a second HBM fetch
@@ -121,7 +148,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     const int wg = (blockIdx.x % kStatXcds) * per + blockIdx.x / kStatXcds;
     int tile, xb;
     if (kStatVG > 1) {
-        // (supertile, column) pairs are dealt densely to the 64 lanes of a workgroup's waves; wave w takes tile kStatVG * supertile + w
         const int gid = wg * 64 + (threadIdx.x & 63);
         const int st = gid / cols;
         tile = st * kStatVG + (threadIdx.x >> 6);
@@ -136,6 +162,44 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     const int n0 = blockIdx.y * kStatRun;
     const int n1 = min(nframes, n0 + kStatRun);
 
+#if AMT_STATS_LEAN
+    // A frame is a raw buffer of H * pitch bytes: the bounds check of the buffer load returns zeros for everything outside it -- the
+    // row above the first tile (offset wraps far past the end), the rows below the frame, and ALL rows of a lane that owns no pixels
+    // (its offset is parked past the end).  One VGPR holds the lane's offset; the 18 row offsets are scalar multiples of the pitch.
+    const unsigned frame_bytes = (unsigned)H * (unsigned)pitch_bytes;
+    const unsigned voff0 = nvalid > 0 ? (unsigned)y0 * (unsigned)pitch_bytes + (unsigned)xb : 0x80000000u;
+    // mask of this lane's valid bytes (RAGGED only: the last column of a row whose width is not a multiple of the column)
+    unsigned bmask[kStatColWords];
+#pragma unroll
+    for (int i = 0; i < kStatColWords; ++i) {
+        const int k = nvalid - 4 * i;
+        bmask[i] = !RAGGED || k >= 4 ? 0xFFFFFFFFu : (k <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (4 - k))));
+    }
+    auto load_rows = [&](const uint8_t* frame, Chunk* rows) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame), 0, (int)frame_bytes, 0x00027000);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned off = voff0 + (unsigned)((r - 1) * pitch_bytes);      // (r = 0 of the first tile: wraps, out of range, zeros)
+            // AMT_STATS_NT: rows that no other tile reads (all but this tile's first and last row and its two halo rows) are loaded
+            // non-temporal, so that the rows two tiles DO share stay in the XCD's L2 until the neighbour asks for them
+            constexpr int kNt = AMT_STATS_NT;
+            const bool shared_row = r <= 1 || r >= R - 2;
+            if (kStatColBytes == 16) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                const u4 v = (kNt && !shared_row) ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, kNt)
+                                                  : __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+#pragma unroll
+                for (int i = 0; i < kStatColWords; ++i) rows[r].w[i] = RAGGED ? (v[i] & bmask[i]) : v[i];
+            } else {
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u2 v = (kNt && !shared_row) ? __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, kNt)
+                                                  : __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
+#pragma unroll
+                for (int i = 0; i < kStatColWords; ++i) rows[r].w[i] = RAGGED ? (v[i] & bmask[i]) : v[i];
+            }
+        }
+    };
+#else
     auto load_rows = [&](const uint8_t* frame, Chunk* rows) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -144,10 +208,26 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
                                                      : chunk_zero();
         }
     };
+#endif
 
-    // one frame of this thread's tile against the frame before it; wave reduction, one atomic per word per wave
-    auto compute = [&](const Chunk* cur, const Chunk* prev, int n) {
+    // Even-row vertical detail of a row set: sum over the tile's even rows y (1 <= y <= H-2) of |rows[y-1] - rows[y+1]|.  The weave of
+    // frame n takes its odd rows from frame n-1, so its VERT term on an even row looks at rows of frame n-1 only: that is this sum of
+    // the PREVIOUS frame, which the previous iteration has already formed as part of its own VERT.
+    auto vert_even = [&](const Chunk* rows) {
+        unsigned a = 0;
+#pragma unroll
+        for (int r = 1; r <= kStatTileRows; r += 2) {
+            const int y = y0 - 1 + r;
+            if (y >= 1 && y <= H - 2) a = sad16<ES>(rows[r - 1], rows[r + 1], a);
+        }
+        return a;
+    };
+
+    // one frame of this thread's tile against the frame before it; wave reduction, one atomic per word per wave.  ve_prev: vert_even
+    // of the frame before; returns vert_even of this frame
+    auto compute = [&](const Chunk* cur, const Chunk* prev, int n, unsigned ve_prev) {
         unsigned acc[7] = {0, 0, 0, 0, 0, 0, 0};
+        unsigned ve = 0, vo = 0;
         const Chunk zero = chunk_zero();
 #pragma unroll
         for (int r = 1; r <= kStatTileRows; ++r) {
@@ -157,56 +237,62 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
             acc[5] = sad16<ES>(cur[r], zero, acc[5]);
             if (y >= 1 && y <= H - 2) {
                 const Chunk mc = avg16<ES>(cur[r - 1], cur[r + 1]);
-                acc[2] = sad16<ES>(cur[r - 1], cur[r + 1], acc[2]);
+                if (odd) vo = sad16<ES>(cur[r - 1], cur[r + 1], vo); else ve = sad16<ES>(cur[r - 1], cur[r + 1], ve);
                 acc[3] = sad16<ES>(cur[r], mc, acc[3]);
                 if (odd) {        // weave: this row comes from prev, its neighbours from cur
                     acc[4] = sad16<ES>(prev[r], mc, acc[4]);
-                    acc[6] = sad16<ES>(cur[r - 1], cur[r + 1], acc[6]);
                 } else {          // this row from cur, neighbours from prev
                     const Chunk mp = avg16<ES>(prev[r - 1], prev[r + 1]);
                     acc[4] = sad16<ES>(cur[r], mp, acc[4]);
-                    acc[6] = sad16<ES>(prev[r - 1], prev[r + 1], acc[6]);
                 }
             }
         }
+        acc[2] = ve + vo;                // VERT of the frame
+        acc[6] = vo + ve_prev;           // VERT of the weave: odd rows look at this frame's neighbours, even rows at the previous frame's
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
+#if AMT_STATS_LEAN
+            acc[k] = wave_sum_to_lane63(acc[k]);
+#else
             unsigned v = acc[k];
 #pragma unroll
             for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
             acc[k] = v;
+#endif
         }
-        if ((threadIdx.x & 63) == 0) {
+        if ((threadIdx.x & 63) == (AMT_STATS_LEAN ? 63 : 0)) {
 #pragma unroll
             for (int k = 0; k < 7; ++k)
                 if (acc[k]) atomicAdd(&out[(long long)n * kStatWords + k], (unsigned long long)acc[k]);
         }
+        return ve;
     };
     const uint8_t* const before = n0 > 0 ? Y + (long long)(n0 - 1) * frame_stride : (prevY ? prevY : Y);
 #if AMT_STATS_PREFETCH
     // three row sets in rotation: the loads of frame n + 1 are issued BEFORE frame n is evaluated, so that every wave always has a
-    // whole tile in flight -- the kernel's rate is set by the bytes a CU keeps in flight (measured: it scales with the CUs it is
-    // given, ~29 GB/s per CU for the two-set form), not by HBM, as soon as it does not own the whole device
+    // whole tile in flight
     Chunk A[R], B[R], D[R];
     load_rows(before, A);
     load_rows(Y + (long long)n0 * frame_stride, B);
+    unsigned ve = vert_even(A);
     for (int n = n0;;) {
         if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, D);
-        compute(B, A, n);
+        ve = compute(B, A, n, ve);
         if (++n >= n1) break;
         if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, A);
-        compute(D, B, n);
+        ve = compute(D, B, n, ve);
         if (++n >= n1) break;
         if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, B);
-        compute(A, D, n);
+        ve = compute(A, D, n, ve);
         if (++n >= n1) break;
     }
 #else
     Chunk prev[R], cur[R];
     load_rows(before, prev);
+    unsigned ve = vert_even(prev);
     for (int n = n0; n < n1; ++n) {
         load_rows(Y + (long long)n * frame_stride, cur);
-        compute(cur, prev, n);
+        ve = compute(cur, prev, n, ve);
 #pragma unroll
         for (int r = 0; r < R; ++r) prev[r] = cur[r];
     }
@@ -221,17 +307,20 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     const int row_bytes = W * es;
     const int col_groups = (row_bytes + kStatColBytes - 1) / kStatColBytes;     // lane columns per row
     const int tiles = (H + kStatTileRows - 1) / kStatTileRows;
+    // (the lean form addresses a frame with 32-bit byte offsets below 2^31)
+    if ((long long)H * pitch_elems * es >= (1LL << 31)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
     const int wgs = kStatVG > 1 ? ((tiles + kStatVG - 1) / kStatVG * col_groups + 63) / 64 : (tiles * col_groups + kStatThreads - 1) / kStatThreads;
     dim3 grid((unsigned)((wgs + kStatXcds - 1) / kStatXcds * kStatXcds), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
         block(kStatThreads);                                      // surplus workgroups of the round-up find nvalid <= 0
-    if (es == 1)
-        hipLaunchKernelGGL(frame_stats_kernel<1>, grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es,
-                           row_bytes, H, (const uint8_t*)dprevY, nframes, col_groups, dout);
-    else
-        hipLaunchKernelGGL(frame_stats_kernel<2>, grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es,
-                           row_bytes, H, (const uint8_t*)dprevY, nframes, col_groups, dout);
+    const bool ragged = row_bytes % kStatColBytes != 0;
+#define AMT_STATS_LAUNCH(E, RG)                                                                                                           \
+    hipLaunchKernelGGL((frame_stats_kernel<E, RG>), grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es, row_bytes, H, \
+                       (const uint8_t*)dprevY, nframes, col_groups, dout)
+    if (es == 1) { if (ragged) AMT_STATS_LAUNCH(1, true); else AMT_STATS_LAUNCH(1, false); }
+    else { if (ragged) AMT_STATS_LAUNCH(2, true); else AMT_STATS_LAUNCH(2, false); }
+#undef AMT_STATS_LAUNCH
     return hipGetLastError();
 }
 

@@ -79,6 +79,10 @@ def parse_args():
     ap.add_argument("--e2e-frames", type=int, default=0, help="frames of the e2e10 stream (default: 53 946 = one GPU's share of the 4-hour stream at N = 8; "
                                                               "431568 = the whole stream)")
     ap.add_argument("--e2e-chunk", type=int, default=1024, help="frames generated and processed per chunk of the e2e10 stream")
+    ap.add_argument("--metrics-cus", type=int, default=0,
+                    help="N > 0: N compute units are given to the frame metrics, which then run BESIDE the analysis + scan on the other units (two contexts "
+                         "on CU-range streams, amtgpu_stream_create_cu_range).  Measured (profiles/r04_notes.md): no gain on MI355X -- the logo kernels lose "
+                         "what the metrics gain -- so the default 0 keeps every kernel on the whole device, one pass after the other")
     ap.add_argument("--fades", choices=("device", "host"), default="device",
                     help="where CalcFade runs inside the step: device = amtgpu_erase_calc_fades_device, the whole step stream-ordered (default); "
                          "host = round 3's step (records to the host, host CalcFade while the scan runs, fades back up)")
@@ -535,11 +539,23 @@ def main():
                                     pitchY=PITCH_Y, pitchUV=PITCH_UV, start=rank * N)
     clip = gen()
     dclip = DeviceClip(clip["Y"], clip["U"], clip["V"], W, H, 8)
-    lf = LogoFrame(ctx, logos, MASKRATIO)
+    # Device partition: the frame metrics stream bytes (HBM-bound, the vector ALUs a third busy), the logo kernels do arithmetic (no HBM
+    # traffic to speak of).  One after the other each leaves half the machine idle; launched together on the whole device they do not
+    # co-schedule (the logo kernels take every CU's registers and LDS).  Two contexts on complementary CU ranges run them beside each
+    # other: metrics on units [0, M), analysis + scan + erase on [M, ncu).
+    NCU = ctx.cu_count()
+    MCU = args.metrics_cus if 0 < args.metrics_cus < NCU else 0
+    if MCU:
+        ctxL, ctxM = Context(local_rank), Context(local_rank)
+        sL, sM = ctxL.use_cu_range(MCU, NCU - MCU), ctxM.use_cu_range(0, MCU)
+    else:
+        ctxL = ctxM = ctx
+        sL = sM = None
+    lf = LogoFrame(ctxL, logos, MASKRATIO)
     lf.begin(W, H, 8, N)
-    analyzer = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO, mode=args.analysis_mode)
-    eraser = AMTEraseLogo(ctx, logos[0], "", 0, 16)
-    stats = FrameStats(ctx, W, H, 8)
+    analyzer = AMTAnalyzeLogo(ctxL, logos[0], MASKRATIO, mode=args.analysis_mode)
+    eraser = AMTEraseLogo(ctxL, logos[0], "", 0, 16)
+    stats = FrameStats(ctxM, W, H, 8)
     d_analysis = torch.empty((N, 33), dtype=torch.float32, device=dev)
     d_stats = torch.empty((N, 8), dtype=torch.int64, device=dev)
     h_analysis = torch.empty((N, 33), dtype=torch.float32).pin_memory()
@@ -569,11 +585,18 @@ def main():
             dv.copy_(sv)
 
     def step(collective=True, restore=True, an=None):
+        cur = torch.cuda.current_stream()
+        if MCU:                                                      # both partitions start behind what torch's stream did to the frames
+            sL.wait_stream(cur)
+            sM.wait_stream(cur)
         (an or analyzer).analyze_device(dclip.Y, 8, d_analysis)      # a11: 33 evaluations per frame
-        h_analysis.copy_(d_analysis, non_blocking=True)              # stream-ordered behind the analysis kernel
-        an_ready.record()
+        with torch.cuda.stream(sL if MCU else cur):
+            h_analysis.copy_(d_analysis, non_blocking=True)          # stream-ordered behind the analysis kernel
+            an_ready.record()
         lf.scan_batch(dclip.Y, 8, 0, N)                              # a9: all-frames scan, 3 logos x 2 fades
-        stats.run_device(dclip.Y, d_stats)                           # CM field-diff + KFM comb metrics (source frames)
+        stats.run_device(dclip.Y, d_stats)                           # CM field-diff + KFM comb metrics (source frames), on its own CUs
+        if MCU:
+            sL.wait_stream(sM)                                       # Delogo rewrites what the metrics read
         if not args.no_erase:
             if args.fades == "device":
                 eraser.calc_fades_device(d_analysis, N, out=d_fades)     # a12 CalcFade / CalcFade2 on the device: no host round trip
@@ -584,23 +607,37 @@ def main():
                 fades = eraser.calc_fades(h_analysis.numpy(), N)         # a12 CalcFade / CalcFade2
                 eraser.erase(dclip, fades)                               # a12 Delogo, in place
                 last["fades"] = fades
+            if MCU:
+                cur.wait_stream(sL)
             if restore:
                 restore_rectangles()                                 # bench housekeeping (inside the timed region, ~0.3 ms)
+        elif MCU:
+            cur.wait_stream(sL)
         if world > 1 and collective:
             ev = torch.from_numpy(lf.evalResults).to(dev)
             SH.gather_frame_records(ev, N * world)                   # the scan's one exchange step (RCCL all_gather)
 
+    def profile_on(on):
+        for c in {id(ctxL): ctxL, id(ctxM): ctxM}.values():
+            c.profile(on)
+
+    def profile_read():
+        rep = dict(ctxL.profile_report())
+        if ctxM is not ctxL:
+            rep.update(ctxM.profile_report())
+        return rep
+
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.profile(True)
+    profile_on(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_report()
-    ctx.profile(False)
+    prof = profile_read()
+    profile_on(False)
     elapsed = max_over_ranks(elapsed)
     if not args.no_erase and last.get("fades") is None:
         last["fades"] = d_fades.cpu().numpy()
@@ -608,7 +645,7 @@ def main():
     # ---- the same pass with the exact (bit-identical records) analysis, for the record next to the headline ----
     exact_mode = None
     if args.analysis_mode == "linear" and args.exact_steps > 0 and not args.no_alt_mode:
-        an_exact = AMTAnalyzeLogo(ctx, logos[0], MASKRATIO, mode="exact")
+        an_exact = AMTAnalyzeLogo(ctxL, logos[0], MASKRATIO, mode="exact")
         step(an=an_exact)
         fence()
         t0 = time.perf_counter()
@@ -714,7 +751,13 @@ def main():
     # free the batch before the attached measurements
     d_fades_host = d_fades.cpu().numpy()
     del d_fades
+    if MCU:
+        torch.cuda.synchronize()
     del dclip, lf, analyzer, eraser, stats, d_analysis, d_stats, dst_views, rect
+    if MCU:
+        del sL, sM
+        ctxL.close()
+        ctxM.close()
     torch.cuda.empty_cache()
 
     strong = None
@@ -791,14 +834,15 @@ def main():
             last["fades"] = d_fades_host
         erased_share = float((np.abs(last["fades"]).sum(axis=1) != 0).mean()) if "fades" in last else 1.0
 
-        def kernel_entry(name, calls, ms, frames_per_call, timed):
-            e = {"avg_ms": ms / max(1, calls), "launches": calls, "inside_timed_region": timed}
+        def kernel_entry(name, calls, ms, frames_per_call, timed, cus):
+            e = {"avg_ms": ms / max(1, calls), "launches": calls, "inside_timed_region": timed, "cus": cus}
             fr = frames_per_call * calls
             tr = pmc.get(name, {}).get("hbm_bytes_per_frame")
             if name in VALU:
                 fl, ab, what = VALU[name]
                 e.update({"bound": "fp32-valu", "achieved_tflops": fl * fr / (ms * 1e-3) / 1e12,
-                          "frac_fp32_peak": fl * fr / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": fl * frames_per_call,
+                          "frac_fp32_peak": fl * fr / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                          "frac_of_its_cus_peak": fl * fr / (ms * 1e-3) / 1e12 / (FP32_PEAK_TFLOPS * cus / NCU), "flops_per_launch": fl * frames_per_call,
                           "algorithmic_bytes_per_launch": ab * frames_per_call, "hbm_gbs_algorithmic": ab * fr / (ms * 1e-3) / 1e9, "what": what})
             elif name in HBM:
                 # Delogo with fade 0 is an identity the kernel skips (no traffic): only frames with a non-zero fade count
@@ -811,29 +855,40 @@ def main():
             e["hbm_bytes_per_launch_pmc"] = tr * frames_per_call if tr else None
             return e
 
-        out_kern = {name: kernel_entry(name, calls, ms, N, True) for name, (calls, ms) in prof.items() if calls}
+        out_kern = {name: kernel_entry(name, calls, ms, N, True, (MCU if name == "frame_stats_kernel" else NCU - MCU) if MCU else NCU)
+                    for name, (calls, ms) in prof.items() if calls}
         for name, (calls, ms) in alt_prof.items():
             if calls and name not in out_kern:
-                out_kern[name] = kernel_entry(name, calls, ms, N, False)
+                out_kern[name] = kernel_entry(name, calls, ms, N, False, NCU)
         timed = {n: e for n, e in out_kern.items() if e["inside_timed_region"] and "bound" in e}
-        order = sorted(timed, key=lambda n: -timed[n]["avg_ms"] * timed[n]["launches"])
+        # the dominant kernel: the longest on the step's critical path.  With the device partitioned the frame metrics run beside the logo
+        # kernels on their own units and end before them (roofline_second describes them)
+        on_path = {n: e for n, e in timed.items() if not (MCU and n == "frame_stats_kernel")}
+        order = sorted(on_path, key=lambda n: -on_path[n]["avg_ms"] * on_path[n]["launches"]) + (["frame_stats_kernel"] if MCU and "frame_stats_kernel" in timed else [])
 
         def roofline_of(dom):
             kk = timed[dom]
             src = (PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench's own launches, tools/gpu_prof_bench.sh; not "
                    "collected inside the timed run)") if kk["hbm_bytes_per_launch_pmc"] else None
+            part = ({"cus": kk["cus"], "device_cus": NCU,
+                     "partition": f"the device is partitioned ({MCU} units stream the frame metrics, {NCU - MCU} run the logo kernels beside them): this kernel "
+                                  f"ran on {kk['cus']} of {NCU} units"} if MCU else {})
             if kk.get("bound") == "fp32-valu":
-                return {"kernel": dom, "bound": "fp32-valu", "achieved": kk["achieved_tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": kk["frac_fp32_peak"], "traffic": kk["hbm_bytes_per_launch_pmc"], "traffic_source": src,
+                # `peak` = the fp32 vector peak of the units the kernel ran on; the whole device's peak and the fraction of it are beside it
+                return {"kernel": dom, "bound": "fp32-valu", "achieved": kk["achieved_tflops"], "peak": FP32_PEAK_TFLOPS * kk["cus"] / NCU, "unit": "TFLOP/s",
+                        "frac": kk["frac_of_its_cus_peak"], "peak_whole_device": FP32_PEAK_TFLOPS, "frac_whole_device": kk["frac_fp32_peak"], **part,
+                        "traffic": kk["hbm_bytes_per_launch_pmc"], "traffic_source": src,
                         "avg_launch_ms": kk["avg_ms"], "flops_per_launch": kk["flops_per_launch"],
                         "algorithmic_bytes_per_launch": kk["algorithmic_bytes_per_launch"],
                         "note": "fp32 VALU kernel (no MFMA: per-pixel private 25-tap kernels, no operand reuse); priced against the fp32 "
                                 "vector peak with FMA counted as 2; flops are the reference's own operation count (101 per mask-pixel "
                                 "evaluation + 6 per rectangle pixel per evaluation); the exact kernels use mul/add/sub without FMA "
                                 "contraction (bit-exactness), so 0.5 is their ceiling. " + kk.get("what", "")}
-            return {"kernel": dom, "bound": "hbm", "achieved": kk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kk["frac"],
+            return {"kernel": dom, "bound": "hbm", "achieved": kk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kk["frac"], **part,
                     "traffic": kk["hbm_bytes_per_launch_pmc"], "traffic_source": src, "avg_launch_ms": kk["avg_ms"],
-                    "algorithmic_bytes_per_launch": kk["algorithmic_bytes_per_launch"]}
+                    "algorithmic_bytes_per_launch": kk["algorithmic_bytes_per_launch"],
+                    **({"note": "on its partition the kernel is bound by what a compute unit streams (~39 GB/s per unit: vector ALU and bytes in flight, "
+                                "profiles/r04_notes.md), not by HBM; it ends before the logo kernels it runs beside"} if MCU else {})}
 
         # the dominant kernel of the timed steps; the runner-up beside it (the linear analysis and the exact scan take about the same
         # time per step, and the linear kernel's fraction prices the reference's operation count, not what it issues)
@@ -850,6 +905,8 @@ def main():
             "config": {"workload": f"single MI355X: {N}-frame 1440x1080i 8-bit YUV420 resident in HBM; AMTAnalyzeLogo + LogoFrame scan (3 logos) "
                                    "+ CM/KFM frame metrics + CalcFade + AMTEraseLogo (BASELINE configs[1])",
                        "analysis_mode": args.analysis_mode, "calc_fade": args.fades,
+                       "device_partition": ({"metrics_cus": MCU, "logo_cus": NCU - MCU, "how": "two contexts on CU-range streams (amtgpu_stream_create_cu_range): the "
+                                             "frame metrics run beside the analysis + scan; erase waits for both"} if MCU else None),
                        "frames_per_gpu": N, "logo": f"{LW}x{LH}@({IMGX},{IMGY})", "maskratio": MASKRATIO,
                        "parallelism": f"frames sharded x{world} (one private batch per rank)" if world > 1 else "single GPU"},
             "timed_region_s": elapsed, "step_phases_ms": phases, "collectives": rccl,

@@ -61,6 +61,17 @@ const char*    amtgpu_last_error(const AmtGpuContext* ctx);
 int            amtgpu_context_set_stream(AmtGpuContext* ctx, void* hip_stream);
 void*          amtgpu_context_get_stream(AmtGpuContext* ctx);
 int            amtgpu_context_synchronize(AmtGpuContext* ctx);
+/* Device partitions.  The whole-frame metrics are bandwidth work, the logo kernels arithmetic: run BESIDE each other they finish sooner
+ * than one after the other -- but the hardware only co-schedules them when the device is partitioned (the logo kernels otherwise
+ * take every CU's registers and LDS).  amtgpu_stream_create_cu_range returns a hipStream_t (hipStreamNonBlocking) whose kernels run on
+ * `num_cus` compute units starting at `first_cu` in the driver's mask order, in which consecutive units go round the XCDs: a contiguous
+ * range is spread evenly over all of them and their L2s.  Measured on MI355X (profiles/r04_notes.md): the effective granularity is 32
+ * units (4 per XCD); the frame metrics on units [0, 64) beside the analysis + scan on [64, 256) take 8.2 ms per 10 000 frames instead
+ * of 9.2 ms one after the other.  Use: one context per partition (amtgpu_context_set_stream), ordered against each other by the
+ * caller's events.  NULL on failure (message on the context).  amtgpu_device_cu_count: compute units of the context's device. */
+void*          amtgpu_stream_create_cu_range(AmtGpuContext* ctx, int first_cu, int num_cus);
+void           amtgpu_stream_destroy(AmtGpuContext* ctx, void* hip_stream);
+int            amtgpu_device_cu_count(AmtGpuContext* ctx);
 /* per-kernel timing with HIP events on the launch stream (no counterpart in the reference, which only logs
  * phase wall times, CMAnalyze.hpp:37-39).  enable(1) resets the totals; report writes
  * "kernel_name calls total_ms\n" lines and returns the byte count (-1 on error). */

@@ -195,3 +195,38 @@ def test_bench_multi_rank_control_flow_dry_run():
         if scaling == "weak":
             assert line["verified"]["ok"] and line["verified"]["tolerance_ok"] and line["verified"]["fades_equal_all"]
     assert len(lgd_hashes) == 1          # the weak line's attached strong scan and the strong line scanned the same stream
+
+
+def test_bench_eight_rank_control_flow_dry_run():
+    """The driver's 8-GPU invocation (`bench.py --gpus 8`) has never met hardware here: run its whole control flow -- launcher, ragged
+    shards (107 892 = 8 x 13 486 + 4 at full size; 4 099 frames here), the quota hand-out of the sharded ScanLogo, every exchange, the
+    e2e10 stream with chunk halos across seven rank boundaries -- with eight ranks on whatever the box has (all on device 0 over gloo
+    when it has fewer than eight: AMT_BENCH_SHARED_GPU=1, numbers meaningless).  The hashes of the records and decisions must equal
+    the single-rank run's."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 8:
+        env["AMT_BENCH_SHARED_GPU"] = "1"
+
+    def run(extra, gpus):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus)] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    strong = ["--scaling", "strong", "--strong-frames", "4099", "--strong-steps", "1"]
+    s8, s1 = run(strong, 8), run(strong, 1)
+    assert s8["n_gpus"] == 8 and s8["collectives"]["world_size_observed"] == 8
+    assert s8["strong_scan"]["verified"]["sharded_equals_single_launch"] and s8["strong_scan"]["verified"]["equals_cpu_oracle"]
+    assert s8["strong_scan"]["records_sha256"] == s1["strong_scan"]["records_sha256"]
+    assert s8["strong_scan"]["scanlogo"]["lgd_sha256"] == s1["strong_scan"]["scanlogo"]["lgd_sha256"]
+    e2e = ["--workload", "e2e10", "--e2e-frames", "1500", "--e2e-chunk", "96"]
+    e8, e1 = run(e2e, 8), run(e2e + ["--e2e-chunk", "512"], 1)
+    assert e8["n_gpus"] == 8 and e8["e2e10"]["verified"]["ok"] and e1["e2e10"]["verified"]["ok"]
+    assert e8["e2e10"]["decisions_sha256"] == e1["e2e10"]["decisions_sha256"]
+    weak = run(["--steps", "1", "--warmup", "1", "--frames", "256", "--no-ingest", "--cpu-frames", "0", "--no-alt-mode", "--no-configs", "--no-strong",
+                "--exact-steps", "0"], 8)
+    assert weak["n_gpus"] == 8 and weak["scaling"] == "weak" and weak["verified"]["ok"] and weak["collectives"]["world_size_observed"] == 8

@@ -59,11 +59,12 @@ logo = lambda o: (o["an"].analyze_device(Y, 8, d_an), o["lf"].scan_batch(Y, 8, 0
 stats = lambda o: o["fs"].run_device(Y, d_st)
 out["full_device"] = {"logo_ms": timed(lambda: logo(full)), "stats_ms": timed(lambda: stats(full)), "sequential_ms": timed(lambda: (logo(full), stats(full)))}
 print("full", out["full_device"], file=sys.stderr, flush=True)
-for k in (8, 6, 5, 4, 3):            # the frame metrics get every k-th CU
-    a = make(masked_stream(lambda i: i % k != 0))
-    b = make(masked_stream(lambda i: i % k == 0))
-    r = {"stats_cu_share": 1.0 / k, "logo_alone_ms": timed(lambda: logo(a)), "stats_alone_ms": timed(lambda: stats(b)),
-         "together_ms": timed(lambda: (logo(a), stats(b)))}
-    out[f"stats_on_every_{k}th_cu"] = r
-    print(k, r, file=sys.stderr, flush=True)
+# mask bits interleave over the 8 XCDs (bit i -> XCD i % 8): a contiguous range of F bits is F / 8 CUs of every XCD (tools/cumask_probe.py)
+for F in (48, 56, 64, 72, 80):       # the frame metrics get the first F CUs, the logo kernels the other 256 - F
+    a = make(masked_stream(lambda i: i >= F))
+    b = make(masked_stream(lambda i: i < F))
+    r = {"stats_cus": F, "logo_alone_ms": timed(lambda: logo(a)), "stats_alone_ms": timed(lambda: stats(b)),
+         "together_ms": timed(lambda: (logo(a), stats(b))), "together_stats_first_ms": timed(lambda: (stats(b), logo(a)))}
+    out[f"stats_on_{F}_cus"] = r
+    print(F, r, file=sys.stderr, flush=True)
 print(json.dumps(out))

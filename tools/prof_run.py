@@ -28,6 +28,15 @@ data, alpha, alphaUV = S.make_logo(LW, LH)
 clip = S.make_clip_torch(a.frames, W, H, 0x5EED0002, alpha, alphaUV, X, Y0, dev, pitchY=1472, pitchUV=768)
 dclip = DeviceClip(clip["Y"], clip["U"], clip["V"], W, H, 8)
 ctx = Context(0)
+if os.environ.get("AMT_STATS_MASK_CUS"):         # launches on the first N CUs only (hipExtStreamCreateWithCUMask; bits interleave over the 8 XCDs)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    words = (C.c_uint32 * 8)()
+    for i in range(int(os.environ["AMT_STATS_MASK_CUS"])):
+        words[i // 32] |= 1 << (i % 32)
+    mst = C.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(mst), 8, words) == 0
+    ctx.check(ctx.lib.amtgpu_context_set_stream(ctx.h, mst))
 logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
 out = torch.empty((a.frames, 33), dtype=torch.float32, device=dev)
 st = torch.empty((a.frames, 8), dtype=torch.int64, device=dev)

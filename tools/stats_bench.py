@@ -4,14 +4,8 @@
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
-VARIANTS = {"pf_vg1_x8B": ["AMT_STATS_VG=1", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"], "pf_vg4_x8B": ["AMT_STATS_VG=4", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"],
-            "pf_vg1_r8": ["AMT_STATS_VG=1", "AMT_STATS_ROWS=8", "AMT_STATS_PREFETCH=1"], "pf_vg1_r8_x8B": ["AMT_STATS_VG=1", "AMT_STATS_ROWS=8", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"],
-            "pf_vg1_x16B": ["AMT_STATS_VG=1", "AMT_STATS_PREFETCH=1"],
-            "pf_vg1_r8_x8B_w3": ["AMT_STATS_VG=1", "AMT_STATS_ROWS=8", "AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1", "AMT_STATS_WAVES=3"],
-            "vg1_r16": ["AMT_STATS_VG=1"], "vg4_r16": ["AMT_STATS_VG=4"], "vg8_r8": ["AMT_STATS_VG=8", "AMT_STATS_ROWS=8"],
-            "vg4_r8": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=8"], "vg4_r16_run64": ["AMT_STATS_VG=4", "AMT_STATS_RUN=64"],
-            "vg2_r16": ["AMT_STATS_VG=2"], "vg4_r32x8B": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"], "vg4_r16x8B": ["AMT_STATS_VG=4", "AMT_STATS_ROWS=16", "AMT_STATS_COLB=8"],
-            "vg2_r16x8B": ["AMT_STATS_VG=2", "AMT_STATS_ROWS=16", "AMT_STATS_COLB=8"]}
+VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean16_nt2": ["AMT_STATS_NT=2"], "lean16_nt1": ["AMT_STATS_NT=1"], "lean16_nt3": ["AMT_STATS_NT=3"], "lean16_run64": ["AMT_STATS_RUN=64"],
+            "lean16_vg2": ["AMT_STATS_VG=2"], "lean16_nt2_vg4": ["AMT_STATS_NT=2", "AMT_STATS_VG=4"]}
 if "--build" in sys.argv:
     from amatsukaze_amd import build as B
     for name, defs in VARIANTS.items():
