@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profb_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-strong --no-ingest --cpu-frames 0 --no-verify --no-alt-mode --no-configs"
+COMMON="--no-strong --no-ingest --cpu-frames 0 --no-verify --no-alt-mode --no-configs --no-e2e"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $REPO/bench.py --steps 20 --warmup 2 $COMMON > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_exact -- python $REPO/bench.py --steps 10 --warmup 2 --analysis-mode exact $COMMON > $OUT/kt_exact.log 2>&1
 for mode in linear exact; do
