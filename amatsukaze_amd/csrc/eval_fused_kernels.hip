@@ -87,6 +87,12 @@ __device__ __forceinline__ void Raw4<uint16_t>::load(gptr_t base, unsigned byteo
     v = *reinterpret_cast<const __attribute__((address_space(1))) ua_t*>(base + byteoff);
 }
 
+// AMT_FUSED_BG_LDS: the background-estimate window is NOT kept in registers across the fade loop; every fade reads it from the LDS
+// plane straight into the registers its blend is formed in (15 two-dword reads).  30 VGPRs less -> three waves per SIMD instead of
+// two; the price is LDS traffic inside the loop.
+#ifndef AMT_FUSED_BG_LDS
+#define AMT_FUSED_BG_LDS 0
+#endif
 constexpr int kFusedWaves = kEvalThreads / 64;
 constexpr int kStageRows = 4;         // rows a staging wave handles per trip
 
@@ -264,17 +270,29 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
             for (int fr = 0; fr < FPI; ++fr) {
             if (fr >= nfr) break;
             // ---- 4. windows -> registers: per row the column pairs (1,2) (3,4) (0,5) ----
-            f2 S[15], BG[15];
+            f2 S[15];
+#if !AMT_FUSED_BG_LDS
+            f2 BG[15];
+#endif
             const float* const planeS = planes + fr * 2 * plane_cap;
             const float* const planeB = planeS + plane_cap;
+            unsigned bgrow[5];                                   // LDS byte addresses of the five rows of the bg window
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                bgrow[r] = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)(planeB + woff + r * lp);
             if (act) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     const float* ps = planeS + woff + r * lp;
+                    S[3 * r + 0] = f2{ps[1], ps[2]};
+                    S[3 * r + 1] = f2{ps[3], ps[4]};
+                    S[3 * r + 2] = f2{ps[0], ps[5]};
+#if !AMT_FUSED_BG_LDS
                     const float* pb = planeB + woff + r * lp;
-                    S[3 * r + 0] = f2{ps[1], ps[2]};  BG[3 * r + 0] = f2{pb[1], pb[2]};
-                    S[3 * r + 1] = f2{ps[3], ps[4]};  BG[3 * r + 1] = f2{pb[3], pb[4]};
-                    S[3 * r + 2] = f2{ps[0], ps[5]};  BG[3 * r + 2] = f2{pb[0], pb[5]};
+                    BG[3 * r + 0] = f2{pb[1], pb[2]};
+                    BG[3 * r + 1] = f2{pb[3], pb[4]};
+                    BG[3 * r + 2] = f2{pb[0], pb[5]};
+#endif
                 }
             }
 #ifdef AMT_FUSED_TIMING
@@ -288,8 +306,22 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
                     const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(fade_bits, f));   // no memory op in the loop
                     const float omf = 1 - fade;
                     f2 W[15];
+#if AMT_FUSED_BG_LDS
+                    // the bg window lands in the registers its blend is formed in: column pairs (1,2) (3,4) (0,5) of every row
+#pragma unroll
+                    for (int r = 0; r < 5; ++r)
+                        asm volatile("ds_read2_b32 %0, %3 offset0:1 offset1:2\n\tds_read2_b32 %1, %3 offset0:3 offset1:4\n\t"
+                                     "ds_read2_b32 %2, %3 offset1:5"
+                                     : "=&v"(W[3 * r]), "=&v"(W[3 * r + 1]), "=&v"(W[3 * r + 2]) : "v"(bgrow[r]) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(W[4]), "+v"(W[5]), "+v"(W[6]), "+v"(W[7]), "+v"(W[8]), "+v"(W[9]),
+                                   "+v"(W[10]), "+v"(W[11]), "+v"(W[12]), "+v"(W[13]), "+v"(W[14]) : : "memory");
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) W[i] = W[i] * fade + S[i] * omf;       // fade*bg + (1-fade)*s
+#else
 #pragma unroll
                     for (int i = 0; i < 15; ++i) W[i] = BG[i] * fade + S[i] * omf;      // fade*bg + (1-fade)*s
+#endif
                     // column sums ((r0+r1)+(r2+r3))+r4 for the column pairs
                     const f2 CA = ((W[0] + W[3]) + (W[6] + W[9])) + W[12];               // cols 1,2
                     const f2 CB = ((W[1] + W[4]) + (W[7] + W[10])) + W[13];              // cols 3,4
@@ -379,8 +411,13 @@ void logo_eval_fused_body(const EvalLogoDev* __restrict__ logos, const EvalBand*
 // <= 256 VGPRs: two waves per SIMD, nothing spilled (the fade loop alone holds ~200 live registers: taps 50, the two
 // windows 60, their blend 30, two alternating result/gather sets).  Three waves per SIMD (<= 168) spills taps to
 // scratch inside the fade loop and measured 2.6x slower.
+#if AMT_FUSED_BG_LDS
+#define AMT_FUSED_OCC 3
+#else
+#define AMT_FUSED_OCC 2
+#endif
 template <typename pix_t, int FPI>
-__global__ __launch_bounds__(kEvalThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(kEvalThreads) __attribute__((amdgpu_waves_per_eu(AMT_FUSED_OCC, AMT_FUSED_OCC)))
 void logo_eval_fused_kernel(const EvalLogoDev* __restrict__ logos, const EvalBand* __restrict__ bands, const float* __restrict__ fades,
                             int nfades, int fade0, const pix_t* __restrict__ Y, const int* __restrict__ frame_map,
                             long long frame_stride, int pitch, float maxv, int nframes, int G, int ngroups, float* __restrict__ out,
