@@ -76,7 +76,11 @@ int main(int argc, char** argv)
         int ndev = 0;
         HIPCHK(hipGetDeviceCount(&ndev));
         if (ndev < 1) throw std::runtime_error("no HIP device");
-        const int world = std::max(1, std::min(ndev, argc > 10 ? std::atoi(argv[10]) : ndev));
+        const int asked = argc > 10 ? std::atoi(argv[10]) : ndev;
+        const int world = std::max(1, std::min(ndev, asked));
+        if (asked > ndev)        // RCCL refuses two ranks of one communicator on the same device ("Duplicate GPU detected"): the multi-rank
+            std::fprintf(stderr, "note: %d ranks asked for, %d device(s) visible: running %d rank(s) (RCCL does not place several ranks of a communicator on one "
+                                 "device; the multi-rank control flow on one device is covered over gloo by tests/test_gpu_sharded.py)\n", asked, ndev, world);
         const char* paths[2] = {argv[2], argv[3]};
 
         // ---- one GPU: the answers the sharded runs must reproduce ----

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import amt_synth as S
 from amtlib import _ptr
 from test_gpu_parity import gpu, make_case, oracle_eval_logos  # noqa: F401  (fixture + helpers)
 
@@ -277,3 +278,29 @@ def test_linear_mode_hands_out_of_range_samples_to_the_exact_kernel(gpu):
     an2 = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35, mode="linear")
     an2.analyze(cs["dclip"])
     assert an2.last_refined() < cfg["N"] // 2
+
+
+@pytest.mark.parametrize("bits,maskratio", [(8, 0.35), (16, 1.0), (10, 0.6)])
+def test_linear_mode_under_adversarial_coefficients(gpu, bits, maskratio):
+    """Logos the bound has to work hardest for: alpha up to 0.9 (|a| + |b| ~ 19 instead of ~ 4: window values twenty times the
+    sample range, the bin test's fixed point loses four bits), every pixel in the mask, 16-bit samples.  The unguarded kernel's error
+    must stay inside the library's own rigorous bound, the guarded mode's fades must be the exact mode's."""
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, DeviceClip, Logo
+    torch = gpu["torch"]
+    W, H, LW, LH, X, Y0, N = 352, 240, 96, 48, 224, 18, 16
+    data, alpha, alphaUV = S.make_logo(LW, LH, strength=1.5)
+    assert np.abs(data[:LW * LH]).max() > 9.0                    # a = 1 / (1 - alpha) up to 10
+    clip = S.make_clip_np(N, W, H, 0x5EED0031, alpha, alphaUV, X, Y0, bits=bits, period=5, fade=3, flat_every=4)
+    tdt = torch.uint8 if bits <= 8 else torch.int16
+    dclip = DeviceClip(*(torch.from_numpy(clip[k].view(np.uint8 if bits <= 8 else np.int16)).to(gpu["dev"]).to(tdt) for k in "YUV"), width=W, height=H, bits=bits)
+    logo = Logo.from_planes(gpu["ctx"], data, LW, LH, W, H, X, Y0)
+    exact = AMTAnalyzeLogo(gpu["ctx"], logo, maskratio).analyze(dclip)
+    raw_an = AMTAnalyzeLogo(gpu["ctx"], logo, maskratio, mode="linear_unguarded")
+    raw = raw_an.analyze(dclip)
+    scale = max(1.0, float(np.abs(exact).max()))
+    for k in range(3):
+        err = float(np.abs(raw - exact)[:, 11 * k:11 * k + 11].max())
+        assert err <= raw_an.error_bound(k, bits) * scale, (k, err, raw_an.error_bound(k, bits))
+    guarded = AMTAnalyzeLogo(gpu["ctx"], logo, maskratio, mode="linear").analyze(dclip)
+    er = AMTEraseLogo(gpu["ctx"], logo, "", 0, 16)
+    assert er.calc_fades(guarded, N).tobytes() == er.calc_fades(exact, N).tobytes()
