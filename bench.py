@@ -78,7 +78,7 @@ def parse_args():
                     help="e2e10: BASELINE configs[4] (tools/bench_e2e.py) as the line's own workload, frames sharded over --gpus ranks (strong scaling)")
     ap.add_argument("--e2e-frames", type=int, default=0, help="frames of the e2e10 stream (default: 53 946 = one GPU's share of the 4-hour stream at N = 8; "
                                                               "431568 = the whole stream)")
-    ap.add_argument("--e2e-chunk", type=int, default=1024, help="frames generated and processed per chunk of the e2e10 stream")
+    ap.add_argument("--e2e-chunk", type=int, default=4096, help="frames generated and processed per chunk of the e2e10 stream")
     ap.add_argument("--metrics-cus", type=int, default=0,
                     help="N > 0: N compute units are given to the frame metrics, which then run BESIDE the analysis + scan on the other units (two contexts "
                          "on CU-range streams, amtgpu_stream_create_cu_range).  Measured (profiles/r04_notes.md): no gain on MI355X -- the logo kernels lose "

@@ -49,7 +49,7 @@ def _generate(S, torch, dev, a0, a1, alpha, alphaUV, seed=0x5EED0006):
     return cat(Ys), cat(Us), cat(Vs)
 
 
-def run(E, nt=SHARE_FRAMES, chunk=1024, verify=True, mode="linear"):
+def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
     """E: namespace with torch, dist, rank, world, dev, ctx, logos_np, alpha, alphaUV, fence(), max_over_ranks(x), OracleLogos, rccl"""
     torch, dist, rank, world, dev, ctx = E.torch, E.dist, E.rank, E.world, E.dev, E.ctx
     import amt_synth as S
