@@ -113,3 +113,40 @@ def test_config3_frame_size_cadence_segments(gpu):
         assert (cad[k * SEG + 10:(k + 1) * SEG] == code).mean() > 0.98, (k, code)
     cuts = set(range(97, N, 97))
     assert len(cuts & set(sc)) >= 0.95 * len(cuts) and len(set(sc) - cuts) <= 2
+
+
+def test_contexts_on_cu_range_streams_run_side_by_side():
+    """amtgpu_stream_create_cu_range: two contexts on complementary parts of the device -- the frame metrics on the first 64 compute
+    units, the analysis on the others -- give the results of the whole-device run (a partition changes where a kernel runs, nothing
+    else); ranges outside the device are refused."""
+    import torch
+    import amt_synth as S
+    from amatsukaze_amd import AMTAnalyzeLogo, Context, FrameStats, Logo
+    dev = torch.device("cuda:0")
+    W, H, N = 352, 240, 300
+    data, alpha, alphaUV = S.make_logo(96, 48)
+    Y = S.make_clip_torch(N, W, H, 0x5EED0044, alpha, alphaUV, 224, 18, dev, period=40, fade=6, chroma=False)["Y"]
+    whole = Context(0)
+    ncu = whole.cu_count()
+    assert ncu >= 128
+    logo = Logo.from_planes(whole, data, 96, 48, W, H, 224, 18)
+    want_m = torch.zeros((N, 8), dtype=torch.int64, device=dev)
+    FrameStats(whole, W, H, 8).run_device(Y, want_m)
+    want_a = torch.zeros((N, 33), dtype=torch.float32, device=dev)
+    AMTAnalyzeLogo(whole, logo, 0.35).analyze_device(Y, 8, want_a)
+    torch.cuda.synchronize()
+    cm, ca = Context(0), Context(0)
+    sm, sa = cm.use_cu_range(0, 64), ca.use_cu_range(64, ncu - 64)
+    cur = torch.cuda.current_stream()
+    sm.wait_stream(cur); sa.wait_stream(cur)
+    got_m = torch.zeros((N, 8), dtype=torch.int64, device=dev)
+    got_a = torch.zeros((N, 33), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    fs, an = FrameStats(cm, W, H, 8), AMTAnalyzeLogo(ca, logo, 0.35)
+    for _ in range(3):
+        fs.run_device(Y, got_m)
+        an.analyze_device(Y, 8, got_a)
+    torch.cuda.synchronize()
+    assert torch.equal(got_m, want_m) and got_a.cpu().numpy().tobytes() == want_a.cpu().numpy().tobytes()
+    assert not cm.lib.amtgpu_stream_create_cu_range(cm.h, ncu - 8, 16)
+    assert b"outside the device" in cm.lib.amtgpu_last_error(cm.h)

@@ -4,8 +4,9 @@
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
-VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean16_nt2": ["AMT_STATS_NT=2"], "lean16_nt1": ["AMT_STATS_NT=1"], "lean16_nt3": ["AMT_STATS_NT=3"], "lean16_run64": ["AMT_STATS_RUN=64"],
-            "lean16_vg2": ["AMT_STATS_VG=2"], "lean16_nt2_vg4": ["AMT_STATS_NT=2", "AMT_STATS_VG=4"]}
+VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean_no_nt": ["AMT_STATS_NT=0"], "lean_nt3": ["AMT_STATS_NT=3"], "lean_vg4": ["AMT_STATS_VG=4"],
+            "lean_8B_columns": ["AMT_STATS_COLB=8"], "lean_8B_prefetch": ["AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"],
+            "lean_8rows_prefetch": ["AMT_STATS_ROWS=8", "AMT_STATS_PREFETCH=1"], "lean_run64": ["AMT_STATS_RUN=64"]}
 if "--build" in sys.argv:
     from amatsukaze_amd import build as B
     for name, defs in VARIANTS.items():
