@@ -44,33 +44,51 @@ std::string logoframe_text(const float* evals, int numFrames, int numLogos, int 
     const int N = numFrames;
     if (N <= 0) return std::string();
 
-    // per-frame signed evidence; frames outside the clip repeat the end values
-    std::vector<float> ev(N);
-    for (int n = 0; n < N; ++n) {
+    // per-frame signed evidence; frames outside the clip repeat the end values (a padded copy: no clamps in the loops below)
+    const int pad = std::max(halfAvg, halfMed) + 1;
+    std::vector<float> evp((size_t)N + 2 * pad);
+    for (int j = 0; j < N + 2 * pad; ++j) {
+        const int n = std::max(0, std::min(N - 1, j - pad));
         const float* r = evals + ((size_t)n * numLogos + logoIndex) * 2;
-        ev[n] = std::max(0.0f, r[0]) + std::min(0.0f, r[1]);
+        evp[j] = std::max(0.0f, r[0]) + std::min(0.0f, r[1]);
     }
-    auto at = [&](int i) { return ev[i < 0 ? 0 : (i >= N ? N - 1 : i)]; };
+    const float* const ev = evp.data() + pad;                  // ev[i], -pad <= i < N + pad
 
+    // The selection and the text are replicated on every rank over the WHOLE clip: the window passes run
+    // window-offset outermost, frames innermost (vector loops over frames; every frame still sees its window's values in the
+    // reference's order -- the fp32 mean is a left-to-right sum), the median slides a sorted window.
     std::vector<int> state(N);
     std::vector<float> smooth(N);
-    std::vector<float> med(2 * halfMed + 1);
-    for (int i = 0; i < N; ++i) {
-        float before = at(i - halfAvg), after = at(i + 1);
-        for (int d = 1; d < halfAvg; ++d) {
-            before = std::max(before, at(i - halfAvg + d));
-            after = std::max(after, at(i + 1 + d));
+    {
+        std::vector<float> before(N), after(N), sum(N, 0.0f);
+        for (int i = 0; i < N; ++i) { before[i] = ev[i - halfAvg]; after[i] = ev[i + 1]; }
+        for (int d = 1; d < halfAvg; ++d)
+            for (int i = 0; i < N; ++i) {
+                before[i] = std::max(before[i], ev[i - halfAvg + d]);
+                after[i] = std::max(after[i], ev[i + 1 + d]);
+            }
+        for (int d = -halfAvg; d <= halfAvg; ++d)
+            for (int i = 0; i < N; ++i) sum[i] += ev[i + d];
+        for (int i = 0; i < N; ++i) {
+            const float mm = std::min(before[i], after[i]);
+            const int byMinMax = (std::abs(mm) < 0.5f) ? 1 : (mm < 0.0f) ? 0 : 2;
+            const float mean = sum[i] / avgLen;
+            const int byMean = (std::abs(mean) < kUnknownBelow) ? 1 : (mean < 0.0f) ? 0 : 2;
+            state[i] = (byMinMax == byMean) ? byMinMax : 1;
         }
-        const float mm = std::min(before, after);
-        const int byMinMax = (std::abs(mm) < 0.5f) ? 1 : (mm < 0.0f) ? 0 : 2;
-        float s = 0.0f;
-        for (int d = -halfAvg; d <= halfAvg; ++d) s += at(i + d);
-        const float mean = s / avgLen;
-        const int byMean = (std::abs(mean) < kUnknownBelow) ? 1 : (mean < 0.0f) ? 0 : 2;
-        state[i] = (byMinMax == byMean) ? byMinMax : 1;
-        for (int d = -halfMed; d <= halfMed; ++d) med[d + halfMed] = at(i + d);
-        std::nth_element(med.begin(), med.begin() + halfMed, med.end());
-        smooth[i] = med[halfMed];
+        const int K = 2 * halfMed + 1;
+        std::vector<float> win(ev - halfMed, ev - halfMed + K);       // the window of frame 0, then kept in ascending order
+        std::sort(win.begin(), win.end());
+        for (int i = 0; i < N; ++i) {
+            smooth[i] = win[halfMed];
+            if (i + 1 == N) break;
+            const float out = ev[i - halfMed], in = ev[i + 1 + halfMed];
+            int k = 0;
+            while (win[k] != out) ++k;
+            for (; k + 1 < K && win[k + 1] < in; ++k) win[k] = win[k + 1];    // the gap moves up ...
+            for (; k > 0 && win[k - 1] > in; --k) win[k] = win[k - 1];        // ... or down to where `in` belongs
+            win[k] = in;
+        }
     }
 
     // unknown runs adopt their neighbours' state when both sides agree (outside the clip counts as off)

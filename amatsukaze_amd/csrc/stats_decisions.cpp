@@ -11,23 +11,30 @@ inline uint64_t m(const uint64_t* metrics, int n, int w) { return metrics[(size_
 }
 
 // frame n starts a new scene when its field-difference energy is at least 4 per pixel on average and more
-// than three times the median of the previous 15 frames' energies
+// than three times the median of the previous 15 frames' energies (frames 1 .. n-1 near the clip's start; the
+// median of s values = the one at index s / 2 in ascending order).  The window is kept sorted as it slides -- the
+// decisions are replicated on every rank over the WHOLE clip, so they cost O(1) per frame.
 std::vector<int> scene_changes(const uint64_t* metrics, int nframes, int width, int height)
 {
     std::vector<int> out;
     const uint64_t floor_energy = (uint64_t)width * height * 4;
-    std::vector<uint64_t> hist;
+    auto energy = [&](int k) { return m(metrics, k, W_DIFF_TOP) + m(metrics, k, W_DIFF_BOT); };
+    uint64_t win[16];
+    int s = 0;                                   // win[0..s) = the energies of frames max(1, n-15) .. n-1, ascending
     for (int n = 1; n < nframes; ++n) {
-        const uint64_t e = m(metrics, n, W_DIFF_TOP) + m(metrics, n, W_DIFF_BOT);
-        const int k0 = std::max(1, n - 15);
-        hist.clear();
-        for (int k = k0; k < n; ++k) hist.push_back(m(metrics, k, W_DIFF_TOP) + m(metrics, k, W_DIFF_BOT));
-        uint64_t med = 0;
-        if (!hist.empty()) {
-            std::nth_element(hist.begin(), hist.begin() + hist.size() / 2, hist.end());
-            med = hist[hist.size() / 2];
-        }
+        const uint64_t e = energy(n);
+        const uint64_t med = s ? win[s / 2] : 0;
         if (e >= floor_energy && e > 3 * med) out.push_back(n);
+        if (s == 15) {                           // frame n-15 leaves
+            const uint64_t old = energy(n - 15);
+            int i = 0;
+            while (win[i] != old) ++i;
+            for (; i + 1 < s; ++i) win[i] = win[i + 1];
+            --s;
+        }
+        int i = s++;                             // frame n enters
+        for (; i > 0 && win[i - 1] > e; --i) win[i] = win[i - 1];
+        win[i] = e;
     }
     return out;
 }
@@ -36,32 +43,41 @@ std::vector<int> scene_changes(const uint64_t* metrics, int nframes, int width, 
 // own vertical detail): 'C' the frame's own fields belong together (COMB*1.5 < COMB_PREV), 'P' its top
 // field belongs with the previous bottom field (COMB_PREV*1.5 < COMB), 'B' undecided.  3:2 pulldown gives
 // C C P P x every five frames, progressive 30p gives all C, interlaced video all B (while moving).
+// Frame n is classified from the 10-frame window [n-4, n+6) cut to the clip.  The window's counts slide with it: the 3:2 hits
+// are kept per cycle offset q = (position of frame 0 in the cycle), which does not move with the window -- the phase ph of the
+// window's first frame a is q = (ph - a) mod 5.
 void classify_cadence(const uint64_t* metrics, int nframes, int width, int height, uint8_t* cadence, uint8_t* phase)
 {
     std::vector<char> code(nframes, 'B');
+    std::vector<uint64_t> motion_of(nframes);
     for (int n = 0; n < nframes; ++n) {
         const uint64_t c0 = m(metrics, n, W_COMB), c1 = m(metrics, n, W_COMB_PREV);
         if (c0 * 3 < c1 * 2) code[n] = 'C';
         else if (c1 * 3 < c0 * 2) code[n] = 'P';
+        motion_of[n] = m(metrics, n, W_DIFF_TOP) + m(metrics, n, W_DIFF_BOT);
     }
     const uint64_t still = (uint64_t)width * height / 2;      // < 0.5 per pixel of field difference: nothing moves
+    int hitq[5] = {0, 0, 0, 0, 0}, nC = 0, nDecided = 0;
+    auto slide = [&](int k, int sign) {                        // frame k enters (+1) or leaves (-1) the window
+        nC += sign * (code[k] == 'C');
+        nDecided += sign * (code[k] != 'B');
+        if (code[k] == 'B') return;
+        // C counts where (k + q) % 5 is 0 or 1, P where it is 2 or 3: two offsets q each
+        const int r = k % 5, q0 = code[k] == 'C' ? 5 - r : 7 - r;
+        hitq[q0 % 5] += sign;
+        hitq[(q0 + 1) % 5] += sign;
+    };
+    int wa = 0, wb = 0;                                        // the counts cover [wa, wb)
     uint8_t last = kCadence60i, lastPhase = 0;
     for (int n = 0; n < nframes; ++n) {
         const int a = std::max(0, n - 4), b = std::min(nframes, n + 6);      // 10-frame window
-        int best = -1, bestPhase = 0, nC = 0, nDecided = 0;
+        while (wb < b) slide(wb++, +1);
+        while (wa < a) slide(wa++, -1);
+        int best = -1, bestPhase = 0;
         uint64_t motion = 0;
-        for (int k = a; k < b; ++k) {
-            nC += code[k] == 'C';
-            nDecided += code[k] != 'B';
-            motion = std::max(motion, m(metrics, k, W_DIFF_TOP) + m(metrics, k, W_DIFF_BOT));
-        }
+        for (int k = a; k < b; ++k) motion = std::max(motion, motion_of[k]);
         for (int ph = 0; ph < 5; ++ph) {          // ph = position of frame `a` in the cycle
-            int hit = 0;
-            for (int k = a; k < b; ++k) {
-                const int pos = (k - a + ph) % 5;
-                if (pos <= 1) hit += code[k] == 'C';
-                else if (pos <= 3) hit += code[k] == 'P';
-            }
+            const int hit = hitq[((ph - a) % 5 + 5) % 5];
             if (hit > best) { best = hit; bestPhase = ph; }
         }
         const int span = b - a;

@@ -988,17 +988,31 @@ def config_kfm(ctx, dev, logos_np, alpha, alphaUV, args, N=18000, SEG=1800):
     if not (ok_metrics and ok_dec):
         raise SystemExit(f"configs[2] verification FAILED: metrics == oracle: {ok_metrics}, decisions == oracle: {ok_dec}")
     # ---- detector accuracy against the generator's labels ----
-    interior = np.ones(N, bool)
+    # interior = frames whose whole 10-frame classifier window [n-4, n+6) lies inside one cadence segment (and inside the clip)
+    interior = np.zeros(N, bool)
     for s0 in range(0, N, SEG):
-        interior[s0:s0 + 10] = False                                # the classifier looks at a 10-frame window
+        interior[s0 + 4:max(s0 + 4, min(N, s0 + SEG) - 5)] = True
     agree = cad == truth
     per_class = {c: float(agree[truth == v].mean()) for c, v in code.items()}
     cuts = set(range(97, N, 97))
     det = set(int(x) for x in sc.tolist())
     near = lambda a, B: any((a + d) in B for d in (-1, 0, 1))
+    # the interior misses, looked at: where they are relative to the scene cuts and what the per-frame field-match codes were
+    c0m, c1m = m[:, 3].astype(np.float64), m[:, 4].astype(np.float64)
+    fcode = np.where(c0m * 3 < c1m * 2, "C", np.where(c1m * 3 < c0m * 2, "P", "B"))
+    miss = np.nonzero(~agree & interior)[0]
+    runs = []
+    for n in miss.tolist():
+        if runs and n == runs[-1][1] + 1:
+            runs[-1][1] = n
+        else:
+            runs.append([n, n])
+    miss_runs = [{"frames": [a, b], "truth": int(truth[a]), "got": sorted(set(int(x) for x in cad[a:b + 1])), "nearest_cut_distance": int(min(abs(a - c) for c in cuts)),
+                  "codes_window": "".join(fcode[max(0, a - 4):b + 7].tolist())} for a, b in runs[:40]]
     tp = len(det & cuts)
     acc = {"cadence_agreement_all_frames": float(agree.mean()), "cadence_agreement_segment_interiors": float(agree[interior].mean()),
            "cadence_agreement_per_class": per_class,
+           "interior_miss_frames": int(miss.size), "interior_miss_runs": miss_runs,
            "scene_cuts_truth": len(cuts), "scene_cuts_detected": len(det),
            "scene_cut_precision": tp / max(1, len(det)), "scene_cut_recall": tp / max(1, len(cuts)),
            "scene_cut_precision_pm1": sum(near(a, cuts) for a in det) / max(1, len(det)),
