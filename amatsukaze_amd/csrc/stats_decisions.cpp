@@ -68,16 +68,23 @@ void classify_cadence(const uint64_t* metrics, int nframes, int width, int heigh
         hitq[(q0 + 1) % 5] += sign;
     };
     int wa = 0, wb = 0;                                        // the counts cover [wa, wb)
+    uint64_t motion = 0;
+    int motion_from = -1;                                      // the latest frame of the window that holds `motion`
     uint8_t last = kCadence60i, lastPhase = 0;
     for (int n = 0; n < nframes; ++n) {
         const int a = std::max(0, n - 4), b = std::min(nframes, n + 6);      // 10-frame window
         while (wb < b) slide(wb++, +1);
         while (wa < a) slide(wa++, -1);
+        // the window's largest motion: recomputed only when the frame that left held it or the window is still growing
+        if (n == 0 || motion_from < a) {
+            motion = 0;
+            for (int k = a; k < b; ++k) if (motion_of[k] >= motion) { motion = motion_of[k]; motion_from = k; }
+        } else if (b > 0 && motion_of[b - 1] >= motion) { motion = motion_of[b - 1]; motion_from = b - 1; }
         int best = -1, bestPhase = 0;
-        uint64_t motion = 0;
-        for (int k = a; k < b; ++k) motion = std::max(motion, motion_of[k]);
+        const int a5 = a % 5;
         for (int ph = 0; ph < 5; ++ph) {          // ph = position of frame `a` in the cycle
-            const int hit = hitq[((ph - a) % 5 + 5) % 5];
+            const int q = ph - a5;
+            const int hit = hitq[q < 0 ? q + 5 : q];
             if (hit > best) { best = hit; bestPhase = ph; }
         }
         const int span = b - a;
