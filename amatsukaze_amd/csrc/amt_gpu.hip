@@ -434,6 +434,23 @@ int amtgpu_logoframe_allgather_results(AmtGpuLogoFrame* lf, const AmtGpuCollecti
     });
 }
 
+int amtgpu_logoframe_decide_host(const float* evals, int num_frames, int num_logos, int num_candidates, int logo_index,
+                                 int fps_num, int fps_den, int* best_logo, float* logo_ratio, char* text, int cap, int* text_len)
+{
+    try {
+        if (!evals || num_frames < 0 || num_logos <= 0 || fps_num <= 0 || fps_den <= 0 || logo_index >= num_logos) return 0;
+        const LogoSelection sel = select_logo(evals, num_frames, num_logos, num_candidates);
+        if (best_logo) *best_logo = sel.bestLogo;
+        if (logo_ratio) *logo_ratio = sel.logoRatio;
+        const int li = logo_index < 0 ? sel.bestLogo : logo_index;
+        const std::string t = li < 0 ? std::string() : logoframe_text(evals, num_frames, num_logos, li, fps_num, fps_den);
+        if (text_len) *text_len = (int)t.size();
+        if (!text || cap < (int)t.size()) return text == nullptr && cap == 0 ? 1 : 0;
+        std::memcpy(text, t.data(), t.size());
+        return 1;
+    } catch (...) { return 0; }
+}
+
 int amtgpu_logoframe_select_logo(AmtGpuLogoFrame* lf, int ncand)
 {
     return guard(lf->ctx, [&] {

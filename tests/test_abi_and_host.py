@@ -157,6 +157,85 @@ def test_stats_decisions_match_oracle(lib):
     assert sc[:k.value].tolist() == FS.scene_changes(m, W, H) and 77 in sc[:k.value].tolist()
 
 
+def _metric_stream(rng, n, W, H, kind):
+    m = np.zeros((n, 8), np.uint64)
+    if kind == 0:                                            # noise: every branch of the classifiers, ties included
+        m[:, 0] = rng.randint(0, W * H * 6, n); m[:, 1] = rng.randint(0, W * H * 6, n)
+        m[:, 3] = rng.randint(1, W * H * 10, n) // 1000 * 1000; m[:, 4] = rng.randint(1, W * H * 10, n) // 1000 * 1000
+        return m
+    for i in range(n):                                       # segments of 24p / 30p / 30i / noise with stills and cuts
+        seg = (i // 60) % 4
+        mot = 0 if (i // 25) % 7 == 3 else int(rng.randint(W * H, W * H * 3))
+        if i % 97 == 0:
+            mot *= 20
+        base = int(rng.randint(W * H, 2 * W * H))
+        if seg == 0:
+            c = (base, base * 3) if i % 5 < 2 else ((base * 3, base) if i % 5 < 4 else (base, base))
+        elif seg == 1:
+            c = (base, base * 4)
+        elif seg == 2:
+            c = (base, base + int(rng.randint(0, W * H // 4)))
+        else:
+            c = (base * int(rng.randint(1, 4)), base * int(rng.randint(1, 4)))
+        m[i, 0], m[i, 1], m[i, 3], m[i, 4] = mot, mot // 2, c[0], c[1]
+    return m
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 4, 5, 6, 9, 10, 11, 15, 16, 17, 31, 40, 333, 1500])
+def test_sliding_window_decisions_match_the_oracle_at_every_length(lib, n):
+    """the replicated decisions run in O(1) per frame (sorted sliding windows, per-offset 3:2 hit counts): same outputs as the
+    oracle's per-frame window scans at every clip length around the window sizes (10 and 15 frames), on noise and on structure"""
+    W, H = 352, 240
+    for kind in (0, 1):
+        m = _metric_stream(np.random.RandomState(1000 * kind + n), n, W, H, kind)
+        cad, ph, sc, k = np.zeros(max(1, n), np.uint8), np.zeros(max(1, n), np.uint8), np.zeros(max(1, n), np.int32), C.c_int()
+        assert lib.amtgpu_kfm_cadence(_ptr(m), n, W, H, _ptr(cad), _ptr(ph)) == 1
+        assert lib.amtgpu_cm_scene_changes(_ptr(m), n, W, H, _ptr(sc), max(1, n), C.byref(k)) == 1
+        ocad, oph = FS.classify_cadence(m, W, H)
+        assert np.array_equal(cad[:n], ocad) and np.array_equal(ph[:n], oph)
+        assert sc[:k.value].tolist() == FS.scene_changes(m, W, H)
+
+
+@pytest.mark.parametrize("fps", [(30000, 1001), (24000, 1001), (60000, 1001), (25, 1), (5, 1), (1, 1)])
+def test_logoframe_decisions_on_the_host_match_the_oracle(lib, fps):
+    """amtgpu_logoframe_decide_host = LogoFrame::selectLogo + the text of writeResult (LogoScan.hpp:1647-1827) from scan records alone:
+    bytes of the oracle's text (itself pinned to the real reference, tests/test_oracle_vs_ref.py) at clip lengths around the
+    window sizes, for on/off runs, noise, zeros, infinities and NaNs (a logo whose blackScore is 0 scores 0/0)"""
+    O = Oracle()
+    rng = np.random.RandomState(fps[0] + fps[1])
+    for t, n in enumerate([1, 2, 3, 7, 14, 15, 16, 29, 30, 31, 32, 61, 200, 1000, 5000, 20000]):
+        nl = 1 + t % 3
+        ev = np.zeros((n, nl, 2), np.float32)
+        mode = t % 4
+        for l in range(nl):
+            on = ((np.arange(n) // (40 + 17 * l + t)) % 2).astype(np.float32)
+            if mode == 0:
+                ev[:, l, 0] = rng.uniform(-1, 1, n); ev[:, l, 1] = rng.uniform(-1, 1, n)
+            elif mode == 1:
+                ev[:, l, 0] = on * 0.9 - 0.1 + rng.uniform(-0.3, 0.3, n)
+                ev[:, l, 1] = np.where(on > 0, rng.uniform(-0.05, 0.05, n), -0.7 + rng.uniform(-0.2, 0.2, n))
+            elif mode == 2:
+                ev[:, l, 0] = np.where(rng.randint(0, 3, n) == 0, 0, on); ev[:, l, 1] = np.where(rng.randint(0, 4, n) == 0, 0, -0.5 * on)
+            else:
+                ev[:, l, 0] = on * 0.9 - 0.1 + rng.uniform(-0.6, 0.6, n); ev[:, l, 1] = -0.3 + rng.uniform(-0.6, 0.6, n)
+                ev[rng.randint(0, 50, n) == 0, l, 0] = np.inf
+                ev[rng.randint(0, 60, n) == 0, l, 1] = np.nan
+        ev = np.ascontiguousarray(ev)
+        ob, orat = C.c_int(), C.c_float()
+        O.lib.orc_logoframe_select(_ptr(ev), n, nl, -1, C.byref(ob), C.byref(orat))
+        for li in (-1, nl - 1):
+            want = C.create_string_buffer(1 << 20)
+            wl = O.lib.orc_logoframe_write_result(_ptr(ev), n, nl, ob.value if li < 0 else li, fps[0], fps[1], want, len(want))
+            assert wl >= 0
+            best, ratio, tl = C.c_int(-2), C.c_float(), C.c_int()
+            assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, li, fps[0], fps[1], C.byref(best), C.byref(ratio), None, 0, C.byref(tl)) == 1
+            got = C.create_string_buffer(max(1, tl.value))
+            assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, li, fps[0], fps[1], C.byref(best), C.byref(ratio), got, tl.value, C.byref(tl)) == 1
+            assert best.value == ob.value and np.float32(ratio.value).tobytes() == np.float32(orat.value).tobytes()
+            assert got.raw[:tl.value] == want.raw[:wl], (n, nl, li, mode)
+    assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, nl, fps[0], fps[1], None, None, None, 0, None) == 0       # logo index outside
+
+
 def test_c_and_numpy_stat_oracles_agree():
     """the two restatements of the self-specified metrics (C for the CPU baseline, numpy for readability)"""
     orc = Oracle()
