@@ -136,8 +136,13 @@ template <> struct Quad<uint8_t> {
         const unsigned e0 = __builtin_amdgcn_perm(r0.v, r0.v, 0x0C020C00u), o0 = __builtin_amdgcn_perm(r0.v, r0.v, 0x0C030C01u);
         const unsigned e1 = __builtin_amdgcn_perm(r1.v, r1.v, 0x0C020C00u), o1 = __builtin_amdgcn_perm(r1.v, r1.v, 0x0C030C01u);
         const unsigned e2 = __builtin_amdgcn_perm(r2.v, r2.v, 0x0C020C00u), o2 = __builtin_amdgcn_perm(r2.v, r2.v, 0x0C030C01u);
-        const unsigned se = ((e1 << 1) + e0) + (e2 + bias);
-        const unsigned so = ((o1 << 1) + o0) + (o2 + bias);
+        // (two instructions per sum -- v_lshl_add_u32, v_add3_u32 -- where the compiler's own association of
+        //  ((e1 << 1) + e0) + (e2 + bias) takes three: 1 % of the scan kernel)
+        unsigned te, to;
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(te) : "v"(e1), "v"(e0));
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(to) : "v"(o1), "v"(o0));
+        const unsigned se = te + e2 + bias;
+        const unsigned so = to + o2 + bias;
         // (ldexp, not a multiply by 0.25: the vectoriser would pair the multiplies and the pairs {s0,s1}, {s2,s3} then need four
         //  moves into the {s, bg} order of the LDS store)
         s[0] = __builtin_amdgcn_ldexpf((float)(se & 0xFFFFu), -2);

@@ -1,7 +1,8 @@
 // sharded_rccl_test.cpp -- the frame-sharded drivers of the C ABI over RCCL, the way a C++ host with one rank per GPU runs
 // them (include/amt_rccl_collectives.hpp): LogoFrame::scanFrames sharded + all-gather of the records (LogoScan.hpp:1577-1584) and
 // ScanLogo sharded -- quota of the first numMaxFrames valid frames in stream order (:885), three exact int64 all-reduces
-// (:917-1036) -- against the same calls on one GPU.  One thread per rank, communicators from ncclCommInitAll; the world is every
+// (:917-1036) -- and the CM / KFM frame metrics sharded with their one-frame halo + all-gather of the 64-byte records + replicated
+// cadence / scene-change decisions (amtgpu_framestats_sharded), against the same calls on one GPU.  One thread per rank, communicators from ncclCommInitAll; the world is every
 // visible GPU (1 on a single-GPU box: the collectives then run over a one-rank communicator -- RCCL is still what executes them).
 //   sharded_rccl_test <clip.raw> <logo.lgd> <logo2.lgd> <outdir> imgx imgy w h numMaxFrames [max_ranks]
 // clip.raw: int32 {W,H,bits(8),N,pitchY,pitchUV} then Y[N][H][pitchY], U[N][H/2][pitchUV], V[...]
@@ -46,13 +47,17 @@ static std::string slurp(const std::string& p)
     std::ifstream f(p, std::ios::binary);
     return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
-// frames [a, b) of the clip on the current device
+// frames [a, b) of the clip on the current device, and the frame before them (the frame metrics' one-frame halo; null for a = 0)
 struct DevShard {
-    void *Y = nullptr, *U = nullptr, *V = nullptr;
+    void *Y = nullptr, *U = nullptr, *V = nullptr, *prevY = nullptr;
     int n = 0;
     DevShard(const Clip& c, int a, int b) : n(b - a)
     {
         const size_t fy = (size_t)c.H * c.pY, fc = (size_t)(c.H / 2) * c.pUV;
+        if (a > 0) {
+            HIPCHK(hipMalloc(&prevY, fy));
+            HIPCHK(hipMemcpy(prevY, c.Y.data() + fy * (a - 1), fy, hipMemcpyHostToDevice));
+        }
         HIPCHK(hipMalloc(&Y, std::max<size_t>(1, fy * n)));
         HIPCHK(hipMalloc(&U, std::max<size_t>(1, fc * n)));
         HIPCHK(hipMalloc(&V, std::max<size_t>(1, fc * n)));
@@ -62,7 +67,7 @@ struct DevShard {
             HIPCHK(hipMemcpy(V, c.V.data() + fc * a, fc * n, hipMemcpyHostToDevice));
         }
     }
-    ~DevShard() { (void)hipFree(Y); (void)hipFree(U); (void)hipFree(V); }
+    ~DevShard() { (void)hipFree(Y); (void)hipFree(U); (void)hipFree(V); (void)hipFree(prevY); }
 };
 static void shard_range(int n, int rank, int world, int& a, int& b) { a = (int)((long long)n * rank / world); b = (int)((long long)n * (rank + 1) / world); }
 
@@ -85,6 +90,7 @@ int main(int argc, char** argv)
 
         // ---- one GPU: the answers the sharded runs must reproduce ----
         std::vector<float> eval_single((size_t)clip.N * 2 * 2);
+        std::vector<uint64_t> metrics_single((size_t)clip.N * AMTGPU_FS_WORDS);
         {
             HIPCHK(hipSetDevice(0));
             AmtGpuContext* ctx = amtgpu_context_create(0);
@@ -99,6 +105,14 @@ int main(int argc, char** argv)
                 !amtgpu_logoframe_scan_batch(lf, all.Y, (int64_t)clip.H * clip.pY, clip.pY, 0, clip.N) || !amtgpu_logoframe_get_results(lf, eval_single.data()))
                 throw std::runtime_error(std::string("single-GPU scan: ") + amtgpu_last_error(ctx));
             amtgpu_logoframe_destroy(lf);
+            AmtGpuFrameStats* fs = amtgpu_framestats_create(ctx, clip.W, clip.H, 8);
+            void* dm = nullptr;
+            HIPCHK(hipMalloc(&dm, metrics_single.size() * 8));
+            if (!fs || !amtgpu_framestats_batch(fs, all.Y, (int64_t)clip.H * clip.pY, clip.pY, nullptr, clip.N, (uint64_t*)dm) || !amtgpu_context_synchronize(ctx))
+                throw std::runtime_error(std::string("single-GPU frame metrics: ") + amtgpu_last_error(ctx));
+            HIPCHK(hipMemcpy(metrics_single.data(), dm, metrics_single.size() * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(dm);
+            amtgpu_framestats_destroy(fs);
             amtgpu_context_destroy(ctx);
             std::ofstream(out + "/eval_single.bin", std::ios::binary).write(reinterpret_cast<const char*>(eval_single.data()), eval_single.size() * 4);
         }
@@ -112,6 +126,7 @@ int main(int argc, char** argv)
         ncclGetVersion(&nccl_version);
         std::vector<std::string> errors(world);
         std::vector<std::vector<float>> evals(world, std::vector<float>((size_t)clip.N * 2 * 2));
+        std::vector<std::vector<uint64_t>> metrics(world, std::vector<uint64_t>((size_t)clip.N * AMTGPU_FS_WORDS));
         std::vector<std::thread> th;
         for (int r = 0; r < world; ++r)
             th.emplace_back([&, r] {
@@ -135,6 +150,11 @@ int main(int argc, char** argv)
                         !amtgpu_logoframe_allgather_results(lf, coll.get(), a, b - a) || !amtgpu_logoframe_get_results(lf, evals[r].data()))
                         throw std::runtime_error(std::string("sharded scan: ") + amtgpu_last_error(ctx) + " / " + coll.last_error());
                     amtgpu_logoframe_destroy(lf);
+                    // CM / KFM frame metrics: own range with the frame before it as halo, records all-gathered
+                    AmtGpuFrameStats* fs = amtgpu_framestats_create(ctx, clip.W, clip.H, 8);
+                    if (!fs || !amtgpu_framestats_sharded(fs, coll.get(), mine.Y, (int64_t)clip.H * clip.pY, clip.pY, mine.prevY, a, b - a, clip.N, metrics[r].data()))
+                        throw std::runtime_error(std::string("sharded frame metrics: ") + amtgpu_last_error(ctx) + " / " + coll.last_error());
+                    amtgpu_framestats_destroy(fs);
                     // logo generation
                     const std::string dst = out + "/sharded.lgd";
                     if (!amtgpu_scanlogo_sharded(ctx, coll.get(), mine.Y, mine.U, mine.V, (int64_t)clip.H * clip.pY, (int64_t)(clip.H / 2) * clip.pUV, clip.pY,
@@ -152,6 +172,24 @@ int main(int argc, char** argv)
         for (int r = 0; r < world; ++r) {
             std::ofstream(out + "/eval_rank" + std::to_string(r) + ".bin", std::ios::binary).write(reinterpret_cast<const char*>(evals[r].data()), evals[r].size() * 4);
             if (std::memcmp(evals[r].data(), eval_single.data(), eval_single.size() * 4)) { std::fprintf(stderr, "rank %d: gathered records differ\n", r); ok = false; }
+        }
+        // the replicated decisions: every rank's gathered records are the single-GPU ones, so are the cadence and the scene changes
+        auto decide = [&](const std::vector<uint64_t>& m, std::vector<uint8_t>& cad, std::vector<int>& sc) {
+            cad.assign((size_t)clip.N * 2, 0);
+            sc.assign((size_t)std::max(1, clip.N), 0);
+            int nsc = 0;
+            if (!amtgpu_kfm_cadence(m.data(), clip.N, clip.W, clip.H, cad.data(), cad.data() + clip.N) ||
+                !amtgpu_cm_scene_changes(m.data(), clip.N, clip.W, clip.H, sc.data(), clip.N, &nsc))
+                throw std::runtime_error("decisions");
+            sc.resize(nsc);
+        };
+        std::vector<uint8_t> cad0, cadr;
+        std::vector<int> sc0, scr;
+        decide(metrics_single, cad0, sc0);
+        for (int r = 0; r < world; ++r) {
+            if (metrics[r] != metrics_single) { std::fprintf(stderr, "rank %d: gathered frame metrics differ\n", r); ok = false; }
+            decide(metrics[r], cadr, scr);
+            if (cadr != cad0 || scr != sc0) { std::fprintf(stderr, "rank %d: replicated decisions differ\n", r); ok = false; }
         }
         if (!ok) return 1;
         std::printf("ok world=%d devices=%d rccl=%d\n", world, ndev, nccl_version);
