@@ -315,8 +315,11 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     dim3 grid((unsigned)((wgs + kStatXcds - 1) / kStatXcds * kStatXcds), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
         block(kStatThreads);                                      // surplus workgroups of the round-up find nvalid <= 0
     const bool ragged = row_bytes % kStatColBytes != 0;
+#ifndef AMT_STATS_LDS_BYTES
+#define AMT_STATS_LDS_BYTES 0      /* experiments: an LDS reservation the kernel never touches caps its workgroups per CU */
+#endif
 #define AMT_STATS_LAUNCH(E, RG)                                                                                                           \
-    hipLaunchKernelGGL((frame_stats_kernel<E, RG>), grid, block, 0, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es, row_bytes, H, \
+    hipLaunchKernelGGL((frame_stats_kernel<E, RG>), grid, block, AMT_STATS_LDS_BYTES, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es, row_bytes, H, \
                        (const uint8_t*)dprevY, nframes, col_groups, dout)
     if (es == 1) { if (ragged) AMT_STATS_LAUNCH(1, true); else AMT_STATS_LAUNCH(1, false); }
     else { if (ragged) AMT_STATS_LAUNCH(2, true); else AMT_STATS_LAUNCH(2, false); }
