@@ -6,7 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean_no_nt": ["AMT_STATS_NT=0"], "lean_nt3": ["AMT_STATS_NT=3"], "lean_vg4": ["AMT_STATS_VG=4"],
             "lean_8B_columns": ["AMT_STATS_COLB=8"], "lean_8B_prefetch": ["AMT_STATS_COLB=8", "AMT_STATS_PREFETCH=1"],
-            "lean_8rows_prefetch": ["AMT_STATS_ROWS=8", "AMT_STATS_PREFETCH=1"], "lean_run64": ["AMT_STATS_RUN=64"]}
+            "lean_8rows_prefetch": ["AMT_STATS_ROWS=8", "AMT_STATS_PREFETCH=1"], "lean_run64": ["AMT_STATS_RUN=64"],
+            # taller tiles: the halo rows are 2 / ROWS of the traffic
+            "rows24": ["AMT_STATS_ROWS=24"], "rows24_8B": ["AMT_STATS_ROWS=24", "AMT_STATS_COLB=8"], "rows32_8B": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"],
+            "rows32_8B_run64": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8", "AMT_STATS_RUN=64"]}
+ONLY = [a for a in sys.argv[1:] if not a.startswith("--")]
+if ONLY:
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in ONLY}
 if "--build" in sys.argv:
     from amatsukaze_amd import build as B
     for name, defs in VARIANTS.items():
