@@ -42,6 +42,11 @@ class Context:
             import torch
             torch.cuda.init()
         self.lib = binding.load()
+        buf = C.create_string_buffer(2048)
+        if self.lib.amtgpu_hip_runtimes_loaded(buf, len(buf)) > 1:
+            raise AmtError("more than one HIP runtime is mapped into this process (" + ", ".join(buf.value.decode().split()) + "): device "
+                           "memory and streams of one are unknown to the other -- load torch (or whichever component brings its own "
+                           "libamdhip64) before amatsukaze_amd")
         self.h = self.lib.amtgpu_context_create(device)
         if not self.h:
             raise AmtError(f"amtgpu_context_create({device}) failed: no usable HIP device")

@@ -89,6 +89,7 @@ SIGNATURES = {
     "amtgpu_logoframe_set_results": (c_i, [c_p, c_i, c_i, c_p]),
     "amtgpu_logoframe_select_logo": (c_i, [c_p, c_i]),
     "amtgpu_logoframe_write_result": (c_i, [c_p, c_s, c_i]),
+    "amtgpu_hip_runtimes_loaded": (c_i, [c_p, c_i]),
     "amtgpu_logoframe_decide_host": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
     "amtgpu_logoframe_best_logo": (c_i, [c_p]),
     "amtgpu_logoframe_logo_ratio": (c_f, [c_p]),

@@ -2,11 +2,15 @@
 // logo model, LogoFrame, AMTAnalyzeLogo).  Parts 2/3 live in amt_gpu_erase_scan.hip / amt_gpu_stats.hip.
 #include "../../include/amt_gpu.h"
 
+#include <link.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "api_common.hpp"
@@ -19,6 +23,29 @@ namespace amt { void trace_stamp(AmtGpuContext* c, hipStream_t st, int slot); }
 extern "C" {
 
 int amtgpu_abi_version(void) { return AMTGPU_ABI_VERSION; }
+
+int amtgpu_hip_runtimes_loaded(char* paths, int cap)
+{
+    struct Acc { std::vector<std::string> v; } acc;
+    dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* user) {
+        const char* name = info->dlpi_name ? info->dlpi_name : "";
+        const char* base = std::strrchr(name, '/');
+        base = base ? base + 1 : name;
+        if (std::strncmp(base, "libamdhip64.so", 14) == 0) {
+            auto& v = static_cast<Acc*>(user)->v;
+            if (std::find(v.begin(), v.end(), std::string(name)) == v.end()) v.emplace_back(name);
+        }
+        return 0;
+    }, &acc);
+    if (paths && cap > 0) {
+        std::string all;
+        for (const auto& p : acc.v) { all += p; all += '\n'; }
+        const size_t n = std::min(all.size(), (size_t)cap - 1);
+        std::memcpy(paths, all.data(), n);
+        paths[n] = 0;
+    }
+    return (int)acc.v.size();
+}
 
 // ---------------------------------------------------------------------------------------------
 // context

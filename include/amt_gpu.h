@@ -46,6 +46,12 @@ typedef struct AmtGpuFrameStats AmtGpuFrameStats; /* self-specified CM / KFM who
 typedef int (*AMTGPU_LOGO_ANALYZE_CB)(float progress, int nread, int total, int ngather);
 
 int amtgpu_abi_version(void);
+/* How many copies of the HIP runtime (libamdhip64) are mapped into this process, and where from (newline-separated paths in `paths`,
+ * truncated to cap; may be NULL).  More than one -- e.g. this library bound to /opt/rocm's copy while another component brought its
+ * own -- means device pointers and streams of one are unknown to the other: copies fail with "invalid argument", kernels fault.
+ * A host that mixes ROCm users checks this once after loading everything (the Python mirror does, and loads torch first so that
+ * both bind to the same copy). */
+int amtgpu_hip_runtimes_loaded(char* paths, int cap);
 
 /* ---- context: replaces AMTContext_Create / ATMContext_Delete / AMTContext_GetError
  *      (StreamUtils.hpp:1037-1039) ---- */

@@ -36,6 +36,17 @@ def test_exports_every_declared_symbol(lib):
     assert lib.amtgpu_abi_version() == 3
 
 
+def test_hip_runtime_count_is_reported(lib):
+    """amtgpu_hip_runtimes_loaded: the copies of libamdhip64 mapped into the process, by path -- one here (the library's own)"""
+    buf = C.create_string_buffer(1024)
+    n = lib.amtgpu_hip_runtimes_loaded(buf, len(buf))
+    paths = buf.value.decode().split()
+    assert n == len(paths) >= 1 and all("libamdhip64.so" in p for p in paths)
+    assert lib.amtgpu_hip_runtimes_loaded(None, 0) == n
+    tiny = C.create_string_buffer(8)
+    assert lib.amtgpu_hip_runtimes_loaded(tiny, len(tiny)) == n and len(tiny.value) <= 7
+
+
 def test_no_gpu_means_loud_failure(lib):
     import torch
     if torch.cuda.is_available():
