@@ -389,7 +389,9 @@ void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitc
     int qlog2 = 24;
     while (qlog2 > 4 && std::ldexp(vwin, qlog2) >= 1073741824.0) --qlog2;
     if (!(std::ldexp(vwin, qlog2) < 1073741824.0)) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }   // (absurd coefficients: the exact kernel)
-    const int G = std::min(kLinMaxFrames, group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(8LL, (long long)nframes * nl / 2048)));
+    const int gmax = bits > 8 ? kLinMaxFrames16 : kLinMaxFrames;
+    const long long wgs_min = bits > 8 ? AMT_LIN_WGS_MIN16 : 2048;
+    const int G = std::min(gmax, group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(16LL, (long long)nframes * nl / wgs_min)));
     const size_t dot = prof_name_.find('.');
     const int sp = ctx_->prof_begin(("logo_eval_linear_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
     AMT_HIP(launch_logo_eval_linear(ctx_->stream, bits, d_logos_.get(), d_tls_.get(), nl, d_fades_.get(), 11, 0, dY, dframe_map,

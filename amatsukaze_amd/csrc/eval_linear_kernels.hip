@@ -376,7 +376,7 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     // (the caller guarantees dfades[fade0] == 0 and dfades[fade0 + nfades - 1] == 1: EvalEngine::run_linear)
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
     if (qlog2 < 4 || qlog2 > 24 || !(bin_eps >= 0.0f) || bin_eps * (float)(1 << qlog2) > 1048576.0f) return hipErrorInvalidValue;
-    if (nfades != 11 || G < 1 || G > kLinMaxFrames || G * nfades > kLinWgThreads) return hipErrorInvalidValue;       // (AMTAnalyzeLogo's fades; anything else keeps the exact kernel)
+    if (nfades != 11 || G < 1 || G > (bits > 8 ? kLinMaxFrames16 : kLinMaxFrames) || G * nfades > kLinWgThreads) return hipErrorInvalidValue;       // (AMTAnalyzeLogo's fades; anything else keeps the exact kernel)
     LinLaunch A;
     A.logos = dlogos; A.tls = dtls; A.fades = dfades; A.Y = dY; A.frame_map = dframe_map; A.frame_stride = frame_stride_elems; A.pitch = pitch;
     A.maxv = (float)((1 << bits) - 1);

@@ -39,6 +39,13 @@ constexpr int kLinMaxFades = 12;    // fades the linear kernel's source is writt
 #define AMT_LIN_G 6
 #endif
 constexpr int kLinMaxFrames = AMT_LIN_G;     // frames per workgroup of the linear kernel: bounded by the LDS its running sums take (three workgroups share a CU)
+#ifndef AMT_LIN_G16
+#define AMT_LIN_G16 8
+#endif
+constexpr int kLinMaxFrames16 = AMT_LIN_G16; // ... of its 16-bit instantiation, which runs two workgroups per CU (180 VGPRs) and has the LDS for more
+#ifndef AMT_LIN_WGS_MIN16
+#define AMT_LIN_WGS_MIN16 1024      /* (measured, 4 096-frame launches at 10 bits: 6 frames 1.749 ms, 8 frames 1.689, 10-12 frames 1.82) */
+#endif
 
 // a band = up to kEvalThreads consecutive run slots (one per thread) and the logo rows their windows touch
 struct EvalBand {

@@ -9,7 +9,14 @@ VARIANTS = {
     "w15_g5_occ4": ["AMT_PAIR_OCC=4", "AMT_TILE_WAVES=15", "AMT_TILE_G=5"],
     "w7_g6_occ4": ["AMT_PAIR_OCC=4", "AMT_TILE_WAVES=7", "AMT_TILE_G=6"],
     "w7_g8": ["AMT_TILE_WAVES=7", "AMT_TILE_G=8"],
+    # the 16-bit linear kernel runs two workgroups per CU: room for more frames per workgroup
+    "lin16_g8": ["AMT_LIN_G16=8"], "lin16_g8_1k": ["AMT_LIN_G16=8", "AMT_LIN_WGS_MIN16=1024"],
+    "lin16_g10_1k": ["AMT_LIN_G16=10", "AMT_LIN_WGS_MIN16=1024"], "lin16_g12_1k": ["AMT_LIN_G16=12", "AMT_LIN_WGS_MIN16=1024"],
+    "lin16_g4": ["AMT_LIN_G16=4"],
 }
+ONLY = [a for a in sys.argv[1:] if not a.startswith("--")]
+if ONLY:
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in ONLY}
 if "--build" in sys.argv:
     from amatsukaze_amd import build as B
     for name, defs in VARIANTS.items():
@@ -43,7 +50,7 @@ if "--child" in sys.argv:
         del Y
     print(json.dumps(out)); sys.exit(0)
 res = {}
-names = ["default"] + [v for v in VARIANTS if not sys.argv[1:] or v in sys.argv[1:]]
+names = ["default"] + list(VARIANTS)
 for name in names:
     env = dict(os.environ)
     if name != "default":
