@@ -141,6 +141,27 @@ inline TilePlan build_tile_plan(const std::vector<uint32_t>& pos, int count, int
             if ((int)groups.size() <= kTileWaves) break;
             n = std::max(1, n - std::max(1, n / 8));       // sparse stretch: a shorter band
         }
+        // Which wave takes which tile is free.  Waves are dealt to the CU's four SIMDs round-robin (wave w on SIMD w % 4: with eleven
+        // evaluation waves three each on SIMDs 0-2, two and the summing wave on SIMD 3), a SIMD issues for one wave at a time, and a
+        // tile with more than 64 staging units costs a second staging pass: the tiles go heaviest first to the SIMD with the least
+        // work so far (scan kernel 2.759 -> 2.712 ms per 10 000 frames; the records do not depend on it).
+        {
+            std::vector<size_t> order(groups.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            auto cost = [&](size_t i) { const Geometry G = bbox(groups[i], 0, groups[i].size()); return 131 + 31 * (G.nrows * G.ncol4 > kTileLanes ? 2 : 1); };
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost(a) > cost(b); });
+            int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, cap[4] = {0, 0, 0, 0};
+            for (int w = 0; w < kTileWaves; ++w) ++cap[w % 4];
+            std::vector<std::vector<Px>> placed(kTileWaves);
+            for (size_t i : order) {
+                int best = -1;
+                for (int k = 0; k < 4; ++k)
+                    if (used[k] < cap[k] && (best < 0 || load[k] < load[best])) best = k;
+                placed[best + 4 * used[best]] = groups[i];
+                load[best] += cost(i); ++used[best];
+            }
+            groups.swap(placed);                                  // (a wave without a tile keeps an empty group: npix 0, it idles through the band)
+        }
         const int band = (int)P.bands.size();
         P.bands.push_back(TileBandDesc{m, n});
         P.tiles.resize((size_t)(band + 1) * kTileWaves, TileDesc{0, 0, 0, 1, 4, 0, 65536, 0});
@@ -148,6 +169,7 @@ inline TilePlan build_tile_plan(const std::vector<uint32_t>& pos, int count, int
         P.slot_pixel.resize((size_t)(band + 1) * kTileBandPix, -1);
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const std::vector<Px>& g = groups[gi];
+            if (g.empty()) continue;
             const Geometry G = bbox(g, 0, g.size());
             // pitch: the candidate with the fewest LDS cycles per window read, the narrowest among equals
             int best_tp = G.ncol4 * 4, best_cyc = 1 << 30;
