@@ -1,7 +1,7 @@
 // stats_kernels.hip -- whole-frame field-difference / combing metrics (self-specified).
 //
 // Streaming reduction over the Y plane: every byte of every frame is read from HBM once.  A thread owns a 16-byte-wide column of a
-// 16-row tile for a RUN of consecutive frames ((tile, column) pairs are dealt densely to the threads of the grid), so the vertical
+// tile of 24 rows (8-bit samples; 16 rows at 16 bits) for a RUN of consecutive frames ((tile, column) pairs are dealt densely to the threads of the grid), so the vertical
 // neighbours (rows y-1, y+1) and the previous frame's rows are all in the thread's own registers -- no LDS staging, no re-reads
 // except the two halo rows per tile.  Loads are 16 B per lane, 64 lanes = 1 KiB contiguous per row.  The per-byte work is done four
 // pixels at a time with v_sad_u8 / v_lerp_u8 (two per instruction for 16-bit samples).
@@ -51,7 +51,14 @@ constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
 #ifndef AMT_STATS_NT
 #define AMT_STATS_NT 2         /* cache-policy bits of the loads of rows no other tile reads: 2 = nt (non-temporal) */
 #endif
-constexpr int kStatTileRows = AMT_STATS_ROWS;
+constexpr int kStatTileRows = AMT_STATS_ROWS;          // rows of a tile for 16-bit samples (two halo rows per tile are read twice)
+#ifndef AMT_STATS_ROWS8
+#define AMT_STATS_ROWS8 24
+#endif
+// 8-bit samples: 24 rows (halo 2 / 24 instead of 2 / 16 of the traffic; 244 VGPRs.  At 16 bits the same tile needs 256-264 and drops
+// to one wave per SIMD: measured 2.879 -> 2.818 ms at 8 bits, 2.077 -> 2.121 at 10 -- profiles/r04_notes.md section 4)
+constexpr int kStatTileRows8 = AMT_STATS_ROWS8;
+template <int ES> constexpr int stat_tile_rows() { return ES == 1 ? kStatTileRows8 : kStatTileRows; }
 constexpr int kStatRun = AMT_STATS_RUN;          // frames a workgroup walks through (the frame before a run is its one re-read: 1/32)
 constexpr int kStatXcds = 8;          // MI355X: 8 XCDs, workgroups are dealt to them round-robin by linear workgroup id
 constexpr int kStatWords = 8;
@@ -136,7 +143,8 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
                         const uint8_t* __restrict__ prevY /* frame before the batch or null */, int nframes, int col_groups,
                         unsigned long long* __restrict__ out)
 {
-    constexpr int R = kStatTileRows + 2;
+    constexpr int TR = stat_tile_rows<ES>();
+    constexpr int R = TR + 2;
     // (tile, lane column) pairs are dealt to threads densely -- `cols` columns per tile, no idle lanes when the
     // row is not a multiple of the workgroup's span (1440 bytes = 90 columns); a wave may straddle two tiles
     const int cols = col_groups;
@@ -157,7 +165,7 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         tile = gid / cols;
         xb = (gid - tile * cols) * kStatColBytes;                 // byte column of this thread
     }
-    const int y0 = tile * kStatTileRows;
+    const int y0 = tile * TR;
     const int nvalid = y0 < H ? min(kStatColBytes, row_bytes - xb) : 0;      // <= 0: thread has no pixels
     const int n0 = blockIdx.y * kStatRun;
     const int n1 = min(nframes, n0 + kStatRun);
@@ -216,7 +224,7 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     auto vert_even = [&](const Chunk* rows) {
         unsigned a = 0;
 #pragma unroll
-        for (int r = 1; r <= kStatTileRows; r += 2) {
+        for (int r = 1; r <= TR; r += 2) {
             const int y = y0 - 1 + r;
             if (y >= 1 && y <= H - 2) a = sad16<ES>(rows[r - 1], rows[r + 1], a);
         }
@@ -230,7 +238,7 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         unsigned ve = 0, vo = 0;
         const Chunk zero = chunk_zero();
 #pragma unroll
-        for (int r = 1; r <= kStatTileRows; ++r) {
+        for (int r = 1; r <= TR; ++r) {
             const int y = y0 - 1 + r;                  // rows >= H were loaded as zeros and add nothing
             const bool odd = ((r - 1) & 1) != 0;       // tiles start on even rows: a constant once unrolled
             acc[odd ? 1 : 0] = sad16<ES>(cur[r], prev[r], acc[odd ? 1 : 0]);
@@ -306,7 +314,8 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     const int es = bits <= 8 ? 1 : 2;
     const int row_bytes = W * es;
     const int col_groups = (row_bytes + kStatColBytes - 1) / kStatColBytes;     // lane columns per row
-    const int tiles = (H + kStatTileRows - 1) / kStatTileRows;
+    const int tile_rows = es == 1 ? kStatTileRows8 : kStatTileRows;
+    const int tiles = (H + tile_rows - 1) / tile_rows;
     // (the lean form addresses a frame with 32-bit byte offsets below 2^31)
     if ((long long)H * pitch_elems * es >= (1LL << 31)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
