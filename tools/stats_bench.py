@@ -9,7 +9,8 @@ VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean_no_nt": ["AMT_STATS_NT=0"], 
             "lean_8rows_prefetch": ["AMT_STATS_ROWS=8", "AMT_STATS_PREFETCH=1"], "lean_run64": ["AMT_STATS_RUN=64"],
             # taller tiles: the halo rows are 2 / ROWS of the traffic
             "rows24": ["AMT_STATS_ROWS=24"], "rows24_8B": ["AMT_STATS_ROWS=24", "AMT_STATS_COLB=8"], "rows32_8B": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"],
-            "rows32_8B_run64": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8", "AMT_STATS_RUN=64"]}
+            "rows32_8B_run64": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8", "AMT_STATS_RUN=64"],
+            "rows8bit_16": ["AMT_STATS_ROWS8=16"], "rows8bit_20": ["AMT_STATS_ROWS8=20"], "rows8bit_28": ["AMT_STATS_ROWS8=28"]}
 ONLY = [a for a in sys.argv[1:] if not a.startswith("--")]
 if ONLY:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in ONLY}
@@ -38,7 +39,7 @@ if "--child" in sys.argv:
         assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, words) == 0
         ctx.check(ctx.lib.amtgpu_context_set_stream(ctx.h, st))
     out = {}
-    for tag, (W, H, bits, pitch, N) in {"1440x1080_8bit": (1440, 1080, 8, 1472, 10000), "1920x1080_10bit": (1920, 1080, 10, 1920, 3000)}.items():
+    for tag, (W, H, bits, pitch, N) in {"1440x1080_8bit": (1440, 1080, 8, 1472, 10000), "1920x1080_8bit": (1920, 1080, 8, 1920, 6000), "1920x1080_10bit": (1920, 1080, 10, 1920, 3000)}.items():
         Y = S.make_clip_torch(N, W, H, 0x5EED0002, None, None, 0, 0, dev, bits=bits, pitchY=pitch, chroma=False)["Y"]
         fs = FrameStats(ctx, W, H, bits)
         o = torch.zeros((N, 8), dtype=torch.int64, device=dev)
