@@ -88,6 +88,10 @@ def test_logoframe_scan_bit_exact(gpu, tmp_path, cfgname, bits, pad):
     assert out.read_bytes() == buf.raw[:ln]
     if cfgname == "small" and bits == 8:
         assert ln > 0
+    # the same decisions from the records alone, on the host (what a rank does with gathered records)
+    from amatsukaze_amd.api import logoframe_decide_host
+    hbest, hratio, htext = logoframe_decide_host(got, 30000, 1001, numCandidates=2)
+    assert hbest == best.value and np.float32(hratio).tobytes() == np.float32(ratio.value).tobytes() and htext == buf.raw[:ln]
 
 
 def test_logoframe_scan_kernel_choice(gpu):
