@@ -224,11 +224,13 @@ private:
 };
 
 // kernel launcher (eval_fused_kernels.hip).  dnframes (device, optional): the number of frames actually present (<= nframes,
-// which then only sizes the grid); scatter != 0: frame i's results go to record dframe_map[i] of dout
+// which then only sizes the grid); scatter != 0: frame i's results go to record dframe_map[i] of dout; fade_chunk > 0 (with dnframes):
+// a workgroup evaluates fade_chunk of the fades, the chunks of a (logo, frame group) run side by side -- a handful of listed frames
+// is a latency problem (one workgroup walking every band for all fades), not a throughput one
 hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* dlogos, int nlogos, const EvalBand* dbands,
                                   const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
                                   long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
-                                  int take_abs, int plane_cap, const int* dnframes = nullptr, int scatter = 0);
+                                  int take_abs, int plane_cap, const int* dnframes = nullptr, int scatter = 0, int fade_chunk = 0);
 // eval_linear_kernels.hip
 hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                    const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,

@@ -399,6 +399,9 @@ void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitc
     ctx_->prof_end(sp);
 }
 
+#ifndef AMT_LISTED_FADE_CHUNK
+#define AMT_LISTED_FADE_CHUNK 1      /* fades per workgroup of the listed re-evaluation (0: all of them, round 3's form) */
+#endif
 void EvalEngine::run_listed(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int max_frames, const int* dlist,
                             const int* dcount, float* dout)
 {
@@ -414,7 +417,7 @@ void EvalEngine::run_listed(const void* dY, int64_t frame_stride_bytes, int pitc
         const int sp = ctx_->prof_begin((prof_name_ + "_refine").c_str());
         AMT_HIP(launch_logo_eval_fused(ctx_->stream, bits, d_logos_.get(), nl, d_bands_.get(), d_fades_.get(), nf, f0, dY, dlist,
                                        frame_stride_bytes / es, pitch, max_frames, G, dout, out_frame_stride_, take_abs_ ? 1 : 0,
-                                       plane_cap_, dcount, 1));
+                                       plane_cap_, dcount, 1, AMT_LISTED_FADE_CHUNK));
         ctx_->prof_end(sp);
     }
 }

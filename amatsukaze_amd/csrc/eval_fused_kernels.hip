@@ -422,7 +422,7 @@ void logo_eval_fused_kernel(const EvalLogoDev* __restrict__ logos, const EvalBan
                             int nfades, int fade0, const pix_t* __restrict__ Y, const int* __restrict__ frame_map,
                             long long frame_stride, int pitch, float maxv, int nframes, int G, int ngroups, float* __restrict__ out,
                             int out_frame_stride, int take_abs, int plane_cap, int sc_pitch, int dbg, const int* __restrict__ nframes_dev,
-                            int scatter, int nlogos)
+                            int scatter, int nlogos, int fade_chunk)
 {
     if (!nframes_dev) {
         logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, nframes, G, ngroups, out,
@@ -431,11 +431,16 @@ void logo_eval_fused_kernel(const EvalLogoDev* __restrict__ logos, const EvalBan
     }
     // listed re-evaluation (decision guard of the linear mode): the number of frames present sits on the device and is usually a
     // handful, so a small fixed grid walks the (logo, group) pairs that exist instead of launching the worst case
+    // The fades are independent of each other (one ordered sum per fade): with fade_chunk > 0 a (logo, group) pair is shared out over
+    // ceil(nfades / fade_chunk) workgroups, each walking the bands for its own fades only.
     const int present = min(*nframes_dev, nframes);
     const int groups = (present + G - 1) / G;
-    for (int b = (int)blockIdx.x; b < groups * nlogos; b += (int)gridDim.x) {
-        logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nfades, fade0, Y, frame_map, frame_stride, pitch, maxv, present, G, groups, out,
-                                         out_frame_stride, take_abs, plane_cap, sc_pitch, dbg, b, scatter);
+    const int nchunks = fade_chunk > 0 ? (nfades + fade_chunk - 1) / fade_chunk : 1;
+    for (int b = (int)blockIdx.x; b < groups * nlogos * nchunks; b += (int)gridDim.x) {
+        const int pair = b / nchunks, f0 = (b - pair * nchunks) * fade_chunk;
+        const int nf = fade_chunk > 0 ? min(fade_chunk, nfades - f0) : nfades;
+        logo_eval_fused_body<pix_t, FPI>(logos, bands, fades, nf, fade0 + f0, Y, frame_map, frame_stride, pitch, maxv, present, G, groups, out,
+                                         out_frame_stride, take_abs, plane_cap, sc_pitch, dbg, pair, scatter);
         __syncthreads();
     }
 }
@@ -448,7 +453,7 @@ static size_t fused_lds_bytes(int plane_cap, int nfades, int sc_pitch, int G, in
 hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* dlogos, int nlogos, const EvalBand* dbands,
                                   const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
                                   long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
-                                  int take_abs, int plane_cap, const int* dnframes, int scatter)
+                                  int take_abs, int plane_cap, const int* dnframes, int scatter, int fade_chunk)
 {
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
     if (scatter && !dframe_map) return hipErrorInvalidValue;
@@ -467,7 +472,9 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
     const float maxv = (float)((1 << bits) - 1);
     const int sc_pitch = kEvalBandPixels + kEvalScorePad;
     // listed mode: a fixed small grid that strides over the (logo, group) pairs present
-    dim3 grid(dnframes ? (unsigned)std::min<long long>((long long)ngroups * nlogos, 1024) : (unsigned)((long long)ngroups * nlogos));
+    if (fade_chunk < 0 || (fade_chunk > 0 && !dnframes)) return hipErrorInvalidValue;
+    const int nchunks = fade_chunk > 0 ? (nfades + fade_chunk - 1) / fade_chunk : 1;
+    dim3 grid(dnframes ? (unsigned)std::min<long long>((long long)ngroups * nlogos * nchunks, 1024) : (unsigned)((long long)ngroups * nlogos));
     // two frames per iteration while the planes and score rows of both fit half a CU's LDS (two workgroups per CU)
     int fpi = fpi_env > 0 ? std::min(2, fpi_env) : 2;
     if (G < 2 || fused_lds_bytes(plane_cap, nfades, sc_pitch, G, 2) > 80 * 1024 - 512) fpi = 1;
@@ -475,7 +482,7 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
 #define AMT_LAUNCH(T, F)                                                                                                          \
     hipLaunchKernelGGL((logo_eval_fused_kernel<T, F>), grid, dim3(kEvalThreads), lds, st, dlogos, dbands, dfades, nfades, fade0,         \
                        (const T*)dY, dframe_map, frame_stride_elems, pitch, maxv, nframes, G, ngroups, dout, out_frame_stride, take_abs, \
-                       plane_cap, sc_pitch, dbg, dnframes, scatter, nlogos)
+                       plane_cap, sc_pitch, dbg, dnframes, scatter, nlogos, fade_chunk)
     if (fpi == 2) { if (bits <= 8) AMT_LAUNCH(uint8_t, 2); else AMT_LAUNCH(uint16_t, 2); }
     else { if (bits <= 8) AMT_LAUNCH(uint8_t, 1); else AMT_LAUNCH(uint16_t, 1); }
 #undef AMT_LAUNCH

@@ -13,6 +13,8 @@ VARIANTS = {
     "lin16_g8": ["AMT_LIN_G16=8"], "lin16_g8_1k": ["AMT_LIN_G16=8", "AMT_LIN_WGS_MIN16=1024"],
     "lin16_g10_1k": ["AMT_LIN_G16=10", "AMT_LIN_WGS_MIN16=1024"], "lin16_g12_1k": ["AMT_LIN_G16=12", "AMT_LIN_WGS_MIN16=1024"],
     "lin16_g4": ["AMT_LIN_G16=4"],
+    # listed re-evaluation of the linear mode's guard: fades per workgroup (0 = all eleven in one workgroup)
+    "listed0": ["AMT_LISTED_FADE_CHUNK=0"], "listed2": ["AMT_LISTED_FADE_CHUNK=2"], "listed4": ["AMT_LISTED_FADE_CHUNK=4"],
 }
 ONLY = [a for a in sys.argv[1:] if not a.startswith("--")]
 if ONLY:
@@ -43,7 +45,7 @@ if "--child" in sys.argv:
             an.analyze_device(Y, bits, o); lf.scan_batch(Y, bits, 0, N)
         torch.cuda.synchronize()
         rep = ctx.profile_report(); ctx.profile(False)
-        r = {k.split(".")[0]: ms / c for k, (c, ms) in rep.items() if c and ("pair" in k or "linear" in k)}
+        r = {(k.split(".")[0] if "refine" not in k else "refine"): ms / c for k, (c, ms) in rep.items() if c and ("pair" in k or "linear" in k or "refine" in k)}
         r["scan_sha"] = hashlib.sha256(lf.evalResults.tobytes()).hexdigest()[:16]
         r["analysis_sha"] = hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest()[:16]
         out[tag] = r
