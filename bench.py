@@ -351,6 +351,135 @@ def tolerance_accounting(lin, exact, fades_lin, eraser, analyzer, N):
     return out
 
 
+
+# --------------------------------------------------------------------------------------------------------------------
+# the printed line: ONE compact JSON object (< 6 KB) as the LAST line of stdout; everything else goes to bench_detail.json
+# --------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6144
+DETAIL_NAME = "bench_detail.json"
+
+
+def _r(x, sig=6):
+    """floats to 6 significant digits (a line that carries 17-digit floats is mostly digits)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short(s, n=120):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(full):
+    """The driver-facing line: the contract's scalar keys, `roofline`, `roofline_second`, `cpu_baseline`, `exact_mode`, `verified` and one
+    scalar per attached measurement.  Prose (`what` / `note`), per-kernel tables, sweeps and histograms stay in bench_detail.json."""
+    g = lambda d, *path: (g(d.get(path[0]), *path[1:]) if len(path) > 1 else d.get(path[0])) if isinstance(d, dict) else None
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    line["config"] = {k: _short(v) for k, v in cfg.items() if v is not None and not isinstance(v, dict)}
+    for k in ("timed_region_s", "collectives"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+
+    def roof(r):
+        if not r:
+            return None
+        o = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "flops_per_launch",
+                  "algorithmic_bytes_per_launch", "cus")
+        o.setdefault("traffic", None)
+        if r.get("traffic_source"):
+            o["traffic_source"] = r["traffic_source"].split(" ")[0]
+        return o
+    if "roofline" in full:
+        line["roofline"] = roof(full["roofline"])
+    if full.get("roofline_second"):
+        line["roofline_second"] = roof(full["roofline_second"])
+    cpu = full.get("cpu_baseline")
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = None
+    if cpu:
+        c = _pick(cpu, "value", "unit", "cores", "kind", "logo_passes_only_fps")
+        c["sample"] = _short(cpu.get("sample_short") or cpu.get("sample"), 110)
+        if cpu.get("all_cores"):
+            c["all_cores"] = _pick(cpu["all_cores"], "value", "cores")
+        if cpu.get("reference_check"):
+            c["reference_check"] = _pick(cpu["reference_check"], "oracle_equals_reference", "frames")
+        line["cpu_baseline"] = c
+        line.update(_pick(full, "gpu_over_cpu", "gpu_over_cpu_all_cores"))
+    if full.get("exact_mode"):
+        line["exact_mode"] = _pick(full["exact_mode"], "value", "ms_per_step", "steps")
+    v = full.get("verified")
+    if v:
+        o = _pick(v, "ok", "frames", "scan", "analysis", "fades", "erase", "metrics", "oracle", "analysis_max_abs_err", "analysis_max_abs",
+                  "fades_equal_all", "guard_refined_frames", "tolerance_ok", "seconds")
+        rel = g(v, "analysis_max_rel", "floor_0.001")
+        if rel is not None:
+            o["analysis_max_rel_floor_1e-3"] = rel
+        line["verified"] = o
+    ks = full.get("kernels")
+    if ks:      # name -> [avg launch ms, fraction of its roofline or null]: the table itself is in the detail file
+        line["kernels_ms_frac"] = {n: [e.get("avg_ms"), e.get("frac_fp32_peak", e.get("frac"))] for n, e in ks.items()}
+    e2e = full.get("e2e10")
+    if e2e:
+        line["e2e10"] = (_pick(e2e, "error") or
+                         {**_pick(e2e, "value", "frames_total", "n_gpus", "scaling", "timed_s"), "verified_ok": g(e2e, "verified", "ok"),
+                          "verified_frames": g(e2e, "verified", "frames_compared_with_cpu_oracle"),
+                          "decisions_sha256": (e2e.get("decisions_sha256") or "")[:16]})
+    cf = full.get("configs")
+    if cf:
+        line["configs"] = {n: (_pick(c, "error") or {**_pick(c, "value", "frames"), **({"verified_frames": g(c, "verified", "frames")}
+                                                                                         if g(c, "verified", "frames") else {})})
+                           for n, c in cf.items() if isinstance(c, dict)}
+    ss = full.get("strong_scan")
+    if ss:
+        line["strong_scan"] = (_pick(ss, "error") or
+                               {**_pick(ss, "value", "frames_total", "n_gpus", "ms_per_step"), "records_sha256": (ss.get("records_sha256") or "")[:16],
+                                "scanlogo_value": g(ss, "scanlogo", "value"), "lgd_sha256": (g(ss, "scanlogo", "lgd_sha256") or "")[:16]})
+    ing = full.get("ingest")
+    if ing:
+        line["ingest"] = _pick(ing, "error") or {"y_plane": _pick(ing.get("y_plane") or {}, "pipelined_fps", "ingest_GBs"),
+                                                 "logo_rows": _pick(ing.get("logo_rectangle_rows") or {}, "pipelined_fps", "ingest_GBs")}
+    bd = full.get("boundary")
+    if bd:
+        line["boundary"] = _pick(bd, "error") or {k: x for k, x in bd.items() if k.endswith("_fps")}
+    line["detail"] = DETAIL_NAME
+    line = _r(line)
+    # never lose the line to its own size: drop the optional parts, least important first
+    for k in ("kernels_ms_frac", "boundary", "ingest", "configs", "strong_scan", "e2e10", "roofline_second"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+def emit(full):
+    """detail -> bench_detail.json (next to the script, and gpurun_out/ where that exists) and stderr; the compact line -> stdout, last"""
+    line = compact_line(full)
+    blob = json.dumps(full, indent=1, default=str)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, DETAIL_NAME), "w") as f:
+                    f.write(blob + "\n")
+        except OSError:
+            pass
+    print(json.dumps({"bench_detail": full}, default=str), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+    return line
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -434,7 +563,7 @@ def main():
                     "config": {"workload": r["workload"], "frames_total": r["frames_total"], "logo": f"{LW}x{LH}@(1600,64)", "maskratio": MASKRATIO,
                                "analysis_mode": args.analysis_mode, "parallelism": f"frames sharded x{world}"},
                     "collectives": rccl, "e2e10": r}
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -529,7 +658,7 @@ def main():
                     "config": {"workload": ss["workload"], "frames_total": ss["frames_total"], "logo": f"{LW}x{LH}@({IMGX},{IMGY})",
                                "maskratio": MASKRATIO, "parallelism": f"frames sharded x{world}"},
                     "collectives": rccl, "strong_scan": ss}
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -906,8 +1035,7 @@ def main():
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"single MI355X: {N}-frame 1440x1080i 8-bit YUV420 resident in HBM; AMTAnalyzeLogo + LogoFrame scan (3 logos) "
-                                   "+ CM/KFM frame metrics + CalcFade + AMTEraseLogo (BASELINE configs[1])",
+            "config": {"workload": f"BASELINE configs[1]: {N} frames 1440x1080i 8-bit in HBM; AMTAnalyzeLogo + LogoFrame scan x3 + CM/KFM metrics + CalcFade + AMTEraseLogo",
                        "analysis_mode": args.analysis_mode, "calc_fade": args.fades,
                        "device_partition": ({"metrics_cus": MCU, "logo_cus": NCU - MCU, "how": "two contexts on CU-range streams (amtgpu_stream_create_cu_range): the "
                                              "frame metrics run beside the analysis + scan; erase waits for both"} if MCU else None),
@@ -921,7 +1049,7 @@ def main():
             "verified": verified, "configs": configs, "e2e10": e2e, "boundary": boundary, "strong_scan": strong, "ingest": ingest,
             "kernels": out_kern,
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,71 @@
+"""The driver reads ONE JSON line from bench.py's stdout; round 4's grew to 20 KB and was not parsed.  bench.compact_line() must keep the
+printed line under 6 KB whatever the attached measurements carry, with the contract's keys, `roofline` and `cpu_baseline` intact."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _canned():
+    # a real full-size line: round 4's 20 KB one
+    return json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
+
+
+def test_compact_line_is_small_and_round_trips():
+    full = _canned()
+    assert len(json.dumps(full)) > 16000                      # the input really is the line that broke the reader
+    line = bench.compact_line(full)
+    s = json.dumps(line)
+    assert len(s) < bench.LINE_LIMIT == 6144
+    assert "\n" not in s
+    back = json.loads(s)
+    assert back == line
+    for k in CONTRACT:
+        assert k in back, k
+    assert back["value"] == float(f"{full['value']:.6g}") and back["n_gpus"] == 1 and back["scaling"] == "weak"
+    assert back["config"]["workload"]
+    r = back["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    c = back["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["all_cores"]["cores"] == 256 and c["reference_check"]["oracle_equals_reference"] is True
+    assert back["verified"]["ok"] is True and back["exact_mode"]["value"] > 0
+    assert back["e2e10"]["value"] > 0 and back["strong_scan"]["value"] > 0 and back["ingest"]["y_plane"]["pipelined_fps"] > 0
+    assert all(len(v) <= 120 for v in back["config"].values() if isinstance(v, str))
+
+
+def test_compact_line_sheds_optional_parts_before_it_outgrows_the_reader():
+    full = _canned()
+    full["kernels"] = {f"kernel_with_a_long_name_{i:04d}": {"avg_ms": 1.0 / 3, "frac": 0.1} for i in range(200)}
+    full["boundary"] = {f"path_{i}_fps": i for i in range(300)}
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    for k in CONTRACT + ("roofline", "cpu_baseline", "verified"):
+        assert k in line, k
+
+
+def test_compact_line_of_the_sharded_variants():
+    # --scaling strong / --workload e2e10 lines carry no roofline of their own; they must still be small and parse
+    full = _canned()
+    for key in ("strong_scan", "e2e10"):
+        line = bench.compact_line({**{k: full[k] for k in CONTRACT}, "collectives": full["collectives"], key: full[key]})
+        assert len(json.dumps(line)) < 2048 and line[key]["value"] > 0
+
+
+def test_emit_prints_the_compact_line_last(capsys, tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    full = _canned()
+    bench.emit(full)
+    cap = capsys.readouterr()
+    last = cap.out.strip().splitlines()[-1]
+    assert len(last) < bench.LINE_LIMIT and json.loads(last)["roofline"]["kernel"] == full["roofline"]["kernel"]
+    assert json.loads(cap.err.strip().splitlines()[-1])["bench_detail"]["kernels"] == full["kernels"]      # the detail goes to stderr ...
+    assert json.load(open(tmp_path / bench.DETAIL_NAME))["ingest"] == full["ingest"]                      # ... and next to the script
