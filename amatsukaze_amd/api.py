@@ -339,10 +339,10 @@ def logoframe_decide_host(evals, fps_num=30000, fps_den=1001, numCandidates=-1, 
     n, nl = int(ev.shape[0]), int(ev.shape[1])
     best, ratio, tl = C.c_int(-1), C.c_float(0.0), C.c_int(0)
     args = (_p(ev), n, nl, numCandidates, logoIndex, fps_num, fps_den, C.byref(best), C.byref(ratio))
-    if not lib.amtgpu_logoframe_decide_host(*args, None, 0, C.byref(tl)):
+    if lib.amtgpu_logoframe_decide_host(*args, None, 0, C.byref(tl)) != 1:
         raise AmtError("amtgpu_logoframe_decide_host: bad arguments")
     buf = C.create_string_buffer(max(1, tl.value))
-    if not lib.amtgpu_logoframe_decide_host(*args, buf, tl.value, C.byref(tl)):
+    if lib.amtgpu_logoframe_decide_host(*args, buf, tl.value, C.byref(tl)) != 1:
         raise AmtError("amtgpu_logoframe_decide_host failed")
     return best.value, ratio.value, buf.raw[:tl.value]
 

@@ -82,6 +82,8 @@ void amtgpu_context_destroy(AmtGpuContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     amt::context_stop_threads(c);                      // keep-alive heartbeat and staging workers
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);    // no copy may still read a slot or a registered range below
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& r : c->registered) (void)hipHostUnregister((void*)r.first);
     for (auto& sp : c->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
@@ -466,13 +468,15 @@ int amtgpu_logoframe_decide_host(const float* evals, int num_frames, int num_log
 {
     try {
         if (!evals || num_frames < 0 || num_logos <= 0 || fps_num <= 0 || fps_den <= 0 || logo_index >= num_logos) return 0;
+        if (num_candidates > num_logos) return 0;               // the records hold num_logos pairs per frame, no more
         const LogoSelection sel = select_logo(evals, num_frames, num_logos, num_candidates);
         if (best_logo) *best_logo = sel.bestLogo;
         if (logo_ratio) *logo_ratio = sel.logoRatio;
         const int li = logo_index < 0 ? sel.bestLogo : logo_index;
         const std::string t = li < 0 ? std::string() : logoframe_text(evals, num_frames, num_logos, li, fps_num, fps_den);
         if (text_len) *text_len = (int)t.size();
-        if (!text || cap < (int)t.size()) return text == nullptr && cap == 0 ? 1 : 0;
+        if (!text && cap == 0) return 1;                        // a length query
+        if (!text || cap < (int)t.size()) return -1;            // buffer too small: *text_len says how much it takes
         std::memcpy(text, t.data(), t.size());
         return 1;
     } catch (...) { return 0; }
@@ -482,6 +486,7 @@ int amtgpu_logoframe_select_logo(AmtGpuLogoFrame* lf, int ncand)
 {
     return guard(lf->ctx, [&] {
         logoframe_sync_results(lf);
+        if (ncand > (int)lf->logos.size()) throw std::runtime_error("num_candidates exceeds the number of logos");
         lf->sel = select_logo(lf->results.data(), lf->numFrames, (int)lf->logos.size(), ncand);
         lf->selected = true;
     });

@@ -10,7 +10,9 @@
 // uploads from inside a registered range skip the ring altogether.
 #include "../../include/amt_gpu.h"
 
+#if defined(__x86_64__)
 #include <emmintrin.h>
+#endif
 
 #include <atomic>
 #include <chrono>
@@ -27,6 +29,17 @@ hipError_t launch_ingest_rows(hipStream_t st, const void* src_host_mapped, long 
                               unsigned long long chunk, long long nchunks);
 }
 using namespace amt;
+
+namespace {
+inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+} // namespace
 
 // ---------------------------------------------------------------------------------------------
 // staging workers: a fixed set of threads that run slices of one job at a time (the caller takes a slice itself)
@@ -81,11 +94,11 @@ struct AmtGpuContext::UploadPool {
             while ((g = generation.load(std::memory_order_acquire)) == seen && !stop.load(std::memory_order_relaxed)) {
                 if ((++polls & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) {
                     std::unique_lock<std::mutex> lk(m);
-                    sleepers.fetch_add(1);
-                    cv_work.wait(lk, [&] { return generation.load(std::memory_order_acquire) != seen || stop.load(); });
+                    sleepers.fetch_add(1, std::memory_order_seq_cst);
+                    cv_work.wait(lk, [&] { return generation.load(std::memory_order_seq_cst) != seen || stop.load(); });
                     sleepers.fetch_sub(1);
                 } else {
-                    __builtin_ia32_pause();
+                    cpu_relax();
                 }
             }
             if (stop.load(std::memory_order_relaxed)) return;
@@ -103,10 +116,13 @@ struct AmtGpuContext::UploadPool {
         pending.store(n, std::memory_order_relaxed);
         const uint64_t g = generation.load(std::memory_order_relaxed) + 1;
         claim.store(((g & 0xFFFFFF) << 40) | ((uint64_t)n << 20), std::memory_order_release);
-        generation.store(g, std::memory_order_release);
-        if (sleepers.load() > 0) { { std::lock_guard<std::mutex> lk(m); } cv_work.notify_all(); }
+        // Dekker-style handshake with loop(): store generation, THEN read sleepers -- against a worker's increment sleepers, THEN read
+        // generation.  Both sides must be sequentially consistent (a release store may pass the later load on x86: a missed wake-up
+        // would leave the worker asleep through the job).
+        generation.store(g, std::memory_order_seq_cst);
+        if (sleepers.load(std::memory_order_seq_cst) > 0) { { std::lock_guard<std::mutex> lk(m); } cv_work.notify_all(); }
         work();
-        while (pending.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+        while (pending.load(std::memory_order_acquire) > 0) cpu_relax();
         // (a worker that wakes late finds no slice left in `claim` and leaves `job` alone: it is only dereferenced for a claimed slice)
     }
 };
@@ -195,6 +211,9 @@ AmtGpuContext::UploadPool* pool_of(AmtGpuContext* c)
 // heads and tails, small pieces) goes through memcpy.
 inline void stream_copy(uint8_t* dst, const uint8_t* src, size_t n)
 {
+#if !defined(__x86_64__)
+    std::memcpy(dst, src, n);
+#else
     if (n < 4096 || ((uintptr_t)dst & 15)) { std::memcpy(dst, src, n); return; }
     size_t i = 0;
     for (; i + 64 <= n; i += 64) {
@@ -207,6 +226,7 @@ inline void stream_copy(uint8_t* dst, const uint8_t* src, size_t n)
     }
     _mm_sfence();
     if (i < n) std::memcpy(dst + i, src + i, n - i);
+#endif
 }
 
 // dst <- src, n bytes, shared out over the staging threads in kSliceBytes pieces

@@ -76,17 +76,22 @@ std::string logoframe_text(const float* evals, int numFrames, int numLogos, int 
             const int byMean = (std::abs(mean) < kUnknownBelow) ? 1 : (mean < 0.0f) ? 0 : 2;
             state[i] = (byMinMax == byMean) ? byMinMax : 1;
         }
+        // The median slides a window kept in ascending order.  NaN evidence (corr0 = +inf with corr1 = -inf: a logo whose blackScore
+        // is 0) has no place in `<`: the reference's std::sort over it is undefined behaviour (LogoScan.hpp:1745-1747), so the
+        // order is fixed here -- NaN after every number, like the checker -- and every search below is bounded.
         const int K = 2 * halfMed + 1;
-        std::vector<float> win(ev - halfMed, ev - halfMed + K);       // the window of frame 0, then kept in ascending order
-        std::sort(win.begin(), win.end());
+        auto lt = [](float a, float b) { return a < b || (b != b && a == a); };
+        auto same = [](float a, float b) { return a == b || (a != a && b != b); };
+        std::vector<float> win(ev - halfMed, ev - halfMed + K);       // the window of frame 0
+        std::sort(win.begin(), win.end(), lt);
         for (int i = 0; i < N; ++i) {
             smooth[i] = win[halfMed];
             if (i + 1 == N) break;
             const float out = ev[i - halfMed], in = ev[i + 1 + halfMed];
             int k = 0;
-            while (win[k] != out) ++k;
-            for (; k + 1 < K && win[k + 1] < in; ++k) win[k] = win[k + 1];    // the gap moves up ...
-            for (; k > 0 && win[k - 1] > in; --k) win[k] = win[k - 1];        // ... or down to where `in` belongs
+            while (k + 1 < K && !same(win[k], out)) ++k;
+            for (; k + 1 < K && lt(win[k + 1], in); ++k) win[k] = win[k + 1];    // the gap moves up ...
+            for (; k > 0 && lt(in, win[k - 1]); --k) win[k] = win[k - 1];        // ... or down to where `in` belongs
             win[k] = in;
         }
     }
@@ -113,8 +118,9 @@ std::string logoframe_text(const float* evals, int numFrames, int numLogos, int 
         const int onAt = firstFrom(cur, [&](int i) { return state[i] == 2; });
         const int offAt = firstFrom(onAt, [&](int i) { return state[i] == 0; });
         int sEnd = onAt, eEnd = offAt;
-        if (sEnd != N) sEnd = above(sEnd) ? lastBefore(sEnd, 0, [&](int i) { return !above(i); }) : firstFrom(sEnd, above);
-        if (eEnd != N) eEnd = below(eEnd) ? lastBefore(eEnd, sEnd, [&](int i) { return !below(i); }) : firstFrom(eEnd, below);
+        // (`< T` and `> -T` as the reference writes them, not `!above` / `!below`: they differ on a NaN median)
+        if (sEnd != N) sEnd = above(sEnd) ? lastBefore(sEnd, 0, [&](int i) { return smooth[i] < kUnknownBelow; }) : firstFrom(sEnd, above);
+        if (eEnd != N) eEnd = below(eEnd) ? lastBefore(eEnd, sEnd, [&](int i) { return smooth[i] > -kUnknownBelow; }) : firstFrom(eEnd, below);
         const int sStart = lastBefore(sEnd, cur, below);
         const int eStart = lastBefore(eEnd, sEnd, above);
         int sBest = sStart;

@@ -58,7 +58,8 @@ constexpr int kStatTileRows = AMT_STATS_ROWS;          // rows of a tile for 16-
 // 8-bit samples: 24 rows (halo 2 / 24 instead of 2 / 16 of the traffic; 244 VGPRs.  At 16 bits the same tile needs 256-264 and drops
 // to one wave per SIMD: measured 2.879 -> 2.818 ms at 8 bits, 2.077 -> 2.121 at 10 -- profiles/r04_notes.md section 4)
 constexpr int kStatTileRows8 = AMT_STATS_ROWS8;
-template <int ES> constexpr int stat_tile_rows() { return ES == 1 ? kStatTileRows8 : kStatTileRows; }
+constexpr int kStatTileRowsPlain = 8;          // the plain-load fallback (BUF = false, rare geometries): byte-wise tails cost registers
+template <int ES, bool BUF = true> constexpr int stat_tile_rows() { return !BUF ? kStatTileRowsPlain : ES == 1 ? kStatTileRows8 : kStatTileRows; }
 constexpr int kStatRun = AMT_STATS_RUN;          // frames a workgroup walks through (the frame before a run is its one re-read: 1/32)
 constexpr int kStatXcds = 8;          // MI355X: 8 XCDs, workgroups are dealt to them round-robin by linear workgroup id
 constexpr int kStatWords = 8;
@@ -137,13 +138,16 @@ __device__ __forceinline__ unsigned wave_sum_to_lane63(unsigned v)
 #endif
 // RAGGED: the row is not a whole number of lane columns (the last column's tail bytes are masked); the common widths -- multiples of 16
 // bytes -- take the version without the masks
-template <int ES, bool RAGGED>
+// BUF: rows come in through raw buffer loads whose bounds check supplies the zeros (the lean form below).  It needs every 16-byte
+// column of a row to end inside the row's pitch -- a ragged row in an unpadded pitch (W = 362, pitch = 362) would have its last column
+// of the bottom row straddle the end of the buffer and lose its valid bytes; such geometries take the plain loads (BUF = false).
+template <int ES, bool RAGGED, bool BUF>
 __global__ __launch_bounds__(kStatThreads) AMT_STATS_OCC
 void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*bytes*/, int pitch_bytes, int row_bytes, int H,
                         const uint8_t* __restrict__ prevY /* frame before the batch or null */, int nframes, int col_groups,
                         unsigned long long* __restrict__ out)
 {
-    constexpr int TR = stat_tile_rows<ES>();
+    constexpr int TR = stat_tile_rows<ES, BUF>();
     constexpr int R = TR + 2;
     // (tile, lane column) pairs are dealt to threads densely -- `cols` columns per tile, no idle lanes when the
     // row is not a multiple of the workgroup's span (1440 bytes = 90 columns); a wave may straddle two tiles
@@ -170,7 +174,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     const int n0 = blockIdx.y * kStatRun;
     const int n1 = min(nframes, n0 + kStatRun);
 
-#if AMT_STATS_LEAN
     // A frame is a raw buffer of H * pitch bytes: the bounds check of the buffer load returns zeros for everything outside it -- the
     // row above the first tile (offset wraps far past the end), the rows below the frame, and ALL rows of a lane that owns no pixels
     // (its offset is parked past the end).  One VGPR holds the lane's offset; the 18 row offsets are scalar multiples of the pitch.
@@ -184,6 +187,15 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         bmask[i] = !RAGGED || k >= 4 ? 0xFFFFFFFFu : (k <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (4 - k))));
     }
     auto load_rows = [&](const uint8_t* frame, Chunk* rows) {
+        if constexpr (!BUF) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 - 1 + r;
+                rows[r] = (nvalid > 0 && y >= 0 && y < H) ? load_chunk(frame + (long long)y * pitch_bytes + xb, nvalid)
+                                                         : chunk_zero();
+            }
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frame), 0, (int)frame_bytes, 0x00027000);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -207,16 +219,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
             }
         }
     };
-#else
-    auto load_rows = [&](const uint8_t* frame, Chunk* rows) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int y = y0 - 1 + r;
-            rows[r] = (nvalid > 0 && y >= 0 && y < H) ? load_chunk(frame + (long long)y * pitch_bytes + xb, nvalid)
-                                                     : chunk_zero();
-        }
-    };
-#endif
 
     // Even-row vertical detail of a row set: sum over the tile's even rows y (1 <= y <= H-2) of |rows[y-1] - rows[y+1]|.  The weave of
     // frame n takes its odd rows from frame n-1, so its VERT term on an even row looks at rows of frame n-1 only: that is this sum of
@@ -314,7 +316,8 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     const int es = bits <= 8 ? 1 : 2;
     const int row_bytes = W * es;
     const int col_groups = (row_bytes + kStatColBytes - 1) / kStatColBytes;     // lane columns per row
-    const int tile_rows = es == 1 ? kStatTileRows8 : kStatTileRows;
+    const bool buf = AMT_STATS_LEAN && (long long)col_groups * kStatColBytes <= (long long)pitch_elems * es;   // see the kernel's BUF
+    const int tile_rows = !buf ? kStatTileRowsPlain : es == 1 ? kStatTileRows8 : kStatTileRows;
     const int tiles = (H + tile_rows - 1) / tile_rows;
     // (the lean form addresses a frame with 32-bit byte offsets below 2^31)
     if ((long long)H * pitch_elems * es >= (1LL << 31)) return hipErrorInvalidValue;
@@ -327,11 +330,11 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
 #ifndef AMT_STATS_LDS_BYTES
 #define AMT_STATS_LDS_BYTES 0      /* experiments: an LDS reservation the kernel never touches caps its workgroups per CU */
 #endif
-#define AMT_STATS_LAUNCH(E, RG)                                                                                                           \
-    hipLaunchKernelGGL((frame_stats_kernel<E, RG>), grid, block, AMT_STATS_LDS_BYTES, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es, row_bytes, H, \
+#define AMT_STATS_LAUNCH(E, RG, BF)                                                                                                          \
+    hipLaunchKernelGGL((frame_stats_kernel<E, RG, BF>), grid, block, AMT_STATS_LDS_BYTES, st, (const uint8_t*)dY, frame_stride_bytes, pitch_elems * es, row_bytes, H, \
                        (const uint8_t*)dprevY, nframes, col_groups, dout)
-    if (es == 1) { if (ragged) AMT_STATS_LAUNCH(1, true); else AMT_STATS_LAUNCH(1, false); }
-    else { if (ragged) AMT_STATS_LAUNCH(2, true); else AMT_STATS_LAUNCH(2, false); }
+    if (es == 1) { if (!buf) AMT_STATS_LAUNCH(1, true, false); else if (ragged) AMT_STATS_LAUNCH(1, true, true); else AMT_STATS_LAUNCH(1, false, true); }
+    else { if (!buf) AMT_STATS_LAUNCH(2, true, false); else if (ragged) AMT_STATS_LAUNCH(2, true, true); else AMT_STATS_LAUNCH(2, false, true); }
 #undef AMT_STATS_LAUNCH
     return hipGetLastError();
 }

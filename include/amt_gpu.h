@@ -231,7 +231,9 @@ int  amtgpu_logoframe_best_logo(const AmtGpuLogoFrame* lf);
 /* The same two decisions -- LogoFrame::selectLogo and the text LogoFrame::writeResult writes (LogoScan.hpp:1647-1827) -- from scan
  * records alone, on the host, no device and no LogoFrame object: what a rank (or a tool) that only holds the gathered
  * records [num_frames][num_logos]{corr0, corr1} needs.  logo_index -1 = the selected logo.  text may be NULL (cap 0) to ask for
- * the length; returns 0 when cap is too small (text_len is still set).  O(1) work per frame. */
+ * the length.  Returns 1 = done, 0 = bad arguments (NULL records, logo_index or num_candidates > num_logos, fps <= 0), -1 = cap
+ * too small (text_len is still set).  O(1) work per frame.  Evidence that is NaN (corr0 = +inf with corr1 = -inf) sorts after
+ * every number in the median window -- the reference's std::sort over it is undefined. */
 int  amtgpu_logoframe_decide_host(const float* evals, int num_frames, int num_logos, int num_candidates, int logo_index,
                                   int fps_num, int fps_den, int* best_logo, float* logo_ratio, char* text, int cap, int* text_len);
 float amtgpu_logoframe_logo_ratio(const AmtGpuLogoFrame* lf);

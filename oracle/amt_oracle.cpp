@@ -724,7 +724,9 @@ int orc_logoframe_write_result(const float* evals, int numFrames, int numLogos, 
         int avgResult = (std::abs(avg) < THRESH) ? 1 : (avg < 0.0f) ? 0 : 2;
         result[i] = (minMaxResult != avgResult) ? 1 : minMaxResult;
         std::copy(raw + i - halfMedianFrames, raw + i + halfMedianFrames + 1, medianBuf.begin());
-        std::sort(medianBuf.begin(), medianBuf.end());
+        // NaN evidence (corr0 = +inf, corr1 = -inf) makes the reference's plain std::sort undefined behaviour (:1746); the checker
+        // fixes the order -- NaN after every number -- which is the reference's own result whenever the window holds no NaN
+        std::sort(medianBuf.begin(), medianBuf.end(), [](float a, float b) { return a < b || (b != b && a == a); });
         score[i] = medianBuf[halfMedianFrames];
     }
     const int N = numFrames;

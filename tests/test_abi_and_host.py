@@ -231,6 +231,11 @@ def test_logoframe_decisions_on_the_host_match_the_oracle(lib, fps):
                 ev[:, l, 0] = on * 0.9 - 0.1 + rng.uniform(-0.6, 0.6, n); ev[:, l, 1] = -0.3 + rng.uniform(-0.6, 0.6, n)
                 ev[rng.randint(0, 50, n) == 0, l, 0] = np.inf
                 ev[rng.randint(0, 60, n) == 0, l, 1] = np.nan
+                # NaN evidence: corr0 = +inf with corr1 = -inf (max(0, inf) + min(0, -inf)); and the harmless mirror image
+                k = rng.randint(0, 45, n) == 0
+                ev[k, l, 0], ev[k, l, 1] = np.inf, -np.inf
+                k = rng.randint(0, 70, n) == 0
+                ev[k, l, 0], ev[k, l, 1] = -np.inf, np.inf
         ev = np.ascontiguousarray(ev)
         ob, orat = C.c_int(), C.c_float()
         O.lib.orc_logoframe_select(_ptr(ev), n, nl, -1, C.byref(ob), C.byref(orat))
@@ -245,6 +250,28 @@ def test_logoframe_decisions_on_the_host_match_the_oracle(lib, fps):
             assert best.value == ob.value and np.float32(ratio.value).tobytes() == np.float32(orat.value).tobytes()
             assert got.raw[:tl.value] == want.raw[:wl], (n, nl, li, mode)
     assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, nl, fps[0], fps[1], None, None, None, 0, None) == 0       # logo index outside
+    assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, nl + 1, -1, fps[0], fps[1], None, None, None, 0, None) == 0   # more candidates than logos
+    small = C.create_string_buffer(4)
+    tl = C.c_int()
+    assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, -1, fps[0], fps[1], None, None, small, 4, C.byref(tl)) == (-1 if tl.value > 4 else 1)
+
+
+def test_logoframe_text_survives_nan_evidence(lib):
+    """one frame with (corr0, corr1) = (+inf, -inf) makes the evidence NaN; the sliding median used to search for it with `!=`
+    and ran off its window.  Every position of the NaN frame in a short clip, and runs of them."""
+    O = Oracle()
+    for n in (1, 5, 17, 40, 200):
+        for pos in sorted({0, 1, n // 2, n - 1}):
+            for run in (1, 3, 20):
+                ev = np.zeros((n, 1, 2), np.float32)
+                ev[:, 0, 0] = 0.8
+                ev[pos:pos + run, 0, 0], ev[pos:pos + run, 0, 1] = np.inf, -np.inf
+                want = C.create_string_buffer(1 << 16)
+                wl = O.lib.orc_logoframe_write_result(_ptr(ev), n, 1, 0, 30000, 1001, want, len(want))
+                got = C.create_string_buffer(1 << 16)
+                tl = C.c_int()
+                assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, 1, -1, 0, 30000, 1001, None, None, got, len(got), C.byref(tl)) == 1
+                assert got.raw[:tl.value] == want.raw[:wl], (n, pos, run)
 
 
 def test_c_and_numpy_stat_oracles_agree():
