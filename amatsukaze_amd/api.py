@@ -317,6 +317,10 @@ class LogoFrame:
     def writeResult(self, outpath, logoIndex=-1):
         self.ctx.check(self.ctx.lib.amtgpu_logoframe_write_result(self.h, str(outpath).encode(), logoIndex))
 
+    def dumpResult(self, basepath):
+        """LogoScan.hpp:1632-1643: "<basepath><logo index>", one "%f,%f" line {corr0, corr1} per frame"""
+        self.ctx.check(self.ctx.lib.amtgpu_logoframe_dump_result(self.h, str(basepath).encode()))
+
     def getBestLogo(self):
         return self.ctx.lib.amtgpu_logoframe_best_logo(self.h)
 

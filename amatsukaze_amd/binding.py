@@ -30,6 +30,7 @@ class Collectives(C.Structure):
 # name -> (restype, argtypes); mirrors include/amt_gpu.h one to one
 SIGNATURES = {
     "amtgpu_abi_version": (c_i, []),
+    "amtgpu_host_set_parallelism": (None, [c_i, c_i]),
     "amtgpu_context_create": (c_p, [c_i]),
     "amtgpu_context_destroy": (None, [c_p]),
     "amtgpu_last_error": (c_s, [c_p]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "amtgpu_logoframe_select_logo": (c_i, [c_p, c_i]),
     "amtgpu_logoframe_write_result": (c_i, [c_p, c_s, c_i]),
     "amtgpu_hip_runtimes_loaded": (c_i, [c_p, c_i]),
+    "amtgpu_logoframe_dump_result": (c_i, [c_p, c_s]),
     "amtgpu_logoframe_decide_host": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
     "amtgpu_logoframe_best_logo": (c_i, [c_p]),
     "amtgpu_logoframe_logo_ratio": (c_f, [c_p]),

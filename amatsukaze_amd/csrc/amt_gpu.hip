@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "api_common.hpp"
+#include "host_parallel.hpp"
 
 using namespace amt;
 #ifdef AMT_TRACE_CALLS
@@ -23,6 +24,11 @@ namespace amt { void trace_stamp(AmtGpuContext* c, hipStream_t st, int slot); }
 extern "C" {
 
 int amtgpu_abi_version(void) { return AMTGPU_ABI_VERSION; }
+void amtgpu_host_set_parallelism(int max_threads, int min_frames_per_thread)
+{
+    amt::HostParallelism::max_threads().store(std::max(0, max_threads));
+    amt::HostParallelism::min_frames().store(std::max(0, min_frames_per_thread));
+}
 
 int amtgpu_hip_runtimes_loaded(char* paths, int cap)
 {
@@ -505,6 +511,28 @@ int amtgpu_logoframe_write_result(AmtGpuLogoFrame* lf, const char* outpath, int 
         std::ofstream f(outpath, std::ios::binary);
         if (!f) throw std::runtime_error(std::string("failed to open file ") + outpath);
         f.write(text.data(), (std::streamsize)text.size());
+    });
+}
+
+int amtgpu_logoframe_dump_result(AmtGpuLogoFrame* lf, const char* basepath)
+{
+    return guard(lf->ctx, [&] {
+        if (!basepath) throw std::runtime_error("no base path");
+        logoframe_sync_results(lf);
+        const int nl = (int)lf->logos.size();
+        std::string sb;
+        char line[96];
+        for (int i = 0; i < nl; ++i) {
+            sb.clear();
+            for (int n = 0; n < lf->numFrames; ++n) {
+                const float* r = lf->results.data() + ((size_t)n * nl + i) * 2;
+                sb.append(line, (size_t)std::snprintf(line, sizeof line, "%f,%f\n", r[0], r[1]));
+            }
+            const std::string path = std::string(basepath) + std::to_string(i);
+            std::ofstream f(path, std::ios::binary);
+            if (!f) throw std::runtime_error("failed to open file " + path);
+            f.write(sb.data(), (std::streamsize)sb.size());
+        }
     });
 }
 

@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <limits>
 #include <stdexcept>
+#include <thread>
+
+#include "host_parallel.hpp"
 
 namespace amt {
 
@@ -17,20 +20,33 @@ LogoSelection select_logo(const float* evals, int numFrames, int numLogos, int n
 {
     if (numCandidates < 0) numCandidates = numLogos;
     LogoSelection sel;
-    float bestScore = 0;
-    int bestHits = 0;
-    for (int i = 0; i < numCandidates; ++i) {
-        // a frame counts for logo i when the logo is seen (corr0) and erasing it leaves little (corr1)
+    if (numCandidates <= 0) return sel;
+    // per candidate: a frame counts for logo i when the logo is seen (corr0) and erasing it leaves little (corr1); the residue is an
+    // fp32 sum in frame order (the reference's).  Candidates are independent: one thread each on long clips.
+    std::vector<int> hitsOf(numCandidates);
+    std::vector<float> scoreOf(numCandidates);
+    auto one = [&](int i) {
         int hits = 0;
         float residue = 0.0f;
         for (int n = 0; n < numFrames; ++n) {
             const float* r = evals + ((size_t)n * numLogos + i) * 2;
             if (r[0] > kUnknownBelow && std::abs(r[1]) < kUnknownBelow) { ++hits; residue += std::abs(r[1]); }
         }
-        const float score = hits == 0 ? std::numeric_limits<float>::infinity()
-                                      : (residue / hits) * (numFrames / (float)hits);
-        if (i == 0 || score < bestScore) { bestScore = score; sel.bestLogo = i; bestHits = hits; }
+        hitsOf[i] = hits;
+        scoreOf[i] = hits == 0 ? std::numeric_limits<float>::infinity() : (residue / hits) * (numFrames / (float)hits);
+    };
+    if (numCandidates > 1 && parallel_parts(numFrames) > 1) {
+        std::vector<std::thread> th;
+        for (int i = 1; i < numCandidates; ++i) th.emplace_back(one, i);
+        one(0);
+        for (auto& t : th) t.join();
+    } else {
+        for (int i = 0; i < numCandidates; ++i) one(i);
     }
+    float bestScore = 0;
+    int bestHits = 0;
+    for (int i = 0; i < numCandidates; ++i)
+        if (i == 0 || scoreOf[i] < bestScore) { bestScore = scoreOf[i]; sel.bestLogo = i; bestHits = hitsOf[i]; }
     if (sel.bestLogo >= 0) sel.logoRatio = (float)bestHits / numFrames;
     return sel;
 }
@@ -54,27 +70,30 @@ std::string logoframe_text(const float* evals, int numFrames, int numLogos, int 
     }
     const float* const ev = evp.data() + pad;                  // ev[i], -pad <= i < N + pad
 
-    // The selection and the text are replicated on every rank over the WHOLE clip: the window passes run
-    // window-offset outermost, frames innermost (vector loops over frames; every frame still sees its window's values in the
-    // reference's order -- the fp32 mean is a left-to-right sum), the median slides a sorted window.
+    // The selection and the text are replicated on every rank over the WHOLE clip.  The window passes are local
+    // -- a frame's state and median depend on +-halfAvg frames of evidence -- so frame ranges run on a few threads; inside a range they
+    // run window-offset outermost, frames innermost (vector loops over frames; every frame still sees its window's values in the
+    // reference's order -- the fp32 mean is a left-to-right sum), and the median slides a sorted window primed at the range's start.
     std::vector<int> state(N);
     std::vector<float> smooth(N);
-    {
-        std::vector<float> before(N), after(N), sum(N, 0.0f);
-        for (int i = 0; i < N; ++i) { before[i] = ev[i - halfAvg]; after[i] = ev[i + 1]; }
+    parallel_ranges(N, parallel_parts(N), [&](int lo, int hi, int) {
+        const int M = hi - lo;
+        std::vector<float> before(M), after(M), sum(M, 0.0f);
+        const float* const e = ev + lo;                               // e[i] = ev[lo + i]
+        for (int i = 0; i < M; ++i) { before[i] = e[i - halfAvg]; after[i] = e[i + 1]; }
         for (int d = 1; d < halfAvg; ++d)
-            for (int i = 0; i < N; ++i) {
-                before[i] = std::max(before[i], ev[i - halfAvg + d]);
-                after[i] = std::max(after[i], ev[i + 1 + d]);
+            for (int i = 0; i < M; ++i) {
+                before[i] = std::max(before[i], e[i - halfAvg + d]);
+                after[i] = std::max(after[i], e[i + 1 + d]);
             }
         for (int d = -halfAvg; d <= halfAvg; ++d)
-            for (int i = 0; i < N; ++i) sum[i] += ev[i + d];
-        for (int i = 0; i < N; ++i) {
+            for (int i = 0; i < M; ++i) sum[i] += e[i + d];
+        for (int i = 0; i < M; ++i) {
             const float mm = std::min(before[i], after[i]);
             const int byMinMax = (std::abs(mm) < 0.5f) ? 1 : (mm < 0.0f) ? 0 : 2;
             const float mean = sum[i] / avgLen;
             const int byMean = (std::abs(mean) < kUnknownBelow) ? 1 : (mean < 0.0f) ? 0 : 2;
-            state[i] = (byMinMax == byMean) ? byMinMax : 1;
+            state[lo + i] = (byMinMax == byMean) ? byMinMax : 1;
         }
         // The median slides a window kept in ascending order.  NaN evidence (corr0 = +inf with corr1 = -inf: a logo whose blackScore
         // is 0) has no place in `<`: the reference's std::sort over it is undefined behaviour (LogoScan.hpp:1745-1747), so the
@@ -82,19 +101,19 @@ std::string logoframe_text(const float* evals, int numFrames, int numLogos, int 
         const int K = 2 * halfMed + 1;
         auto lt = [](float a, float b) { return a < b || (b != b && a == a); };
         auto same = [](float a, float b) { return a == b || (a != a && b != b); };
-        std::vector<float> win(ev - halfMed, ev - halfMed + K);       // the window of frame 0
+        std::vector<float> win(e - halfMed, e - halfMed + K);         // the window of the range's first frame
         std::sort(win.begin(), win.end(), lt);
-        for (int i = 0; i < N; ++i) {
-            smooth[i] = win[halfMed];
-            if (i + 1 == N) break;
-            const float out = ev[i - halfMed], in = ev[i + 1 + halfMed];
+        for (int i = 0; i < M; ++i) {
+            smooth[lo + i] = win[halfMed];
+            if (i + 1 == M) break;
+            const float out = e[i - halfMed], in = e[i + 1 + halfMed];
             int k = 0;
             while (k + 1 < K && !same(win[k], out)) ++k;
             for (; k + 1 < K && lt(win[k + 1], in); ++k) win[k] = win[k + 1];    // the gap moves up ...
             for (; k > 0 && lt(in, win[k - 1]); --k) win[k] = win[k - 1];        // ... or down to where `in` belongs
             win[k] = in;
         }
-    }
+    });
 
     // unknown runs adopt their neighbours' state when both sides agree (outside the clip counts as off)
     for (int i = 0; i < N;) {

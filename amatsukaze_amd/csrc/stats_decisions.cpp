@@ -3,6 +3,8 @@
 
 #include <algorithm>
 
+#include "host_parallel.hpp"
+
 namespace amt {
 
 namespace {
@@ -16,26 +18,35 @@ inline uint64_t m(const uint64_t* metrics, int n, int w) { return metrics[(size_
 // decisions are replicated on every rank over the WHOLE clip, so they cost O(1) per frame.
 std::vector<int> scene_changes(const uint64_t* metrics, int nframes, int width, int height)
 {
-    std::vector<int> out;
     const uint64_t floor_energy = (uint64_t)width * height * 4;
     auto energy = [&](int k) { return m(metrics, k, W_DIFF_TOP) + m(metrics, k, W_DIFF_BOT); };
-    uint64_t win[16];
-    int s = 0;                                   // win[0..s) = the energies of frames max(1, n-15) .. n-1, ascending
-    for (int n = 1; n < nframes; ++n) {
-        const uint64_t e = energy(n);
-        const uint64_t med = s ? win[s / 2] : 0;
-        if (e >= floor_energy && e > 3 * med) out.push_back(n);
-        if (s == 15) {                           // frame n-15 leaves
-            const uint64_t old = energy(n - 15);
-            int i = 0;
-            while (win[i] != old) ++i;
-            for (; i + 1 < s; ++i) win[i] = win[i + 1];
-            --s;
+    // frames [lo, hi) of the clip: the window is primed from the (up to) 15 frames before lo, so a range needs nothing from its neighbours
+    auto range = [&](int lo, int hi, std::vector<int>& out) {
+        uint64_t win[16];
+        int s = 0;                               // win[0..s) = the energies of frames max(1, n-15) .. n-1, ascending
+        for (int k = std::max(1, lo - 15); k < lo; ++k) win[s++] = energy(k);
+        std::sort(win, win + s);
+        for (int n = std::max(1, lo); n < hi; ++n) {
+            const uint64_t e = energy(n);
+            const uint64_t med = s ? win[s / 2] : 0;
+            if (e >= floor_energy && e > 3 * med) out.push_back(n);
+            if (s == 15) {                       // frame n-15 leaves
+                const uint64_t old = energy(n - 15);
+                int i = 0;
+                while (i + 1 < s && win[i] != old) ++i;
+                for (; i + 1 < s; ++i) win[i] = win[i + 1];
+                --s;
+            }
+            int i = s++;                         // frame n enters
+            for (; i > 0 && win[i - 1] > e; --i) win[i] = win[i - 1];
+            win[i] = e;
         }
-        int i = s++;                             // frame n enters
-        for (; i > 0 && win[i - 1] > e; --i) win[i] = win[i - 1];
-        win[i] = e;
-    }
+    };
+    const int parts = parallel_parts(nframes);
+    std::vector<std::vector<int>> part(parts);
+    parallel_ranges(nframes, parts, [&](int lo, int hi, int p) { range(lo, hi, part[p]); });
+    std::vector<int> out;
+    for (auto& v : part) out.insert(out.end(), v.begin(), v.end());
     return out;
 }
 
@@ -50,55 +61,68 @@ void classify_cadence(const uint64_t* metrics, int nframes, int width, int heigh
 {
     std::vector<char> code(nframes, 'B');
     std::vector<uint64_t> motion_of(nframes);
-    for (int n = 0; n < nframes; ++n) {
-        const uint64_t c0 = m(metrics, n, W_COMB), c1 = m(metrics, n, W_COMB_PREV);
-        if (c0 * 3 < c1 * 2) code[n] = 'C';
-        else if (c1 * 3 < c0 * 2) code[n] = 'P';
-        motion_of[n] = m(metrics, n, W_DIFF_TOP) + m(metrics, n, W_DIFF_BOT);
-    }
     const uint64_t still = (uint64_t)width * height / 2;      // < 0.5 per pixel of field difference: nothing moves
-    int hitq[5] = {0, 0, 0, 0, 0}, nC = 0, nDecided = 0;
-    auto slide = [&](int k, int sign) {                        // frame k enters (+1) or leaves (-1) the window
-        nC += sign * (code[k] == 'C');
-        nDecided += sign * (code[k] != 'B');
-        if (code[k] == 'B') return;
-        // C counts where (k + q) % 5 is 0 or 1, P where it is 2 or 3: two offsets q each
-        const int r = k % 5, q0 = code[k] == 'C' ? 5 - r : 7 - r;
-        hitq[q0 % 5] += sign;
-        hitq[(q0 + 1) % 5] += sign;
-    };
-    int wa = 0, wb = 0;                                        // the counts cover [wa, wb)
-    uint64_t motion = 0;
-    int motion_from = -1;                                      // the latest frame of the window that holds `motion`
+    constexpr uint8_t kStill = 0xFF;                           // first pass: "nothing moves in this frame's window"
+    // First pass, frame ranges in parallel: everything that depends on the frame's window only.  Second pass, in order: a still window
+    // keeps the cadence of the frame before it (and advances its 3:2 phase).
+    parallel_ranges(nframes, parallel_parts(nframes), [&](int lo, int hi, int) {
+        for (int n = lo; n < hi; ++n) {
+            const uint64_t c0 = m(metrics, n, W_COMB), c1 = m(metrics, n, W_COMB_PREV);
+            if (c0 * 3 < c1 * 2) code[n] = 'C';
+            else if (c1 * 3 < c0 * 2) code[n] = 'P';
+            motion_of[n] = m(metrics, n, W_DIFF_TOP) + m(metrics, n, W_DIFF_BOT);
+        }
+    });
+    parallel_ranges(nframes, parallel_parts(nframes), [&](int lo, int hi, int) {
+        int hitq[5] = {0, 0, 0, 0, 0}, nC = 0, nDecided = 0;
+        auto slide = [&](int k, int sign) {                        // frame k enters (+1) or leaves (-1) the window
+            nC += sign * (code[k] == 'C');
+            nDecided += sign * (code[k] != 'B');
+            if (code[k] == 'B') return;
+            // C counts where (k + q) % 5 is 0 or 1, P where it is 2 or 3: two offsets q each
+            const int r = k % 5, q0 = code[k] == 'C' ? 5 - r : 7 - r;
+            hitq[q0 % 5] += sign;
+            hitq[(q0 + 1) % 5] += sign;
+        };
+        int wa = std::max(0, lo - 4), wb = wa;                     // the counts cover [wa, wb)
+        uint64_t motion = 0;
+        int motion_from = -1;                                      // the latest frame of the window that holds `motion`
+        for (int n = lo; n < hi; ++n) {
+            const int a = std::max(0, n - 4), b = std::min(nframes, n + 6);      // 10-frame window
+            while (wb < b) slide(wb++, +1);
+            while (wa < a) slide(wa++, -1);
+            // the window's largest motion: recomputed only when the frame that left held it or the window is still growing
+            if (n == lo || motion_from < a) {
+                motion = 0;
+                for (int k = a; k < b; ++k) if (motion_of[k] >= motion) { motion = motion_of[k]; motion_from = k; }
+            } else if (b > 0 && motion_of[b - 1] >= motion) { motion = motion_of[b - 1]; motion_from = b - 1; }
+            int best = -1, bestPhase = 0;
+            const int a5 = a % 5;
+            for (int ph = 0; ph < 5; ++ph) {          // ph = position of frame `a` in the cycle
+                const int q = ph - a5;
+                const int hit = hitq[q < 0 ? q + 5 : q];
+                if (hit > best) { best = hit; bestPhase = ph; }
+            }
+            const int span = b - a;
+            uint8_t cls, ph = 0;
+            if (motion < still) { cls = kStill; }                        // nothing moves: decided in the second pass
+            else if (nDecided * 2 < span) { cls = kCadence60i; }         // moving, but neither weave is clean: true interlaced
+            else if (best * 10 >= span * 7) { cls = kCadence24p; ph = (uint8_t)((n - a + bestPhase) % 5); }
+            else if (nC * 10 >= span * 7) { cls = kCadence30p; }
+            else if (nDecided * 10 >= span * 7 && best * 10 >= span * 5) { cls = kCadence24p; ph = (uint8_t)((n - a + bestPhase) % 5); }
+            else { cls = kCadence60i; }
+            cadence[n] = cls;
+            phase[n] = ph;
+        }
+    });
     uint8_t last = kCadence60i, lastPhase = 0;
     for (int n = 0; n < nframes; ++n) {
-        const int a = std::max(0, n - 4), b = std::min(nframes, n + 6);      // 10-frame window
-        while (wb < b) slide(wb++, +1);
-        while (wa < a) slide(wa++, -1);
-        // the window's largest motion: recomputed only when the frame that left held it or the window is still growing
-        if (n == 0 || motion_from < a) {
-            motion = 0;
-            for (int k = a; k < b; ++k) if (motion_of[k] >= motion) { motion = motion_of[k]; motion_from = k; }
-        } else if (b > 0 && motion_of[b - 1] >= motion) { motion = motion_of[b - 1]; motion_from = b - 1; }
-        int best = -1, bestPhase = 0;
-        const int a5 = a % 5;
-        for (int ph = 0; ph < 5; ++ph) {          // ph = position of frame `a` in the cycle
-            const int q = ph - a5;
-            const int hit = hitq[q < 0 ? q + 5 : q];
-            if (hit > best) { best = hit; bestPhase = ph; }
+        if (cadence[n] == kStill) {
+            cadence[n] = last;
+            phase[n] = last == kCadence24p ? (uint8_t)((lastPhase + 1) % 5) : 0;
         }
-        const int span = b - a;
-        uint8_t cls, ph = 0;
-        if (motion < still) { cls = last; ph = last == kCadence24p ? (uint8_t)((lastPhase + 1) % 5) : 0; }   // nothing moves: keep
-        else if (nDecided * 2 < span) { cls = kCadence60i; }         // moving, but neither weave is clean: true interlaced
-        else if (best * 10 >= span * 7) { cls = kCadence24p; ph = (uint8_t)((n - a + bestPhase) % 5); }
-        else if (nC * 10 >= span * 7) { cls = kCadence30p; }
-        else if (nDecided * 10 >= span * 7 && best * 10 >= span * 5) { cls = kCadence24p; ph = (uint8_t)((n - a + bestPhase) % 5); }
-        else { cls = kCadence60i; }
-        cadence[n] = cls;
-        phase[n] = ph;
-        last = cls;
-        lastPhase = ph;
+        last = cadence[n];
+        lastPhase = phase[n];
     }
 }
 

@@ -76,8 +76,9 @@ def parse_args():
     ap.add_argument("--exact-steps", type=int, default=40, help="timed steps of the same pass with the exact (bit-identical) analysis, reported as exact_mode")
     ap.add_argument("--workload", choices=("headline", "e2e10"), default="headline",
                     help="e2e10: BASELINE configs[4] (tools/bench_e2e.py) as the line's own workload, frames sharded over --gpus ranks (strong scaling)")
-    ap.add_argument("--e2e-frames", type=int, default=0, help="frames of the e2e10 stream (default: 53 946 = one GPU's share of the 4-hour stream at N = 8; "
-                                                              "431568 = the whole stream)")
+    ap.add_argument("--e2e-frames", type=int, default=0, help="TOTAL frames of the e2e10 stream, sharded over the ranks (strong scaling).  Default 0: 53 946 "
+                                                              "frames per rank = one GPU's share of the 4-hour stream, so N = 8 runs the whole 431 568-frame "
+                                                              "stream of configs[4] (weak scaling)")
     ap.add_argument("--e2e-chunk", type=int, default=4096, help="frames generated and processed per chunk of the e2e10 stream")
     ap.add_argument("--metrics-cus", type=int, default=0,
                     help="N > 0: N compute units are given to the frame metrics, which then run BESIDE the analysis + scan on the other units (two contexts "
@@ -289,41 +290,6 @@ def reference_logo_passes(orc, hs, Y, U, V, nframes, oracle_out):
 # --------------------------------------------------------------------------------------------------------------------
 # verification of the bench's own outputs (outside the timed region)
 # --------------------------------------------------------------------------------------------------------------------
-def verify_step(N, blocks, outputs, pristine, logos_np, erase, analysis_tol=0.0):
-    """outputs: scan records (N,3,2), analysis (N,33), fades (N,2), erased device clip, metrics (N,8) of ONE step over the
-    freshly generated batch at the bench's launch geometry; pristine: {block: (Y,U,V,prevY)} host copies taken before that
-    step.  Compares the frames of every block with the CPU oracle, bytes."""
-    ol = OracleLogos(logos_np)
-    ev_g, an_g, fades_g, dclip, st_g = outputs
-    res = {"frames": 0, "blocks": [list(b) for b in blocks], "scan": True, "analysis": True, "fades": True, "erase": True, "metrics": True}
-    for (b0, bn) in blocks:
-        Y, U, V, prevY = pristine[(b0, bn)]
-        res["frames"] += bn
-        res["scan"] &= ol.scan(Y, bn).tobytes() == np.ascontiguousarray(ev_g[b0:b0 + bn]).tobytes()
-        an = ol.analyze(Y, bn)
-        if analysis_tol == 0.0:
-            res["analysis"] &= an.tobytes() == np.ascontiguousarray(an_g[b0:b0 + bn]).tobytes()
-        else:       # linear mode: scores within the tolerance; the decisions taken from them (fades, erased pixels) still compare as bytes
-            d = float(np.abs(an.reshape(bn, 33) - an_g[b0:b0 + bn]).max())
-            res["analysis_max_abs_err"] = max(res.get("analysis_max_abs_err", 0.0), d)
-            res["analysis"] &= d <= analysis_tol
-        res["metrics"] &= ol.metrics(Y, bn, prevY).tobytes() == np.ascontiguousarray(st_g[b0:b0 + bn]).tobytes()
-        if not erase:
-            continue
-        # CalcFade2 looks at frames n-8..n+8 (LogoScan.hpp:1265-1285): inside a block only frames whose window stays inside
-        # it (or is clamped at the true clip start / end exactly like in the whole clip) are comparable
-        lo = 0 if b0 == 0 else 8
-        hi = bn if b0 + bn == N else bn - 8
-        eY = dclip.Y[b0:b0 + bn].cpu().numpy(); eU = dclip.U[b0:b0 + bn].cpu().numpy(); eV = dclip.V[b0:b0 + bn].cpu().numpy()
-        for i in range(lo, hi):
-            ft, fb = ol.fade(an, bn, i)
-            res["fades"] &= (np.float32(ft).tobytes() + np.float32(fb).tobytes()) == np.ascontiguousarray(fades_g[b0 + i]).tobytes()
-            ol.erase(Y, U, V, i, ft, fb)
-            res["erase"] &= np.array_equal(Y[i], eY[i]) and np.array_equal(U[i], eU[i]) and np.array_equal(V[i], eV[i])
-    res["ok"] = all(res[k] for k in ("scan", "analysis", "fades", "erase", "metrics"))
-    return res
-
-
 def tolerance_accounting(lin, exact, fades_lin, eraser, analyzer, N):
     """Every score of the linear-guarded step against the exact kernel's (= the reference's bytes) on the same frames, and every
     fade pair.  The scores are normalised correlations (CorrelationScore / blackScore: 1.0 = the logo on black, LogoScan.hpp:254)
@@ -549,7 +515,11 @@ def main():
         import bench_e2e
         E = types.SimpleNamespace(torch=torch, dist=dist, rank=rank, world=world, dev=dev, ctx=ctx, logos_np=logos_np, alpha=alpha, alphaUV=alphaUV,
                                   fence=fence, max_over_ranks=max_over_ranks, OracleLogos=OracleLogos, maskratio=MASKRATIO)
-        return bench_e2e.run(E, nt=args.e2e_frames or bench_e2e.SHARE_FRAMES, chunk=args.e2e_chunk, verify=not args.no_verify, mode=args.analysis_mode)
+        # default stream: one GPU's share of the 4-hour stream PER RANK (53 946 frames x world: the whole 431 568-frame stream of configs[4] at
+        # N = 8) -- per-GPU work fixed as N grows, i.e. weak scaling; an explicit --e2e-frames fixes the total instead (strong)
+        nt = args.e2e_frames or bench_e2e.SHARE_FRAMES * world
+        return bench_e2e.run(E, nt=nt, chunk=args.e2e_chunk, verify=not args.no_verify, mode=args.analysis_mode,
+                             scaling="strong" if args.e2e_frames else "weak")
 
     if args.workload == "e2e10":
         r = e2e10()
@@ -558,7 +528,7 @@ def main():
                 print(json.dumps({"e2e10": r}), file=sys.stderr, flush=True)
                 raise SystemExit("e2e10 verification FAILED: sampled blocks differ from the CPU oracle")
             line = {"metric": "frames/sec 1920x1080i 10-bit logo+CM+KFM end-to-end pass", "value": r["value"], "unit": "frames/sec", "n_gpus": world,
-                    "steps": 1, "warmup": 0, "ms_per_step": r["timed_s"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "steps": 1, "warmup": 0, "ms_per_step": r["timed_s"] * 1e3, "higher_is_better": True, "scaling": r["scaling"], "vs_baseline": None,
                     "dtype": "f32", "data": "synthetic",
                     "config": {"workload": r["workload"], "frames_total": r["frames_total"], "logo": f"{LW}x{LH}@(1600,64)", "maskratio": MASKRATIO,
                                "analysis_mode": args.analysis_mode, "parallelism": f"frames sharded x{world}"},
@@ -814,18 +784,13 @@ def main():
                           + ("the device CalcFade: the whole step is stream-ordered, the host only enqueues" if args.fades == "device" else
                              "the host CalcFade, overlapped with the scan and the frame metrics"))
 
-    # ---- verification (untimed): fresh frames, one more step at the same launch geometry, sampled blocks vs the oracle ----
+    # ---- verification (untimed): fresh frames, one more step at the same launch geometry, EVERY frame against the CPU oracle ----
     verified = None
     if not args.no_verify and rank == 0:
+        import bench_verify as BV
         del clip
-        clip = gen()
+        clip = gen()                                                 # stays resident: the pristine frames the oracle is fed
         dclip.Y.copy_(clip["Y"]); dclip.U.copy_(clip["U"]); dclip.V.copy_(clip["V"])
-        del clip
-        blocks = [(0, 40), (max(0, min(N - 64, 864)), 64), (max(0, N - 40), 40)] if N >= 200 else [(0, N)]
-        pristine = {}
-        for (b0, bn) in blocks:
-            pristine[(b0, bn)] = (dclip.Y[b0:b0 + bn].cpu().numpy(), dclip.U[b0:b0 + bn].cpu().numpy(), dclip.V[b0:b0 + bn].cpu().numpy(),
-                                  dclip.Y[b0 - 1].cpu().numpy() if b0 > 0 else None)
         d_exact = None
         if args.analysis_mode == "linear":
             # the whole batch through the exact kernel (bit-identical to the reference) BEFORE the step erases the frames: the
@@ -842,12 +807,18 @@ def main():
             # the device decision against the host routine on the same records (bytes, every frame)
             if eraser.calc_fades(h_analysis.numpy(), N).tobytes() != last["fades"].tobytes():
                 raise SystemExit("bench verification FAILED: amtgpu_erase_calc_fades_device differs from the host CalcFade")
-        outputs = (lf.evalResults, h_analysis.numpy(), last.get("fades"), dclip, d_stats.cpu().numpy().astype(np.uint64))
-        verified = verify_step(N, blocks, outputs, pristine, logos_np, not args.no_erase, 1e-4 if args.analysis_mode == "linear" else 0.0)
+        # all N frames: scan records, frame metrics, fades and the erased planes as bytes, analysis records as bytes (exact mode) or
+        # within 1e-4 (linear-guarded); the oracle on every host core (tools/bench_verify.py)
+        verified = BV.verify_range(torch, OracleLogos(logos_np), 8, N, 0, N,
+                                   lambda lo, hi: (clip["Y"][lo:hi], clip["U"][lo:hi], clip["V"][lo:hi]),
+                                   lambda lo, hi: (dclip.Y[lo:hi], dclip.U[lo:hi], dclip.V[lo:hi]),
+                                   lf.evalResults, h_analysis.numpy(), last.get("fades"), d_stats.cpu().numpy().astype(np.uint64),
+                                   tol=1e-4 if args.analysis_mode == "linear" else 0.0, erase=not args.no_erase)
+        del clip
         verified["analysis_mode"] = args.analysis_mode
         verified["analysis_compare"] = ("bytes" if args.analysis_mode == "exact" else
-                                        "sampled blocks vs the CPU oracle: abs <= 1e-4 (fades and erased frames: bytes); the whole batch vs the "
-                                        "exact GPU kernel: analysis_max_abs / analysis_max_rel / fades_equal_all")
+                                        "every frame vs the CPU oracle: abs <= 1e-4 (fades and erased frames: bytes); and vs the exact GPU "
+                                        "kernel: analysis_max_abs / analysis_max_rel / fades_equal_all")
         verified["guard_refined_frames"] = analyzer.last_refined()
         if d_exact is not None:
             verified.update(tolerance_accounting(h_analysis.numpy(), d_exact.cpu().numpy(), last["fades"], eraser, analyzer, N))
@@ -1105,12 +1076,19 @@ def config_kfm(ctx, dev, logos_np, alpha, alphaUV, args, N=18000, SEG=1800):
     cad, ph = fs.cadence(m)
     sc = fs.scene_changes(m)
     host_ms = (time.perf_counter() - t0) * 1e3
-    # ---- the kernel against the numpy oracle (bytes) on probe blocks; the host decisions against the oracle's on all metrics ----
+    # ---- the kernel against the numpy oracle (bytes) on probe blocks and against the C oracle on EVERY frame; the host decisions against
+    #      the oracle's on all metrics ----
     ok_metrics = True
     for b0 in (0, SEG - 12, 2 * SEG - 12, N // 2, N - 24):
         blk = Y[max(0, b0 - 1):b0 + 24].cpu().numpy()
         want = FS.frame_metrics(blk)
         ok_metrics &= bool(np.array_equal(m[b0:b0 + 24], want[(1 if b0 > 0 else 0):]))
+    vm = None
+    if not args.no_verify:
+        import bench_verify as BV
+        from amtlib import Oracle
+        vm = BV.verify_metrics(torch, Oracle().lib, 8, Wk, Hk, N, lambda lo, hi: Y[lo:hi], m)
+        ok_metrics &= vm["metrics_equal_oracle"]
     ocad, oph = FS.classify_cadence(m, Wk, Hk)
     ok_dec = bool(np.array_equal(cad, ocad) and np.array_equal(ph, oph) and sc.tolist() == FS.scene_changes(m, Wk, Hk))
     if not (ok_metrics and ok_dec):
@@ -1154,7 +1132,8 @@ def config_kfm(ctx, dev, logos_np, alpha, alphaUV, args, N=18000, SEG=1800):
             "frames": N, "value": N / wall, "unit": "frames/sec", "ms_per_pass": wall * 1e3, "host_decisions_ms": host_ms,
             "kernels": {"frame_stats_kernel": {"avg_ms": k_ms, "bound": "hbm", "achieved_gbs": byts * N / (k_ms * 1e-3) / 1e9,
                                                "frac": byts * N / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts * N}},
-            "verified": {"metrics_equal_oracle_on_probe_blocks": ok_metrics, "decisions_equal_oracle": ok_dec, "parity": "unpinned (self-specified pass)"},
+            "verified": {"metrics_equal_oracle_on_probe_blocks": ok_metrics, "frames": vm["frames"] if vm else 120, "all_frames": vm,
+                         "decisions_equal_oracle": ok_dec, "parity": "unpinned (self-specified pass)"},
             "accuracy_vs_generator_labels": acc, "clip_generation_s": gen_s}
 
 
@@ -1194,40 +1173,21 @@ def config_tenbit(ctx, dev, logos_np, alpha, alphaUV, args, N=3000):
                 pl[:, y0:y1, x0:x1] = keep
 
     wall, kern = _prof(ctx, step, 5)
-    # ---- verification: fresh frames, one step, sampled blocks against the CPU oracle (bytes; analysis within 1e-4 in linear mode) ----
+    # ---- verification: fresh frames, one step, EVERY frame against the CPU oracle (bytes; analysis within 1e-4 in linear mode) ----
     verified = None
     if not args.no_verify:
+        import bench_verify as BV
         del clip
-        clip = gen()
+        clip = gen()                                                  # stays resident: the pristine frames the oracle is fed
         dclip.Y.copy_(clip["Y"]); dclip.U.copy_(clip["U"]); dclip.V.copy_(clip["V"])
-        del clip
-        blocks = [(0, 32), (288, 40), (N - 32, 32)]
-        to_np = lambda t: t.cpu().numpy().view(np.uint16)
-        pristine = {b: (to_np(dclip.Y[b[0]:b[0] + b[1]]), to_np(dclip.U[b[0]:b[0] + b[1]]), to_np(dclip.V[b[0]:b[0] + b[1]]),
-                        to_np(dclip.Y[b[0] - 1]) if b[0] > 0 else None) for b in blocks}
         step(restore=False)
         torch.cuda.synchronize()
-        ol = OracleLogos(logos_np, Wk, Hk, X, Y0, bits)
-        ev_g, st_g = lf.evalResults, d_st.cpu().numpy().astype(np.uint64)
-        verified = {"frames": 0, "scan": True, "analysis": True, "fades": True, "erase": True, "metrics": True}
-        tol = 1e-4 if args.analysis_mode == "linear" else 0.0
-        for (b0, bn) in blocks:
-            Yb, Ub, Vb, prevY = pristine[(b0, bn)]
-            verified["frames"] += bn
-            verified["scan"] &= ol.scan(Yb, bn).tobytes() == np.ascontiguousarray(ev_g[b0:b0 + bn]).tobytes()
-            a = ol.analyze(Yb, bn).reshape(bn, 33)
-            dmax = float(np.abs(a - last["an"][b0:b0 + bn]).max())
-            verified["analysis_max_abs_err"] = max(verified.get("analysis_max_abs_err", 0.0), dmax)
-            verified["analysis"] &= (dmax <= tol) if tol else (a.tobytes() == np.ascontiguousarray(last["an"][b0:b0 + bn]).tobytes())
-            verified["metrics"] &= ol.metrics(Yb, bn, prevY).tobytes() == np.ascontiguousarray(st_g[b0:b0 + bn]).tobytes()
-            lo, hi = (0 if b0 == 0 else 8), (bn if b0 + bn == N else bn - 8)
-            eY, eU, eV = to_np(dclip.Y[b0:b0 + bn]), to_np(dclip.U[b0:b0 + bn]), to_np(dclip.V[b0:b0 + bn])
-            for i in range(lo, hi):
-                ft, fb = ol.fade(a.reshape(-1), bn, i)
-                verified["fades"] &= (np.float32(ft).tobytes() + np.float32(fb).tobytes()) == np.ascontiguousarray(last["fades"][b0 + i]).tobytes()
-                ol.erase(Yb, Ub, Vb, i, ft, fb)
-                verified["erase"] &= bool(np.array_equal(Yb[i], eY[i]) and np.array_equal(Ub[i], eU[i]) and np.array_equal(Vb[i], eV[i]))
-        verified["ok"] = all(verified[k] for k in ("scan", "analysis", "fades", "erase", "metrics"))
+        verified = BV.verify_range(torch, OracleLogos(logos_np, Wk, Hk, X, Y0, bits), bits, N, 0, N,
+                                   lambda lo, hi: (clip["Y"][lo:hi], clip["U"][lo:hi], clip["V"][lo:hi]),
+                                   lambda lo, hi: (dclip.Y[lo:hi], dclip.U[lo:hi], dclip.V[lo:hi]),
+                                   lf.evalResults, last["an"], last["fades"], d_st.cpu().numpy().astype(np.uint64),
+                                   tol=1e-4 if args.analysis_mode == "linear" else 0.0, chunk=256)
+        del clip
         verified["guard_refined_frames"] = an.last_refined()
         if not verified["ok"]:
             print(json.dumps({"tenbit_verified": verified}), file=sys.stderr, flush=True)

@@ -24,11 +24,13 @@
 #define AMT_FILTERS_HPP
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -207,6 +209,8 @@ class AMTEraseLogo : public GenericVideoFilter {
     int block_;                                   /* child frames erased per GPU launch */
     DeviceBuffer dbuf_;
     std::mutex mu_;
+    std::condition_variable cv_;                  /* a block some thread is fetching is waited for, not fetched twice */
+    std::set<int> inflight_;                      /* first frames of the blocks being fetched */
     std::vector<float> analysis_;                 /* [num_frames][33], filled on demand from analyzeclip */
     std::vector<char> have_;                      /* per analysis frame */
     int cache_first_ = -1;
@@ -357,13 +361,22 @@ public:
         if (es != 1 && es != 2) env->ThrowError("[AMTEraseLogo] Unsupported pixel format");
         n = std::max(0, std::min(vi.num_frames - 1, n));
         auto cached = [&]() { return cache_first_ >= 0 && n >= cache_first_ && n < cache_first_ + (int)cache_.size(); };
-        {
-            std::lock_guard<std::mutex> lock(mu_);
+        const int first = n - n % block_;
+        std::unique_lock<std::mutex> lock(mu_);
+        for (;;) {
             if (cached()) return cache_[n - cache_first_];
+            if (!inflight_.count(first)) break;
+            cv_.wait(lock);                               /* another thread is pulling this block's upstream frames: wait for it */
         }
-        Fetched f = fetch(n - n % block_, env);           /* upstream work: not under the lock */
-        std::lock_guard<std::mutex> lock(mu_);
-        if (!cached()) process(f, env);                   /* (another thread may have served the same block meanwhile) */
+        inflight_.insert(first);
+        lock.unlock();
+        struct Done {                                     /* whatever happens below, the block leaves the in-flight set and waiters wake */
+            AMTEraseLogo* self; int first; std::unique_lock<std::mutex>& lock;
+            ~Done() { if (!lock.owns_lock()) lock.lock(); self->inflight_.erase(first); self->cv_.notify_all(); }
+        } done{this, first, lock};
+        Fetched f = fetch(first, env);                    /* upstream work: not under the lock */
+        lock.lock();
+        if (!cached()) process(f, env);
         return cache_[n - cache_first_];
     }
     int SetCacheHints(int cachehints, int) override { return cachehints == AMT_AVS_NS CACHE_GET_MTMODE ? AMT_AVS_NS MT_NICE_FILTER : 0; }
@@ -473,6 +486,8 @@ public:
     }
     void selectLogo(int numCandidates = -1) { check(amtgpu_logoframe_select_logo(lf_, numCandidates)); }
     void writeResult(const std::string& outpath, int logoIndex = -1) { check(amtgpu_logoframe_write_result(lf_, outpath.c_str(), logoIndex)); }
+    /* LogoScan.hpp:1632-1643 (CMAnalyze.hpp:296 keeps the call under #if 0) */
+    void dumpResult(const std::string& basepath) { check(amtgpu_logoframe_dump_result(lf_, basepath.c_str())); }
     int getBestLogo() const { return amtgpu_logoframe_best_logo(lf_); }
     float getLogoRatio() const { return amtgpu_logoframe_logo_ratio(lf_); }
 };

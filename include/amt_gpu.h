@@ -46,6 +46,11 @@ typedef struct AmtGpuFrameStats AmtGpuFrameStats; /* self-specified CM / KFM who
 typedef int (*AMTGPU_LOGO_ANALYZE_CB)(float progress, int nread, int total, int ngather);
 
 int amtgpu_abi_version(void);
+/* Host threads of the O(frames) decision routines (selectLogo / writeResult text, scene changes, cadence): they cut the clip into
+ * contiguous frame ranges -- the window filters are local -- and leave only the two small state machines sequential.  max_threads /
+ * min_frames_per_thread <= 0 restore the defaults (half the host's cores up to 32; 32 768 frames).  Process-wide.  Results never depend
+ * on either value.  A host with its own thread pool (AviSynth MT) passes 1 to keep the library on the calling thread. */
+void amtgpu_host_set_parallelism(int max_threads, int min_frames_per_thread);
 /* How many copies of the HIP runtime (libamdhip64) are mapped into this process, and where from (newline-separated paths in `paths`,
  * truncated to cap; may be NULL).  More than one -- e.g. this library bound to /opt/rocm's copy while another component brought its
  * own -- means device pointers and streams of one are unknown to the other: copies fail with "invalid argument", kernels fault.
@@ -227,6 +232,8 @@ int  amtgpu_logoframe_get_results(AmtGpuLogoFrame* lf, float* out);
 int  amtgpu_logoframe_set_results(AmtGpuLogoFrame* lf, int first, int nframes, const float* evals);
 int  amtgpu_logoframe_select_logo(AmtGpuLogoFrame* lf, int num_candidates);        /* -1 = all */
 int  amtgpu_logoframe_write_result(AmtGpuLogoFrame* lf, const char* outpath, int logo_index); /* -1 = best */
+/* LogoFrame::dumpResult (LogoScan.hpp:1632-1643): one text file per logo, "<basepath><logo index>", a line "%f,%f\n" {corr0, corr1} per frame */
+int  amtgpu_logoframe_dump_result(AmtGpuLogoFrame* lf, const char* basepath);
 int  amtgpu_logoframe_best_logo(const AmtGpuLogoFrame* lf);
 /* The same two decisions -- LogoFrame::selectLogo and the text LogoFrame::writeResult writes (LogoScan.hpp:1647-1827) -- from scan
  * records alone, on the host, no device and no LogoFrame object: what a rank (or a tool) that only holds the gathered

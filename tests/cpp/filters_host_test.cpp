@@ -6,12 +6,14 @@
 // clip.raw: int32 {W,H,bits,N,pitchY,pitchUV} then Y[N][H][pitchY], U[N][H/2][pitchUV], V[...] (elements of 1 or 2 bytes)
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <thread>
 
 #include "amt_filters.hpp"
 
@@ -294,6 +296,7 @@ int main(int argc, char** argv)
         dump(out + "/eval.bin", ev.data(), ev.size() * sizeof(float));
         lf.selectLogo(2);
         lf.writeResult(out + "/logof.txt");
+        lf.dumpResult(out + "/dump_");                     // LogoScan.hpp:1632-1643: dump_0, dump_1, dump_2
         {
             std::ofstream f(out + "/select.txt");
             f << lf.getBestLogo() << " " << std::hexfloat << lf.getLogoRatio() << "\n";
@@ -326,6 +329,44 @@ int main(int argc, char** argv)
                     for (int y = 0; y < fr->GetHeight(plane); ++y)
                         f.write(reinterpret_cast<const char*>(fr->GetReadPtr(plane)) + (size_t)y * fr->GetPitch(plane), fr->GetRowSize(plane));
             }
+        }
+
+        // 3c. AviSynth's Prefetch threads: four threads ask for frames of the SAME block at once.  The block's upstream frames must be
+        //     pulled once (the other threads wait for the fetch in flight), and every thread gets the frame the serial walk got.
+        {
+            struct CountingClip : IClip {
+                PClip child; std::atomic<int> calls{0};
+                explicit CountingClip(PClip c) : child(std::move(c)) {}
+                const VideoInfo& GetVideoInfo() override { return child->GetVideoInfo(); }
+                PVideoFrame GetFrame(int n, IScriptEnvironment* e) override
+                {
+                    ++calls;
+                    std::this_thread::sleep_for(std::chrono::microseconds(300));      // a decoder-bound upstream: makes the race window real
+                    return child->GetFrame(n, e);
+                }
+            };
+            auto counted = std::make_shared<CountingClip>(src);
+            const int blk = 5;
+            PClip er = std::make_shared<amtgpu::AMTEraseLogo>(counted, an, logo, "", 0, 16, &env, ctx, blk);
+            PClip serial = std::make_shared<amtgpu::AMTEraseLogo>(src, an, logo, "", 0, 16, &env, ctx, blk);
+            std::ofstream cf(out + "/concurrent.txt");
+            bool same = true, once = true;
+            for (int b0 = 0; b0 < vi.num_frames; b0 += blk) {
+                const int nb = std::min(blk, vi.num_frames - b0), before = counted->calls.load();
+                std::vector<PVideoFrame> got(4);
+                std::vector<std::thread> th;
+                for (int t = 0; t < 4; ++t) th.emplace_back([&, t] { IScriptEnvironment e2; got[t] = er->GetFrame(b0 + t % nb, &e2); });
+                for (auto& t : th) t.join();
+                once = once && counted->calls.load() - before == nb;
+                for (int t = 0; t < 4; ++t) {
+                    PVideoFrame want = serial->GetFrame(b0 + t % nb, &env);
+                    for (int plane : {PLANAR_Y, PLANAR_U, PLANAR_V})
+                        for (int y = 0; y < want->GetHeight(plane); ++y)
+                            same = same && !std::memcmp(want->GetReadPtr(plane) + (size_t)y * want->GetPitch(plane),
+                                                        got[t]->GetReadPtr(plane) + (size_t)y * got[t]->GetPitch(plane), want->GetRowSize(plane));
+                }
+            }
+            cf << "upstream_frames_pulled_once " << (once ? 1 : 0) << "\nframes_equal_serial " << (same ? 1 : 0) << "\n";
         }
 
         // 3b. the same graph built the way AviSynth builds it: through the factories the plugin registered with the

@@ -498,3 +498,46 @@ def test_amts_stream_index_reader_and_weave_plan(lib, tmp_path):
         assert not lib.amtgpu_amts_load(None, str(bad).encode())
     (tmp_path / "neg.dat").write_bytes(b"\\xff" * 8 + data[8:])
     assert not lib.amtgpu_amts_load(None, str(tmp_path / "neg.dat").encode())
+
+
+@pytest.mark.parametrize("threads,grain", [(2, 1), (3, 7), (5, 50), (8, 1000), (32, 4096)])
+def test_decisions_do_not_depend_on_how_the_clip_is_cut_over_threads(lib, threads, grain):
+    """amtgpu_host_set_parallelism: the replicated decisions cut the clip into frame ranges (window filters are local; the state machines
+    stay sequential).  Ranges shorter than every window, ranges of a few frames, many ranges: the oracle's outputs, byte for byte."""
+    O = Oracle()
+    W, H = 352, 240
+    try:
+        lib.amtgpu_host_set_parallelism(threads, grain)
+        for n in (1, 2, 9, 31, 64, 333, 2500, 20011):
+            rng = np.random.RandomState(n + threads)
+            # ---- logo selection + logoframe text ----
+            nl = 3
+            ev = np.zeros((n, nl, 2), np.float32)
+            for l in range(nl):
+                on = ((np.arange(n) // (37 + 11 * l)) % 2).astype(np.float32)
+                ev[:, l, 0] = on * 0.9 - 0.1 + rng.uniform(-0.5, 0.5, n)
+                ev[:, l, 1] = np.where(on > 0, rng.uniform(-0.1, 0.1, n), -0.6 + rng.uniform(-0.3, 0.3, n))
+                k = rng.randint(0, 90, n) == 0
+                ev[k, l, 0], ev[k, l, 1] = np.inf, -np.inf
+            ob, orat = C.c_int(), C.c_float()
+            O.lib.orc_logoframe_select(_ptr(ev), n, nl, -1, C.byref(ob), C.byref(orat))
+            want = C.create_string_buffer(1 << 20)
+            wl = O.lib.orc_logoframe_write_result(_ptr(ev), n, nl, ob.value, 30000, 1001, want, len(want))
+            got = C.create_string_buffer(1 << 20)
+            best, ratio, tl = C.c_int(-2), C.c_float(), C.c_int()
+            assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, -1, 30000, 1001, C.byref(best), C.byref(ratio), got, len(got), C.byref(tl)) == 1
+            assert best.value == ob.value and np.float32(ratio.value).tobytes() == np.float32(orat.value).tobytes()
+            assert got.raw[:tl.value] == want.raw[:wl], (n, threads, grain)
+            # ---- scene changes + cadence ----
+            if n > 2500:
+                continue                                   # (the numpy oracle walks every window in Python)
+            for kind in (0, 1):
+                m = _metric_stream(np.random.RandomState(1000 * kind + n), n, W, H, kind)
+                cad, ph, sc, k = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.int32), C.c_int()
+                assert lib.amtgpu_kfm_cadence(_ptr(m), n, W, H, _ptr(cad), _ptr(ph)) == 1
+                assert lib.amtgpu_cm_scene_changes(_ptr(m), n, W, H, _ptr(sc), n, C.byref(k)) == 1
+                ocad, oph = FS.classify_cadence(m, W, H)
+                assert np.array_equal(cad, ocad) and np.array_equal(ph, oph), (n, threads, grain, kind)
+                assert sc[:k.value].tolist() == FS.scene_changes(m, W, H)
+    finally:
+        lib.amtgpu_host_set_parallelism(0, 0)

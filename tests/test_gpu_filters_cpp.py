@@ -71,6 +71,9 @@ def test_cpp_filters_match_oracle(tmp_path, bits):
     buf = C.create_string_buffer(1 << 16)
     ln = orc.lib.orc_logoframe_write_result(_ptr(want.reshape(-1)), N, 3, best.value, 30000, 1001, buf, len(buf))
     assert (out / "logof.txt").read_bytes() == buf.raw[:ln]
+    # LogoFrame::dumpResult (LogoScan.hpp:1632-1643): "<base><logo>", one "%f,%f\n" line per frame
+    for i in range(3):
+        assert (out / f"dump_{i}").read_text() == "".join("%f,%f\n" % (float(a), float(b)) for a, b in want[:, i])
 
     # ---- AMTAnalyzeLogo: BGR32 64x5 clip of ceil(N/8) frames, 8 records each, source frame numbers clamped ----
     assert (out / "analysis_vi.txt").read_text().split() == ["64", "5", str((N + 7) // 8), "100"]
@@ -105,6 +108,9 @@ def test_cpp_filters_match_oracle(tmp_path, bits):
             assert np.array_equal(g[:W * H].reshape(H, W), eY[i, :, :W]), (name, i)
             assert np.array_equal(g[W * H:W * H + (W // 2) * (H // 2)].reshape(H // 2, W // 2), eU[i, :, :W // 2])
             assert np.array_equal(g[W * H + (W // 2) * (H // 2):].reshape(H // 2, W // 2), eV[i, :, :W // 2])
+
+    # four threads asking for frames of one block: its upstream frames pulled once, frames equal to the serial walk's
+    assert (out / "concurrent.txt").read_text().split() == ["upstream_frames_pulled_once", "1", "frames_equal_serial", "1"]
 
     errs = (out / "errors.txt").read_text().splitlines()
     assert errs[0].startswith("Failed to read logo file (") and "missing.lgd" in errs[0]

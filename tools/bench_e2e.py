@@ -50,7 +50,7 @@ def _generate(S, torch, dev, a0, a1, alpha, alphaUV, seed=0x5EED0006):
     return cat(Ys), cat(Us), cat(Vs)
 
 
-def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
+def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="strong"):
     """E: namespace with torch, dist, rank, world, dev, ctx, logos_np, alpha, alphaUV, fence(), max_over_ranks(x), OracleLogos, rccl"""
     torch, dist, rank, world, dev, ctx = E.torch, E.dist, E.rank, E.world, E.dev, E.ctx
     import amt_synth as S
@@ -85,6 +85,14 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
         probes = [(0, nt)]
     stash = {}                                         # frame index -> erased (Y, U, V) of probe frames this rank owns
     is_probe = lambda n: any(p <= n < p + k for p, k in probes)
+    # ... and one CONTIGUOUS range of up to 4 096 frames per rank, straddling the rank's first chunk boundary where it has one, every
+    # frame of which is compared with the oracle (tools/bench_verify.py); its erased frames stay on the device until then
+    VR = 4096
+    vr0 = -(-max(f0, f0 + chunk - VR // 2) // 8) * 8 if nloc > chunk else -(-f0 // 8) * 8
+    vr1 = min(f1, vr0 + VR)
+    if not verify or vr1 - vr0 < 16:
+        vr0 = vr1 = 0
+    vstash = []                                        # (first frame, Y, U, V) pieces of [vr0, vr1), erased
 
     # warm-up, untimed (the headline's warm-up steps): the first use of every object builds its tile plans and tables, uploads them and
     # loads the 16-bit kernels -- per-logo set-up like the reference's constructors (CreateLogoMask, LogoScan.hpp:1164-1201), ~9 ms.
@@ -152,6 +160,9 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
             for n in range(c0, c1):
                 if is_probe(n):
                     stash[n] = tuple(t[n - c0].cpu().numpy().view(np.uint16) for t in (own.Y, own.U, own.V))
+            s0, s1 = max(c0, vr0), min(c1, vr1)
+            if s0 < s1:
+                vstash.append((s0,) + tuple(t[s0 - c0:s1 - c0].clone() for t in (own.Y, own.U, own.V)))
         del Y, U, V, own
     prof = ctx.profile_report()
     ctx.profile(False)
@@ -164,7 +175,7 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
     t0 = time.perf_counter()
     lap("begin")
     fades_loc = d_fades[:nloc].cpu()
-    stats_loc = d_stats[:nloc].cpu().numpy().astype(np.uint64)
+    stats_loc = d_stats[:nloc].cpu().numpy().view(np.uint64)
     if world > 1:
         SH.logoframe_allgather(lf, f0, nloc, coll)                                        # 8 B per frame per logo
         metrics = SH.framestats_allgather(st, stats_loc, f0, nt, coll)                    # 64 B per frame
@@ -228,6 +239,19 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
                     ol.erase(Yb, Ub, Vb, i, ft, fb)
                     eY, eU, eV = stash[n]
                     ok["erase"] &= bool(np.array_equal(Yb[i], eY) and np.array_equal(Ub[i], eU) and np.array_equal(Vb[i], eV))
+        if vr1 > vr0:
+            import bench_verify as BV
+            eY, eU, eV = (torch.cat([p[k] for p in vstash], 0) for k in (1, 2, 3))
+            assert vstash[0][0] == vr0 and eY.shape[0] == vr1 - vr0
+            vstash.clear()
+            rr = BV.verify_range(torch, ol, BITS, nt, vr0, vr1, lambda lo, hi: _generate(S, torch, dev, lo, hi, E.alpha, E.alphaUV),
+                                 lambda lo, hi: (eY[lo - vr0:hi - vr0], eU[lo - vr0:hi - vr0], eV[lo - vr0:hi - vr0]),
+                                 ev, an_all, fades, metrics, tol=tol, chunk=256)
+            del eY, eU, eV
+            for k in ("scan", "analysis", "fades", "erase", "metrics"):
+                ok[k] &= rr[k]
+            ok["frames"] += rr["frames"]
+            max_an = max(max_an, rr["analysis_max_abs_err"])
     flags = torch.tensor([int(ok[k]) for k in ("scan", "analysis", "fades", "erase", "metrics")] + [ok["frames"]], dtype=torch.int64)
     mx = torch.tensor([max_an], dtype=torch.float64)
     gen_t = torch.tensor([gen_s, timed_s, tail_s], dtype=torch.float64)
@@ -250,6 +274,7 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
     det = set(int(x) for x in sc.tolist())
     verified = dict(zip(("scan", "analysis", "fades", "erase", "metrics"), (bool(v) for v in flags[:5].tolist())))
     verified.update({"frames_compared_with_cpu_oracle": int(flags[5]), "probe_blocks": [[p, k] for p, k in probes],
+                     "contiguous_range_rank0": [vr0, vr1],
                      "analysis_max_abs_err": float(mx[0]), "analysis_compare": "abs <= 1e-4" if mode == "linear" else "bytes",
                      "ok": bool(all(flags[:5].tolist())) if verify else None})
     byts = W * H * 2
@@ -258,9 +283,9 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear"):
         "workload": f"BASELINE configs[4]: end-to-end logo scan + AMTAnalyzeLogo + CalcFade + AMTEraseLogo + CM/KFM frame metrics and decisions on "
                     f"{nt} frames ({nt / 29.97 / 3600:.2f} h) of 1920x1080i 10-bit (16-bit containers), frames sharded over {world} GPU(s) by contiguous "
                     f"range, {chunk}-frame chunks generated on the device with an {HALO}-frame halo either side" +
-                    (f" -- {nt} frames = one GPU's share of the 4-hour stream ({FULL_FRAMES} frames) at N = 8" if nt == SHARE_FRAMES else ""),
+                    (f" -- {SHARE_FRAMES} frames per GPU = one GPU's share of the 4-hour stream ({FULL_FRAMES} frames) at N = 8" if nt == SHARE_FRAMES * world else ""),
         "frames_total": nt, "frames_per_gpu": nloc, "n_gpus": world, "chunk_frames": chunk, "analysis_mode": mode,
-        "value": nt / total_s, "unit": "frames/sec", "timed_s": total_s, "scaling": "strong",
+        "value": nt / total_s, "unit": "frames/sec", "timed_s": total_s, "scaling": scaling,
         "timed_region": "per chunk: analysis (chunk + halo) -> device CalcFade -> scan -> frame metrics -> erase, inputs resident in HBM; plus the "
                         "final exchanges and the replicated decisions; max over ranks.  Untimed: stream generation, and one 32-frame warm-up "
                         "pass (first use of every object: tile plans, tables, code objects -- per-logo set-up)",
