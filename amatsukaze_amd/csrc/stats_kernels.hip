@@ -48,6 +48,9 @@ constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
 #ifndef AMT_STATS_LEAN
 #define AMT_STATS_LEAN 1
 #endif
+#ifndef AMT_STATS_DEAL
+#define AMT_STATS_DEAL 0       /* 0: (tile, column) pairs dealt densely over the threads; 1: wave-segment dealing (see the kernel) */
+#endif
 #ifndef AMT_STATS_NT
 #define AMT_STATS_NT 2         /* cache-policy bits of the loads of rows no other tile reads: 2 = nt (non-temporal) */
 #endif
@@ -159,7 +162,16 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
     const int per = gridDim.x / kStatXcds;
     const int wg = (blockIdx.x % kStatXcds) * per + blockIdx.x / kStatXcds;
     int tile, xb;
-    if (kStatVG > 1) {
+    if (AMT_STATS_DEAL == 1) {
+        // wave-segment dealing: a row is cut into wpt = ceil(cols / 64) equal segments, one wave each; consecutive waves take the segments
+        // of one tile, so (wpt = 2, two waves per workgroup) the waves that share a 128-byte line -- the segment boundary, and a row's tail
+        // with the next row's head when the pitch is not a multiple of the line -- sit in ONE workgroup and ask for it at the same time
+        const int wpt = (cols + 63) >> 6, cpw = (cols + wpt - 1) / wpt;
+        const int wave = wg * (kStatThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        tile = wave / wpt;
+        const int col = (wave - tile * wpt) * cpw + lane;
+        xb = (lane < cpw && col < cols) ? col * kStatColBytes : row_bytes;          // (row_bytes: no valid bytes -> an idle lane)
+    } else if (kStatVG > 1) {
         const int gid = wg * 64 + (threadIdx.x & 63);
         const int st = gid / cols;
         tile = st * kStatVG + (threadIdx.x >> 6);
@@ -323,7 +335,9 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     if ((long long)H * pitch_elems * es >= (1LL << 31)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
-    const int wgs = kStatVG > 1 ? ((tiles + kStatVG - 1) / kStatVG * col_groups + 63) / 64 : (tiles * col_groups + kStatThreads - 1) / kStatThreads;
+    const int wpt = (col_groups + 63) / 64;
+    const int wgs = AMT_STATS_DEAL == 1 ? (tiles * wpt + kStatThreads / 64 - 1) / (kStatThreads / 64)
+                  : kStatVG > 1 ? ((tiles + kStatVG - 1) / kStatVG * col_groups + 63) / 64 : (tiles * col_groups + kStatThreads - 1) / kStatThreads;
     dim3 grid((unsigned)((wgs + kStatXcds - 1) / kStatXcds * kStatXcds), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
         block(kStatThreads);                                      // surplus workgroups of the round-up find nvalid <= 0
     const bool ragged = row_bytes % kStatColBytes != 0;

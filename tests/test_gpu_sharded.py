@@ -166,6 +166,17 @@ def test_sharded_hip_path_world2(tmp_path):
     assert all(p.exitcode == 0 for p in procs)
 
 
+def _bench_lines(r):
+    """(the compact line bench.py prints last on stdout -- what the driver parses --, the full detail it writes to stderr)"""
+    import json
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(r.stdout.strip().splitlines()[-1]) < 6144
+    full = next(json.loads(l)["bench_detail"] for l in reversed(r.stderr.splitlines()) if l.startswith('{"bench_detail"'))
+    for k in ("value", "n_gpus", "scaling", "steps"):
+        assert (line[k] == full[k]) or abs(line[k] - full[k]) <= 1e-5 * abs(full[k]), k
+    return line, full
+
+
 def test_bench_multi_rank_control_flow_dry_run():
     """`bench.py --gpus 2` on whatever box runs this: the launcher re-executes itself under torch.distributed.run, the ranks shard
     the work and exchange their records.  On a 1-GPU box the ranks share device 0 and talk over gloo (AMT_BENCH_SHARED_GPU=1: a
@@ -183,9 +194,9 @@ def test_bench_multi_rank_control_flow_dry_run():
                            (["--scaling", "strong"], "strong")):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + extra, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        line = json.loads(r.stdout.strip().splitlines()[-1])
-        assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
-        assert line["collectives"]["world_size_observed"] == 2 and line["collectives"]["backend"] in ("rccl", "gloo")
+        compact, line = _bench_lines(r)
+        assert compact["n_gpus"] == 2 and compact["scaling"] == scaling and compact["value"] > 0 and compact["strong_scan"]["value"] > 0
+        assert compact["collectives"]["world_size_observed"] == 2 and compact["collectives"]["backend"] in ("rccl", "gloo")
         ss = line["strong_scan"]
         assert ss["n_gpus"] == 2 and ss["verified"]["sharded_equals_single_launch"] and ss["verified"]["equals_cpu_oracle"]
         sl = ss["scanlogo"]                              # the sharded "full LogoScan" of the same stream: quota hand-out + 3 all-reduces
@@ -194,6 +205,7 @@ def test_bench_multi_rank_control_flow_dry_run():
         lgd_hashes.add(sl["lgd_sha256"])
         if scaling == "weak":
             assert line["verified"]["ok"] and line["verified"]["tolerance_ok"] and line["verified"]["fades_equal_all"]
+            assert compact["verified"]["ok"] and compact["verified"]["frames"] == 512 and compact["roofline"]["frac"] > 0
     assert len(lgd_hashes) == 1          # the weak line's attached strong scan and the strong line scanned the same stream
 
 
@@ -215,7 +227,7 @@ def test_bench_eight_rank_control_flow_dry_run():
     def run(extra, gpus):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus)] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        return _bench_lines(r)[1]
 
     strong = ["--scaling", "strong", "--strong-frames", "4099", "--strong-steps", "1"]
     s8, s1 = run(strong, 8), run(strong, 1)

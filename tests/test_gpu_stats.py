@@ -24,7 +24,7 @@ def gpu():
                                           (1920, 1080, 10, 0), (720, 480, 8, 16), (48, 34, 8, 0), (16, 18, 8, 0),
                                           # a ragged row in an unpadded pitch: the last 16-byte column of the bottom row would straddle the
                                           # end of the frame's buffer -- these take the plain-load form of the kernel
-                                          (362, 242, 8, 0), (362, 50, 8, 2), (363, 26, 8, 0), (45, 30, 10, 0), (360, 242, 8, 0)])
+                                          (362, 242, 8, 0), (362, 50, 8, 2), (366, 26, 8, 0), (354, 26, 8, 0), (46, 30, 10, 0), (360, 242, 8, 0)])
 def test_frame_metrics_bit_exact(gpu, W, H, bits, pad):
     from amatsukaze_amd import DeviceClip, FrameStats
     torch = gpu["torch"]

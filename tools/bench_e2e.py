@@ -279,6 +279,34 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
                      "ok": bool(all(flags[:5].tolist())) if verify else None})
     byts = W * H * 2
     fsk = kern.get("frame_stats_kernel")
+    # ---- roofline of the 16-bit kernels (rank 0's launches, HIP events on the launch stream; algorithmic work as in bench.py: 101 flop per
+    #      mask-pixel evaluation + 6 per rectangle pixel per evaluation; HBM traffic from the committed PMC passes over this very workload) ----
+    import json
+    try:
+        pmc16 = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_pmc_traffic16.json")))
+    except Exception:
+        pmc16 = {}
+    an_tab = [logos[0].mask_tables(k, E.maskratio)["count"] for k in (0, 1, 2)]
+    scan_tab = [l.mask_tables(0, E.maskratio)["count"] for l in logos]
+    fl_an = 101 * 11 * sum(an_tab) + 6 * 11 * (LW * LH + 2 * LW * (LH // 2))
+    fl_sc = 101 * 2 * sum(scan_tab) + 6 * 2 * 3 * LW * LH
+    nchunks = -(-nloc // chunk) if nloc else 0
+    fr_an = nloc + 2 * HALO * nchunks                        # (chunk + halo per analysis launch; a little less at the clip's ends)
+    roof16 = {}
+    for name, (kind, per_frame, frames, algb) in {"logo_eval_linear_kernel16.analysis": ("fp32-valu", fl_an, fr_an, 2 * LW * LH + 132),
+                                                  "logo_eval_pair_kernel.scan": ("fp32-valu", fl_sc, nloc, 3 * 2 * LW * LH + 24),
+                                                  "frame_stats_kernel": ("hbm", byts, nloc, byts),
+                                                  "delogo_kernel": ("hbm", 2 * 2 * (LW * LH + 2 * (LW // 2) * (LH // 2)), nloc, 2 * 2 * (LW * LH + 2 * (LW // 2) * (LH // 2)))}.items():
+        k = kern.get(name) or kern.get(name.split(".")[0])
+        if not k or not k["total_ms"]:
+            continue
+        rate = per_frame * frames / (k["total_ms"] * 1e-3)
+        peak = 157.3e12 if kind == "fp32-valu" else 8000e9
+        tr = pmc16.get(name.split(".")[0], {}).get("hbm_bytes_per_frame")
+        roof16[name] = {"bound": kind, "achieved": rate / (1e12 if kind == "fp32-valu" else 1e9), "unit": "TFLOP/s" if kind == "fp32-valu" else "GB/s",
+                        "peak": peak / (1e12 if kind == "fp32-valu" else 1e9), "frac": rate / peak, "launches": k["launches"], "total_ms": k["total_ms"],
+                        "algorithmic_bytes_per_frame": algb, "traffic_bytes_per_frame": tr,
+                        "traffic_source": "profiles/r05_pmc_traffic16.json" if tr else None}
     return {
         "workload": f"BASELINE configs[4]: end-to-end logo scan + AMTAnalyzeLogo + CalcFade + AMTEraseLogo + CM/KFM frame metrics and decisions on "
                     f"{nt} frames ({nt / 29.97 / 3600:.2f} h) of 1920x1080i 10-bit (16-bit containers), frames sharded over {world} GPU(s) by contiguous "
@@ -294,6 +322,7 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
         **({"chunk_phases_ms_fenced_diagnostic": phases} if phases is not None else {}),
         "frame_stats_hbm": ({"achieved_gbs": byts * nloc / (fsk["total_ms"] * 1e-3) / 1e9, "frac": byts * nloc / (fsk["total_ms"] * 1e-3) / 1e9 / 8000.0}
                             if fsk else None),
+        "roofline16": roof16,
         "decisions_sha256": h.hexdigest(),
         "decisions_hashed": "sha256 over the sha256 of: fades (float32 pairs), logoframe text, cadence per frame, 3:2 phase per frame, scene-change "
                             "list (int32), per-frame checksum of the erased logo rectangles (3*sum Y + 5*sum U + 7*sum V) -- identical at every N and "

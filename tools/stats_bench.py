@@ -10,6 +10,8 @@ VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean_no_nt": ["AMT_STATS_NT=0"], 
             # taller tiles: the halo rows are 2 / ROWS of the traffic
             "rows24": ["AMT_STATS_ROWS=24"], "rows24_8B": ["AMT_STATS_ROWS=24", "AMT_STATS_COLB=8"], "rows32_8B": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"],
             "rows32_8B_run64": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8", "AMT_STATS_RUN=64"],
+            "deal1": ["AMT_STATS_DEAL=1"], "deal1_no_nt": ["AMT_STATS_DEAL=1", "AMT_STATS_NT=0"], "deal1_run64": ["AMT_STATS_DEAL=1", "AMT_STATS_RUN=64"],
+            "deal1_rows16": ["AMT_STATS_DEAL=1", "AMT_STATS_ROWS8=16"], "run64": ["AMT_STATS_RUN=64"], "no_nt": ["AMT_STATS_NT=0"],
             "rows8bit_16": ["AMT_STATS_ROWS8=16"], "rows8bit_20": ["AMT_STATS_ROWS8=20"], "rows8bit_28": ["AMT_STATS_ROWS8=28"]}
 ONLY = [a for a in sys.argv[1:] if not a.startswith("--")]
 if ONLY:
