@@ -27,9 +27,15 @@ struct EraseGeom {
 // so a luma pair is one aligned 2*sizeof(pix_t) access; chroma pairs are used when the chroma origin, width and
 // pitch are even too, otherwise that plane goes sample by sample), for kDelogoFrames consecutive frames: the pass is a
 // read-modify-write of 48 KiB per frame against 384 KiB of logo coefficients, which are therefore loaded once per group.
-constexpr int kDelogoRows = 16;
+#ifndef AMT_DELOGO_ROWS
+#define AMT_DELOGO_ROWS 16
+#endif
+#ifndef AMT_DELOGO_FRAMES
+#define AMT_DELOGO_FRAMES 8
+#endif
+constexpr int kDelogoRows = AMT_DELOGO_ROWS;
 constexpr int kDelogoThreads = 256;
-constexpr int kDelogoFrames = 8;       // frames a workgroup walks through with the row's logo coefficients in registers
+constexpr int kDelogoFrames = AMT_DELOGO_FRAMES;       // frames a workgroup walks through with the row's logo coefficients in registers
 
 // four adjacent samples in one access (rows whose width is a multiple of 4: one wave moves 256 / 512 contiguous bytes per row)
 template <typename pix_t> struct PixQuad;
@@ -75,6 +81,13 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
     const int f1 = min(nframes, f0 + kDelogoFrames);
     const size_t ysz = (size_t)g.w * g.h, csz = (size_t)g.wUV * g.hUV;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (zero_identity) {
+        // a group whose frames all carry fade {0, 0} has nothing to rewrite (half of a clip whose logo comes and goes): leave before the
+        // coefficient rows are fetched
+        bool any = false;
+        for (int f = f0; f < f1; ++f) { const float2 fd = fades[f]; any = any || fd.x != 0.0f || fd.y != 0.0f; }
+        if (!any) return;
+    }
     const int rend = min(g.h + 2 * g.hUV, (int)(blockIdx.x + 1) * kDelogoRows);
     for (int r = blockIdx.x * kDelogoRows + wv; r < rend; r += kDelogoThreads / 64) {
         // the row's geometry and logo coefficients are the same for every frame of the group: the logo planes are

@@ -171,6 +171,19 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         tile = wave / wpt;
         const int col = (wave - tile * wpt) * cpw + lane;
         xb = (lane < cpw && col < cols) ? col * kStatColBytes : row_bytes;          // (row_bytes: no valid bytes -> an idle lane)
+    } else if (AMT_STATS_DEAL == 2) {
+        // grouped dealing: every wave's span starts on a multiple of 64 columns (1 KiB) of its tile's rows, so a span boundary never cuts a
+        // 128-byte line of a line-aligned row.  The full 64-column groups of a tile take a wave each; the remainders (r = cols % 64
+        // columns) of P = 64 / r consecutive tiles share one wave.  1440 bytes = 90 columns: waves {tile 2b: 0-63}, {tile 2b+1: 0-63},
+        // {26 + 26 remainder columns of both} -- 94 % of the lanes busy, against dense dealing's arbitrary boundaries (a line cut by a
+        // boundary is fetched by both waves, and the L2 does not merge the two misses: profiles/r05_notes.md)
+        const int G = cols >> 6, r = cols & 63, P = r ? 64 / r : 1, wpb = P * G + (r ? 1 : 0);      // waves per block of P tiles
+        const int wave = wg * (kStatThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int b = wave / wpb, i = wave - b * wpb;
+        int col;
+        if (i < P * G) { tile = b * P + i / G; col = (i % G) * 64 + lane; }
+        else { const int sub = lane / r; tile = b * P + sub; col = sub < P ? G * 64 + (lane - sub * r) : cols; }
+        xb = col < cols ? col * kStatColBytes : row_bytes;
     } else if (kStatVG > 1) {
         const int gid = wg * 64 + (threadIdx.x & 63);
         const int st = gid / cols;
@@ -336,7 +349,9 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     hipError_t e = hipMemsetAsync(dout, 0, (size_t)nframes * kStatWords * sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
     const int wpt = (col_groups + 63) / 64;
-    const int wgs = AMT_STATS_DEAL == 1 ? (tiles * wpt + kStatThreads / 64 - 1) / (kStatThreads / 64)
+    const int dG = col_groups / 64, dR = col_groups % 64, dP = dR ? 64 / dR : 1, dWpb = dP * dG + (dR ? 1 : 0);
+    const int wgs = AMT_STATS_DEAL == 2 ? ((tiles + dP - 1) / dP * dWpb + kStatThreads / 64 - 1) / (kStatThreads / 64)
+                  : AMT_STATS_DEAL == 1 ? (tiles * wpt + kStatThreads / 64 - 1) / (kStatThreads / 64)
                   : kStatVG > 1 ? ((tiles + kStatVG - 1) / kStatVG * col_groups + 63) / 64 : (tiles * col_groups + kStatThreads - 1) / kStatThreads;
     dim3 grid((unsigned)((wgs + kStatXcds - 1) / kStatXcds * kStatXcds), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
         block(kStatThreads);                                      // surplus workgroups of the round-up find nvalid <= 0

@@ -52,7 +52,7 @@ FLOPS_PER_RECT_PIXEL = 6               # EvaluateLogo's unblend per rectangle pi
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3               # fp32 vector peak (FMA counted as 2)
 STRONG_FRAMES = 107892                 # BASELINE configs[3]: 60 min at 29.97 fps
-PMC_TRAFFIC = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r05_pmc_traffic.json")
 EVAL = "logo_eval_fused_kernel"
 
 

@@ -293,7 +293,7 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
     nchunks = -(-nloc // chunk) if nloc else 0
     fr_an = nloc + 2 * HALO * nchunks                        # (chunk + halo per analysis launch; a little less at the clip's ends)
     roof16 = {}
-    for name, (kind, per_frame, frames, algb) in {"logo_eval_linear_kernel16.analysis": ("fp32-valu", fl_an, fr_an, 2 * LW * LH + 132),
+    for name, (kind, per_frame, frames, algb) in {"logo_eval_linear_kernel.analysis": ("fp32-valu", fl_an, fr_an, 2 * LW * LH + 132),
                                                   "logo_eval_pair_kernel.scan": ("fp32-valu", fl_sc, nloc, 3 * 2 * LW * LH + 24),
                                                   "frame_stats_kernel": ("hbm", byts, nloc, byts),
                                                   "delogo_kernel": ("hbm", 2 * 2 * (LW * LH + 2 * (LW // 2) * (LH // 2)), nloc, 2 * 2 * (LW * LH + 2 * (LW // 2) * (LH // 2)))}.items():
@@ -302,8 +302,8 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
             continue
         rate = per_frame * frames / (k["total_ms"] * 1e-3)
         peak = 157.3e12 if kind == "fp32-valu" else 8000e9
-        tr = pmc16.get(name.split(".")[0], {}).get("hbm_bytes_per_frame")
-        roof16[name] = {"bound": kind, "achieved": rate / (1e12 if kind == "fp32-valu" else 1e9), "unit": "TFLOP/s" if kind == "fp32-valu" else "GB/s",
+        tr = pmc16.get({"logo_eval_linear_kernel.analysis": "logo_eval_linear_kernel16"}.get(name, name.split(".")[0]), {}).get("hbm_bytes_per_frame")
+        roof16[name + (" (16-bit samples)" if "linear" in name or "pair" in name else "<16-bit>")] = {"bound": kind, "achieved": rate / (1e12 if kind == "fp32-valu" else 1e9), "unit": "TFLOP/s" if kind == "fp32-valu" else "GB/s",
                         "peak": peak / (1e12 if kind == "fp32-valu" else 1e9), "frac": rate / peak, "launches": k["launches"], "total_ms": k["total_ms"],
                         "algorithmic_bytes_per_frame": algb, "traffic_bytes_per_frame": tr,
                         "traffic_source": "profiles/r05_pmc_traffic16.json" if tr else None}

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 5: full GPU test suite, the bench line as the driver runs it and with the defaults, rocprofv3 kernel stats + PMC traffic of the bench's own launches
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r5_pytest.log )
+tail -4 gpurun_out/r5_pytest.log
+timeout 900 bash tools/gpu_prof_bench.sh r05 > gpurun_out/r5_prof.log 2>&1; echo "prof rc=$?"; tail -5 gpurun_out/r5_prof.log | cut -c1-300
+cp gpurun_out/profb_r05/r05_pmc_traffic.json profiles/r05_pmc_traffic.json 2>/dev/null      # the line below quotes this round's own traffic figures
+timeout 1200 python bench.py > gpurun_out/r5_bench.json 2> gpurun_out/r5_bench.err; echo "bench rc=$?"; tail -n 1 gpurun_out/r5_bench.json | head -c 1500; echo
+cp bench_detail.json gpurun_out/r5_bench_detail.json
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5_bench_driver.json 2> gpurun_out/r5_bench_driver.err; echo "driver-style bench rc=$?"; wc -c gpurun_out/r5_bench_driver.json

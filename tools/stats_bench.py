@@ -10,6 +10,7 @@ VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean_no_nt": ["AMT_STATS_NT=0"], 
             # taller tiles: the halo rows are 2 / ROWS of the traffic
             "rows24": ["AMT_STATS_ROWS=24"], "rows24_8B": ["AMT_STATS_ROWS=24", "AMT_STATS_COLB=8"], "rows32_8B": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"],
             "rows32_8B_run64": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8", "AMT_STATS_RUN=64"],
+            "deal2": ["AMT_STATS_DEAL=2"], "deal2_rows16": ["AMT_STATS_DEAL=2", "AMT_STATS_ROWS8=16"], "deal2_rows20": ["AMT_STATS_DEAL=2", "AMT_STATS_ROWS8=20"],
             "deal1": ["AMT_STATS_DEAL=1"], "deal1_no_nt": ["AMT_STATS_DEAL=1", "AMT_STATS_NT=0"], "deal1_run64": ["AMT_STATS_DEAL=1", "AMT_STATS_RUN=64"],
             "deal1_rows16": ["AMT_STATS_DEAL=1", "AMT_STATS_ROWS8=16"], "run64": ["AMT_STATS_RUN=64"], "no_nt": ["AMT_STATS_NT=0"],
             "rows8bit_16": ["AMT_STATS_ROWS8=16"], "rows8bit_20": ["AMT_STATS_ROWS8=20"], "rows8bit_28": ["AMT_STATS_ROWS8=28"]}
@@ -41,7 +42,12 @@ if "--child" in sys.argv:
         assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, words) == 0
         ctx.check(ctx.lib.amtgpu_context_set_stream(ctx.h, st))
     out = {}
-    for tag, (W, H, bits, pitch, N) in {"1440x1080_8bit": (1440, 1080, 8, 1472, 10000), "1920x1080_8bit": (1920, 1080, 8, 1920, 6000), "1920x1080_10bit": (1920, 1080, 10, 1920, 3000)}.items():
+    shapes = {"1440x1080_8bit": (1440, 1080, 8, 1472, 10000), "1920x1080_8bit": (1920, 1080, 8, 1920, 6000), "1920x1080_10bit": (1920, 1080, 10, 1920, 3000)}
+    if os.environ.get("AMT_STATS_FRAMES"):        # (counter passes: fewer frames)
+        shapes = {k: v[:4] + (min(v[4], int(os.environ["AMT_STATS_FRAMES"])),) for k, v in shapes.items()}
+    if os.environ.get("AMT_STATS_PITCHES"):      # the same 1440-wide frames at other pitches: 1472 = AviSynth's 64-byte alignment (odd rows start mid-line)
+        shapes = {f"1440x1080_8bit_pitch{p}": (1440, 1080, 8, p, int(os.environ.get("AMT_STATS_FRAMES", "10000"))) for p in (1472, 1536, 1440, 1408 + 128 + 64)}
+    for tag, (W, H, bits, pitch, N) in shapes.items():
         Y = S.make_clip_torch(N, W, H, 0x5EED0002, None, None, 0, 0, dev, bits=bits, pitchY=pitch, chroma=False)["Y"]
         fs = FrameStats(ctx, W, H, bits)
         o = torch.zeros((N, 8), dtype=torch.int64, device=dev)
