@@ -41,7 +41,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file extras.  eval_fused_kernels.hip: the fade loop is ~200 straight-line VALU instructions per iteration with
 # 8-cycle dependent-issue latency (tools/ubench/valu_rate.hip); the max-ILP scheduler spaces dependent packed ops
 # further apart than the default occupancy-driven one (measured: 2.58 -> 2.40 ms per 2048-frame analysis).
-EXTRA_FLAGS = {"eval_fused_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# eval_linear_kernels.hip: no SLP vectorisation -- a packed fp32 op issues in 4 cycles against 2 for a plain one (tools/ubench/valu_rate.hip), so
+# pairing the per-fade scalar code gains nothing and costs the v_mov shuffles that assemble the pairs, and a DPP operand cannot fold into
+# a packed add (measured: 3.21 -> 3.12 ms per 10 000 frames, outputs identical; profiles/r05_notes.md).
+EXTRA_FLAGS = {"eval_fused_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               "eval_linear_kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:
@@ -59,8 +63,10 @@ def needs_build(srcs) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(name: str, defines, extra_flags=()) -> str:
-    """An instrumented copy of the library (tools/phase_timing.py): amatsukaze_amd/libamt_gpu_<name>.so"""
+def build_variant(name: str, defines, extra_flags=(), file_flags=None) -> str:
+    """An instrumented copy of the library (tools/phase_timing.py): amatsukaze_amd/libamt_gpu_<name>.so
+    file_flags: {source file: [flags]} on top of EXTRA_FLAGS, for experiments with one translation unit's compiler options"""
+    file_flags = file_flags or {}
     out = os.path.join(HERE, f"libamt_gpu_{name}.so")
     bdir = os.path.join(HERE, "build", name)
     os.makedirs(bdir, exist_ok=True)
@@ -68,7 +74,7 @@ def build_variant(name: str, defines, extra_flags=()) -> str:
     for f in SOURCES:
         o = os.path.join(bdir, f + ".o")
         objs.append(o)
-        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(f, []), *extra_flags, *[f"-D{d}" for d in defines], "-x", "hip", "-c",
+        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(f, []), *file_flags.get(f, []), *extra_flags, *[f"-D{d}" for d in defines], "-x", "hip", "-c",
                os.path.join(CSRC, f), "-o", o]
         procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for f, p in procs:

@@ -32,6 +32,9 @@ namespace amt {
 using namespace lin;
 using namespace tile;
 
+#ifndef AMT_LIN_AB_LDS
+#define AMT_LIN_AB_LDS 0
+#endif
 #ifndef AMT_LIN_WAVES
 #define AMT_LIN_WAVES 4
 #endif
@@ -102,8 +105,12 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     constexpr int NFMAX = NF > 0 ? NF : kLinMaxFades;
     const int nfades = NF > 0 ? NF : A.nfades;
     extern __shared__ float lds[];
-    f2* const planes = reinterpret_cast<f2*>(lds);                 // [kLinWaves][2][kTileCap] a wave's own tile: {s, bg} and the logo's {a, b*maxv}
-    float* const wacc = lds + kLinWaves * 2 * kTileCap * 2;        // [kLinWaves][G][48 lanes][4] a wave's running sums (kLinAccFrameBytes per frame)
+    // AMT_LIN_AB_LDS = 1 (rounds 3-4): a second plane per wave holds the tile's {a, b*maxv} -- the kernel was short of registers.  Since the
+    // taps' broadcasts moved into the multiply-adds it has 36 to spare: the coefficients of a lane's two staging units stay in 16 registers,
+    // two 16-byte LDS reads per unit and frame less in a kernel that the LDS bounds, and half the plane memory (more frames per workgroup).
+    constexpr int kPlanesPerWave = AMT_LIN_AB_LDS ? 2 : 1;
+    f2* const planes = reinterpret_cast<f2*>(lds);                 // [kLinWaves][kPlanesPerWave][kTileCap] a wave's own tile: {s, bg} (and the logo's {a, b*maxv})
+    float* const wacc = lds + kLinWaves * kPlanesPerWave * kTileCap * 2;   // [kLinWaves][G][48 lanes][4] a wave's running sums (kLinAccFrameBytes per frame)
 
     const int G = A.G;
     const int logo = blockIdx.x / A.ngroups;
@@ -155,10 +162,10 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     if (lane < 16) myfades[lane] = A.fades[A.fade0 + min(lane, nfades - 1)];
     const unsigned myfades_base = __builtin_amdgcn_readfirstlane(lds_address(myfades));
 
-    f2* const myplane = planes + wave * 2 * kTileCap;
+    f2* const myplane = planes + wave * kPlanesPerWave * kTileCap;
     const unsigned plane_base = lds_address(myplane);
-    TileStager<pix_t, true, true> st;
-    st.init(Lp, A.pitch, A.maxv, myplane, myplane + kTileCap);
+    TileStager<pix_t, AMT_LIN_AB_LDS != 0, true> st;
+    st.init(Lp, A.pitch, A.maxv, myplane, AMT_LIN_AB_LDS ? myplane + kTileCap : nullptr);
     TilePixel px;
     TileDesc T;
 
@@ -222,6 +229,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
                     float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;   // (LogoScan.hpp:305-308)
                     t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
                     t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+                    asm volatile("" : "+v"(t));       // (left alone the add sinks into the lane-0 branch below and its DPP operand stays a v_mov_b32_dpp)
                     term[r] = t;
                 } else term[r] = 0.0f;
             }
@@ -235,10 +243,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     while (i0 < ntl) {
         AMT_LTICK(0);
         // ---- A. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
-        // The taps are loop-invariant, so LICM would hoist their {k,k} broadcasts out of the loop and keep 50 registers of
-        // copies; an empty asm makes them opaque per iteration and the broadcast folds into the multiply's op_sel instead.
-#pragma unroll
-        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(px.Kp[j]));
+        // (the taps' {k, k} broadcasts live in the multiply-adds' op_sel: eval_tile_stage.h pk_fma_tap)
         f2 R, M;
         {
             unsigned wrow[5];
@@ -361,11 +366,15 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     }
 }
 
-// 8-bit samples: three waves per SIMD (<= 168 registers); 16-bit containers carry twice the raw samples in flight and get two
-// (a spilled register would be reloaded with a wait for EVERY load in flight -- the pipeline's whole point)
+// Three waves per SIMD (<= 168 registers) for both sample sizes: since the taps' broadcasts moved into the multiply-adds (round 5) the
+// 8-bit kernel needs 132 registers and the 16-bit one, whose raw samples in flight take twice the room, 140 (it had 180 and two waves).
+// (A spilled register would be reloaded with a wait for EVERY load in flight -- the pipeline's whole point.)
 __global__ __launch_bounds__(kLinWgThreads) AMT_LIN_OCC_ATTR
 void logo_eval_linear_kernel(const LinLaunch A) { logo_eval_linear_body<uint8_t, 11>(A); }
-__global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef AMT_LIN_OCC16
+#define AMT_LIN_OCC16 3
+#endif
+__global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC16, AMT_LIN_OCC16)))
 void logo_eval_linear_kernel16(const LinLaunch A) { logo_eval_linear_body<uint16_t, 11>(A); }
 
 hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
@@ -383,7 +392,8 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     A.nfades = nfades; A.fade0 = fade0;
     A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
     A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs; A.bin_eps = bin_eps; A.qlog2 = qlog2;
-    const size_t lds = (size_t)kLinWaves * 2 * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * 16 * sizeof(float);
+    const size_t lds = (size_t)kLinWaves * (AMT_LIN_AB_LDS ? 2 : 1) * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * 16 * sizeof(float);
+    if (lds * AMT_LIN_OCC > 160 * 1024) return hipErrorInvalidValue;      // (three workgroups share a CU's LDS)
     dim3 grid((unsigned)((long long)A.ngroups * nlogos));
     if (bits <= 8) hipLaunchKernelGGL(logo_eval_linear_kernel, grid, dim3(kLinWgThreads), lds, st, A);
     else hipLaunchKernelGGL(logo_eval_linear_kernel16, grid, dim3(kLinWgThreads), lds, st, A);

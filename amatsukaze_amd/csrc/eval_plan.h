@@ -36,15 +36,15 @@ struct EvalLogoDev {
 
 constexpr int kLinMaxFades = 12;    // fades the linear kernel's source is written for (11 for AMTAnalyzeLogo, the instantiated case)
 #ifndef AMT_LIN_G
-#define AMT_LIN_G 6
+#define AMT_LIN_G 8
 #endif
-constexpr int kLinMaxFrames = AMT_LIN_G;     // frames per workgroup of the linear kernel: bounded by the LDS its running sums take (three workgroups share a CU)
+constexpr int kLinMaxFrames = AMT_LIN_G;     // frames per workgroup of the linear kernel: bounded by the LDS its running sums take (three workgroups share a CU: 16 KB of tile planes + 3 KB per frame each; 6 frames while a second plane held the coefficients.  Round 5, 10 000 frames: 6 -> 2.977 ms, 7 -> 2.963, 8 -> 2.940, 10 -> 2.944)
 #ifndef AMT_LIN_G16
 #define AMT_LIN_G16 8
 #endif
-constexpr int kLinMaxFrames16 = AMT_LIN_G16; // ... of its 16-bit instantiation, which runs two workgroups per CU (180 VGPRs) and has the LDS for more
+constexpr int kLinMaxFrames16 = AMT_LIN_G16; // ... of its 16-bit instantiation: three workgroups per CU as well since round 5 (140 VGPRs; it had 180, two workgroups and 8 frames)
 #ifndef AMT_LIN_WGS_MIN16
-#define AMT_LIN_WGS_MIN16 1024      /* (measured, 4 096-frame launches at 10 bits: 6 frames 1.749 ms, 8 frames 1.689, 10-12 frames 1.82) */
+#define AMT_LIN_WGS_MIN16 2048      /* (round 5, three workgroups per CU: 4 112-frame launches at 10 bits 6 frames 1.542 ms, 5: 1.568, 4: 1.615; 2 500-frame launches 6: 1.022, 4: 0.972 -- enough workgroups for ~3 rounds first) */
 #endif
 
 // a band = up to kEvalThreads consecutive run slots (one per thread) and the logo rows their windows touch

@@ -91,16 +91,65 @@ template <int OUTSTANDING> __device__ __forceinline__ void row_ready1(f2 (&r)[5]
 {
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(OUTSTANDING) : "memory");
 }
+// acc + {k, k} * w with k = the low (tap 2j) or the high (tap 2j + 1) half of a tap pair, the broadcast done by the instruction's op_sel.
+// Written as instructions: as IR the broadcast is a shufflevector of a loop-carried value that the optimiser moves to where the pair is
+// defined (50 registers of {k, k} copies instead of 13 pairs); the old remedy -- an empty asm that redefines the pairs every iteration --
+// cost 26 v_mov_b64 per iteration (the register allocator kept the redefined pairs apart from the loop-carried ones).
+__device__ __forceinline__ f2 pk_fma_tap(int hi, bool first, f2 kp, f2 w, f2 acc)
+{
+    f2 r;
+    if (first) {
+        if (hi) asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(kp), "v"(w));
+        else asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(kp), "v"(w));
+    } else {
+        if (hi) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(r) : "v"(kp), "v"(w), "v"(acc));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(kp), "v"(w), "v"(acc));
+    }
+    return r;
+}
+#ifndef AMT_LIN_WINDOW_ONE_TRIP
+#define AMT_LIN_WINDOW_ONE_TRIP 1
+#endif
+// The same evaluation with all 25 window reads issued at once (one LDS round trip; 50 registers of window instead of 30 -- the linear
+// kernel has them since its taps' broadcasts moved into the multiply-adds).  Same operations in the same order: identical results.
+__device__ __forceinline__ void window_eval_one_trip(const unsigned (&wrow)[5], const f2 (&Kp)[13], f2& M, f2& R)
+{
+    f2 W[25];
+    window_reads(wrow, W);
+    f2 acc0 = {0.0f, 0.0f}, acc1 = acc0, c[5];
+    auto mac = [&](int e) {
+        if (e & 1) acc1 = pk_fma_tap(1, e == 1, Kp[e >> 1], W[e], acc1);
+        else acc0 = pk_fma_tap(0, e == 0, Kp[e >> 1], W[e], acc0);
+    };
+    window_rows_ready<15, 0, 2>(W);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = W[i] + W[5 + i];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) mac(e);
+    window_rows_ready<5, 2, 2>(W);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = c[i] + (W[10 + i] + W[15 + i]);
+#pragma unroll
+    for (int e = 10; e < 20; ++e) mac(e);
+    window_rows_ready<0, 4, 1>(W);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = c[i] + W[20 + i];
+#pragma unroll
+    for (int e = 20; e < 25; ++e) mac(e);
+    M = div25_pk(((c[0] + c[4]) + c[2]) + (c[1] + c[3]));
+    const f2 sum = acc0 + acc1;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(R) : "v"(Kp[12]), "v"(M), "v"(sum));
+}
 __device__ __forceinline__ void window_eval_streamed(const unsigned (&wrow)[5], const f2 (&Kp)[13], f2& M, f2& R)
 {
+    if (AMT_LIN_WINDOW_ONE_TRIP) { window_eval_one_trip(wrow, Kp, M, R); return; }
     f2 ra[10], rb[10], r4[5];
     window_rows_issue2(wrow[0], wrow[1], ra);
     window_row_issue1(wrow[4], r4);
     f2 acc0 = {0.0f, 0.0f}, acc1 = acc0, c[5];
-    auto tap = [&](int e) { return (e & 1) ? bc_hi(Kp[e >> 1]) : bc_lo(Kp[e >> 1]); };
     auto mac = [&](int e, f2 wv) {
-        if (e & 1) acc1 = __builtin_elementwise_fma(tap(e), wv, acc1);
-        else acc0 = __builtin_elementwise_fma(tap(e), wv, acc0);
+        if (e & 1) acc1 = pk_fma_tap(1, e == 1, Kp[e >> 1], wv, acc1);
+        else acc0 = pk_fma_tap(0, e == 0, Kp[e >> 1], wv, acc0);
     };
     rows_ready2<5>(ra);
 #pragma unroll
@@ -119,7 +168,10 @@ __device__ __forceinline__ void window_eval_streamed(const unsigned (&wrow)[5], 
 #pragma unroll
     for (int e = 0; e < 5; ++e) mac(20 + e, r4[e]);
     M = div25_pk(((c[0] + c[4]) + c[2]) + (c[1] + c[3]));
-    R = __builtin_elementwise_fma(-bc_hi(Kp[12]), M, acc0 + acc1);
+    {   // R = acc0 + acc1 - {sum k, sum k} * M   (sum k = the high half of the last pair)
+        const f2 sum = acc0 + acc1;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(R) : "v"(Kp[12]), "v"(M), "v"(sum));
+    }
 }
 
 // Four adjacent samples of a source row as they come out of memory, and the unit's four s values: the sample itself, or DeintY's

@@ -48,6 +48,9 @@ constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
 #ifndef AMT_STATS_LEAN
 #define AMT_STATS_LEAN 1
 #endif
+#ifndef AMT_STATS_PINGPONG
+#define AMT_STATS_PINGPONG 1
+#endif
 #ifndef AMT_STATS_DEAL
 #define AMT_STATS_DEAL 0       /* 0: (tile, column) pairs dealt densely over the threads; 1: wave-segment dealing (see the kernel) */
 #endif
@@ -322,14 +325,27 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         if (++n >= n1) break;
     }
 #else
-    Chunk prev[R], cur[R];
-    load_rows(before, prev);
-    unsigned ve = vert_even(prev);
-    for (int n = n0; n < n1; ++n) {
-        load_rows(Y + (long long)n * frame_stride, cur);
-        ve = compute(cur, prev, n, ve);
+    // two row sets that swap roles every frame (the loop body holds two frames): copying cur -> prev was 4 R register moves per frame,
+    // 7 % of the kernel's vector instructions
+    Chunk A[R], B[R];
+    load_rows(before, A);
+    unsigned ve = vert_even(A);
+    // (ragged rows keep the copying form: with the byte masks the doubled body needs more than 256 registers at 8 bits)
+    if constexpr (AMT_STATS_PINGPONG && !RAGGED) {
+        for (int n = n0; n < n1; n += 2) {
+            load_rows(Y + (long long)n * frame_stride, B);
+            ve = compute(B, A, n, ve);
+            if (n + 1 >= n1) break;
+            load_rows(Y + (long long)(n + 1) * frame_stride, A);
+            ve = compute(A, B, n + 1, ve);
+        }
+    } else {
+        for (int n = n0; n < n1; ++n) {
+            load_rows(Y + (long long)n * frame_stride, B);
+            ve = compute(B, A, n, ve);
 #pragma unroll
-        for (int r = 0; r < R; ++r) prev[r] = cur[r];
+            for (int r = 0; r < R; ++r) A[r] = B[r];
+        }
     }
 #endif
 }

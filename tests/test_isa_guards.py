@@ -24,7 +24,7 @@ CACHE = os.path.join("/tmp", "amt_isa_cache")
 
 # file -> (extra flags, {kernel-name substring: max VGPRs})   budgets: 512 VGPRs per SIMD lane / waves per SIMD, rounded to the allocation granule of 8
 FILES = {
-    "eval_linear_kernels.hip": ([], {"logo_eval_linear_kernel16": 256, "logo_eval_linear_kernel": 168}),
+    "eval_linear_kernels.hip": (["-fno-slp-vectorize"], {"logo_eval_linear_kernel16": 168, "logo_eval_linear_kernel": 168}),
     "eval_pair_kernels.hip": ([], {"logo_eval_pair_kernel": 168}),
     "eval_fused_kernels.hip": (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], {"logo_eval_fused_kernel": 256}),
     "stats_kernels.hip": ([], {"frame_stats_kernel": 256}),
