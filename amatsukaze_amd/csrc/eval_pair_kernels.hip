@@ -76,6 +76,9 @@ struct PairLaunch {
     int out_frame_stride, take_abs;
 };
 
+#ifndef AMT_PAIR_EARLY_READS
+#define AMT_PAIR_EARLY_READS 0      /* measured round 5: 2.630 ms either way */
+#endif
 #ifdef AMT_PAIR_OCC
 #define AMT_PAIR_OCC_ATTR __attribute__((amdgpu_waves_per_eu(AMT_PAIR_OCC, AMT_PAIR_OCC)))
 #else
@@ -189,6 +192,14 @@ void logo_eval_pair_kernel(const PairLaunch A)
         st.convert();
 #endif
         AMT_PTICK(0);
+#if AMT_PAIR_EARLY_READS
+        // (the window reads are issued right behind the plane's stores -- a wave's LDS operations complete in order -- so that the next
+        //  iteration's requests below are issued under their latency)
+        f2 W[25];
+        unsigned wrow[5];
+        px.rows(wrow);
+        window_reads(wrow, W);
+#endif
         // ---- 2. the next iteration's raw samples travel during the evaluation (past the last iteration: a repeat nobody reads) ----
         if (band_end && b + 1 < nbands) {
             fetch_tile(T, tiles + (b + 1) * kTileWaves);
@@ -205,14 +216,20 @@ void logo_eval_pair_kernel(const PairLaunch A)
         //  makes them opaque per iteration and the broadcast folds into the multiply's op_sel)
 #pragma unroll
         for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(px.Kp[j]));
+#if !AMT_PAIR_EARLY_READS
         f2 W[25];
         unsigned wrow[5];
         px.rows(wrow);
+#endif
 #ifdef AMT_PAIR_NO_EVAL
         const f2 M = px.Kp[1] + f2{100.0f, 120.0f}, R = px.Kp[0];
         (void)W;
 #else
+#if AMT_PAIR_EARLY_READS
+        const f2 M = window_means_as_rows_land(W);
+#else
         const f2 M = window_load_means(wrow, W);
+#endif
         const f2 R = window_corr_exact(px.Kp, W, M);
 #endif
 #ifdef AMT_PAIR_TIMING

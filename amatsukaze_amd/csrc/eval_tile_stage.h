@@ -48,9 +48,15 @@ __device__ __forceinline__ void window_rows_ready(f2 (&W)[25])
 }
 // window reads + {mean(s), mean(bg)} in the reference's order: the column sums ((r0+r1)+(r2+r3))+r4 (ComputeKernel.cpp:88-94) start
 // as the rows arrive, then hsum256_ps' order and /25 (ComputeKernel.cpp:54-74,98)
+__device__ __forceinline__ f2 window_means_as_rows_land(f2 (&W)[25]);
 __device__ __forceinline__ f2 window_load_means(const unsigned (&wrow)[5], f2 (&W)[25])
 {
     window_reads(wrow, W);
+    return window_means_as_rows_land(W);
+}
+// ... the second half on its own, for callers that issue window_reads() earlier (and nothing but vector-memory requests in between)
+__device__ __forceinline__ f2 window_means_as_rows_land(f2 (&W)[25])
+{
     f2 c01[5], c[5];
     window_rows_ready<15, 0, 2>(W);
 #pragma unroll
