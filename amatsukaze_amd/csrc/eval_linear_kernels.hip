@@ -330,7 +330,9 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             advance(i2, g2);
             if (i2 < ntl) {
                 if (i2 != iu) { fetch_tile(T, tiles + tlist[i2]); st.setup_units(T, lane); iu = i2; }
-#ifndef AMT_LIN_NO_RAW                                           // (ablation: the samples of the first two requests are converted over and over)
+#if defined(AMT_LIN_RAW_SAMEFRAME)                              // (ablation: every request hits the cache -- what the raw loads' LATENCY costs)
+                st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, 0));
+#elif !defined(AMT_LIN_NO_RAW)                                    // (ablation: the samples of the first two requests are converted over and over)
                 st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + g2));
 #endif
             }

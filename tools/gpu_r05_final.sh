@@ -10,3 +10,5 @@ cp gpurun_out/profb_r05/r05_pmc_traffic.json profiles/r05_pmc_traffic.json 2>/de
 timeout 1200 python bench.py > gpurun_out/r5_bench.json 2> gpurun_out/r5_bench.err; echo "bench rc=$?"; tail -n 1 gpurun_out/r5_bench.json | head -c 1500; echo
 cp bench_detail.json gpurun_out/r5_bench_detail.json
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5_bench_driver.json 2> gpurun_out/r5_bench_driver.err; echo "driver-style bench rc=$?"; wc -c gpurun_out/r5_bench_driver.json
+timeout 600 python tools/stress_linear.py > gpurun_out/r5_stress_linear.txt 2>&1; tail -2 gpurun_out/r5_stress_linear.txt
+timeout 900 bash tools/gpu_prof_bench16.sh r05 > gpurun_out/r5_prof16.log 2>&1; echo "prof16 rc=$?"
