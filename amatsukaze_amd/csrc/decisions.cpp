@@ -6,7 +6,6 @@
 #include <cstdio>
 #include <limits>
 #include <stdexcept>
-#include <thread>
 
 #include "host_parallel.hpp"
 
@@ -36,10 +35,8 @@ LogoSelection select_logo(const float* evals, int numFrames, int numLogos, int n
         scoreOf[i] = hits == 0 ? std::numeric_limits<float>::infinity() : (residue / hits) * (numFrames / (float)hits);
     };
     if (numCandidates > 1 && parallel_parts(numFrames) > 1) {
-        std::vector<std::thread> th;
-        for (int i = 1; i < numCandidates; ++i) th.emplace_back(one, i);
-        one(0);
-        for (auto& t : th) t.join();
+        // (candidates as "ranges" of one: parallel_ranges joins its threads and forwards exceptions)
+        parallel_ranges(numCandidates, numCandidates, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) one(i); });
     } else {
         for (int i = 0; i < numCandidates; ++i) one(i);
     }

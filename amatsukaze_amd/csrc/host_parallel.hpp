@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -37,9 +38,18 @@ template <class F> void parallel_ranges(int n, int parts, F&& fn)
     std::vector<std::thread> th;
     th.reserve(parts - 1);
     auto bound = [&](int p) { return (int)((long long)n * p / parts); };
-    for (int p = 1; p < parts; ++p) th.emplace_back([&, p] { fn(bound(p), bound(p + 1), p); });
-    fn(0, bound(1), 0);
+    // an exception on a worker (an allocation, say) travels to the caller: the first one is rethrown once every thread has been joined
+    std::vector<std::exception_ptr> err(parts);
+    auto guarded = [&](int p) { try { fn(bound(p), bound(p + 1), p); } catch (...) { err[p] = std::current_exception(); } };
+    int started = 1;
+    try {
+        for (int p = 1; p < parts; ++p, ++started) th.emplace_back(guarded, p);
+    } catch (...) {                                   // (no more threads to be had: the caller takes the remaining ranges itself)
+        for (int p = started; p < parts; ++p) guarded(p);
+    }
+    guarded(0);
     for (auto& t : th) t.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 } // namespace amt
