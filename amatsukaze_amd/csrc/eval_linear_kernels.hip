@@ -32,6 +32,9 @@ namespace amt {
 using namespace lin;
 using namespace tile;
 
+#ifndef AMT_LIN_FLUSH_FIRST
+#define AMT_LIN_FLUSH_FIRST 1
+#endif
 #ifndef AMT_LIN_AB_LDS
 #define AMT_LIN_AB_LDS 0
 #endif
@@ -94,7 +97,7 @@ struct LinLaunch {
 };
 
 #ifndef AMT_LIN_OCC
-#define AMT_LIN_OCC 3
+#define AMT_LIN_OCC 4
 #endif
 #define AMT_LIN_OCC_ATTR __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC, AMT_LIN_OCC)))
 // NF fades (11 for AMTAnalyzeLogo, the only caller of this mode: no per-fade branches; NF == 0 would take nfades <= kLinMaxFades
@@ -242,6 +245,13 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     };
     while (i0 < ntl) {
         AMT_LTICK(0);
+#if AMT_LIN_FLUSH_FIRST && !defined(AMT_LIN_NO_FLUSH)
+        // The previous iteration's terms leave their 22 registers BEFORE the window evaluation, the loop's register peak: 148 -> 126 VGPRs,
+        // i.e. FOUR waves per SIMD (the kernel waits more than it issues: ~40 % of the issue slots and of the LDS cycles used at three).
+        // The price -- less time for the scale gathers to arrive: at three waves 4.97 ms against 4.73 per 16 448 frames -- is more than
+        // paid back by the fourth wave: 4.58 (profiles/r05_notes.md section 9).
+        flush_terms();
+#endif
         // ---- A. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
         // (the taps' {k, k} broadcasts live in the multiply-adds' op_sel: eval_tile_stage.h pk_fma_tap)
         f2 R, M;
@@ -256,7 +266,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         }
         AMT_LTICK(2);
         // ---- D. the previous iteration's terms (their scales arrived long ago) leave their registers to this iteration's gathers ----
-#ifndef AMT_LIN_NO_FLUSH
+#if !defined(AMT_LIN_NO_FLUSH) && !AMT_LIN_FLUSH_FIRST
         flush_terms();
 #endif
         AMT_LTICK(4);
@@ -368,13 +378,13 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     }
 }
 
-// Three waves per SIMD (<= 168 registers) for both sample sizes: since the taps' broadcasts moved into the multiply-adds (round 5) the
-// 8-bit kernel needs 132 registers and the 16-bit one, whose raw samples in flight take twice the room, 140 (it had 180 and two waves).
-// (A spilled register would be reloaded with a wait for EVERY load in flight -- the pipeline's whole point.)
+// Four waves per SIMD (<= 128 registers) for both sample sizes: 126 registers at 8 bits; the 16-bit kernel, whose raw samples in flight take
+// twice the room, parks ONE value in scratch before the loop and fetches it back after it (tests/test_isa_guards.py: nothing inside).
+// (Inside the loop a spilled register would be reloaded with a wait for EVERY load in flight -- the pipeline's whole point.)
 __global__ __launch_bounds__(kLinWgThreads) AMT_LIN_OCC_ATTR
 void logo_eval_linear_kernel(const LinLaunch A) { logo_eval_linear_body<uint8_t, 11>(A); }
 #ifndef AMT_LIN_OCC16
-#define AMT_LIN_OCC16 3
+#define AMT_LIN_OCC16 4
 #endif
 __global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC16, AMT_LIN_OCC16)))
 void logo_eval_linear_kernel16(const LinLaunch A) { logo_eval_linear_body<uint16_t, 11>(A); }
@@ -395,7 +405,7 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
     A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs; A.bin_eps = bin_eps; A.qlog2 = qlog2;
     const size_t lds = (size_t)kLinWaves * (AMT_LIN_AB_LDS ? 2 : 1) * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * 16 * sizeof(float);
-    if (lds * AMT_LIN_OCC > 160 * 1024) return hipErrorInvalidValue;      // (three workgroups share a CU's LDS)
+    if (lds * AMT_LIN_OCC > 160 * 1024) return hipErrorInvalidValue;      // (the workgroups that share a CU must fit its LDS)
     dim3 grid((unsigned)((long long)A.ngroups * nlogos));
     if (bits <= 8) hipLaunchKernelGGL(logo_eval_linear_kernel, grid, dim3(kLinWgThreads), lds, st, A);
     else hipLaunchKernelGGL(logo_eval_linear_kernel16, grid, dim3(kLinWgThreads), lds, st, A);

@@ -36,11 +36,11 @@ struct EvalLogoDev {
 
 constexpr int kLinMaxFades = 12;    // fades the linear kernel's source is written for (11 for AMTAnalyzeLogo, the instantiated case)
 #ifndef AMT_LIN_G
-#define AMT_LIN_G 8
+#define AMT_LIN_G 7
 #endif
-constexpr int kLinMaxFrames = AMT_LIN_G;     // frames per workgroup of the linear kernel: bounded by the LDS its running sums take (three workgroups share a CU: 16 KB of tile planes + 3 KB per frame each; 6 frames while a second plane held the coefficients.  Round 5, 10 000 frames: 6 -> 2.977 ms, 7 -> 2.963, 8 -> 2.940, 10 -> 2.944)
+constexpr int kLinMaxFrames = AMT_LIN_G;     // frames per workgroup of the linear kernel: bounded by the LDS its running sums take (FOUR workgroups share a CU's 160 KB: 16 KB of tile planes + 3 KB per frame each -> 7 frames; with three workgroups: 6 -> 2.977 ms per 10 000 frames, 7 -> 2.963, 8 -> 2.940, 10 -> 2.944)
 #ifndef AMT_LIN_G16
-#define AMT_LIN_G16 8
+#define AMT_LIN_G16 7
 #endif
 constexpr int kLinMaxFrames16 = AMT_LIN_G16; // ... of its 16-bit instantiation: three workgroups per CU as well since round 5 (140 VGPRs; it had 180, two workgroups and 8 frames)
 #ifndef AMT_LIN_WGS_MIN16

@@ -24,7 +24,7 @@ CACHE = os.path.join("/tmp", "amt_isa_cache")
 
 # file -> (extra flags, {kernel-name substring: max VGPRs})   budgets: 512 VGPRs per SIMD lane / waves per SIMD, rounded to the allocation granule of 8
 FILES = {
-    "eval_linear_kernels.hip": (["-fno-slp-vectorize"], {"logo_eval_linear_kernel16": 168, "logo_eval_linear_kernel": 168}),
+    "eval_linear_kernels.hip": (["-fno-slp-vectorize"], {"logo_eval_linear_kernel16": 128, "logo_eval_linear_kernel": 128}),
     "eval_pair_kernels.hip": ([], {"logo_eval_pair_kernel": 168}),
     "eval_fused_kernels.hip": (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], {"logo_eval_fused_kernel": 256}),
     "stats_kernels.hip": ([], {"frame_stats_kernel": 256}),
@@ -138,6 +138,23 @@ def partial_waits_with_smem_outstanding(body):
     return hits, len(blocks)
 
 
+def scratch_inside_loops(body):
+    """scratch instructions between a label and a later branch back to it"""
+    lines = [l.strip() for l in body]
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    hits = []
+    for i, l in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            hits += [x for x in lines[labels[m.group(1)]:i] if "scratch_" in x]
+    return hits
+
+
+def test_scratch_loop_scan_sees_a_planted_reload():
+    assert scratch_inside_loops([".LBB0_1:", "scratch_load_dword v1, off, off", "s_cbranch_scc1 .LBB0_1"])
+    assert not scratch_inside_loops(["scratch_store_dword off, v1, off", ".LBB0_1:", "v_add_f32 v0, v0, v1", "s_cbranch_scc1 .LBB0_1", "scratch_load_dword v1, off, off"])
+
+
 def test_cfg_walker_sees_a_planted_violation():
     bad = ["s_load_dword s0, s[2:3], 0x0", "ds_read_b64 v[0:1], v2", "s_waitcnt lgkmcnt(1)", "s_endpgm"]
     ok = ["s_load_dword s0, s[2:3], 0x0", "s_waitcnt lgkmcnt(0)", "ds_read_b64 v[0:1], v2", "ds_read_b64 v[2:3], v2", "s_waitcnt lgkmcnt(1)", "s_endpgm"]
@@ -155,13 +172,20 @@ def test_kernel_isa_properties(name):
     seen = set()
     for kname, k in ks.items():
         m = k["meta"]
-        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{kname}: scratch / spills {m}"
+        if "logo_eval_linear_kernel16" in kname:
+            # four waves per SIMD leave this kernel one register short: ONE value may be parked before the loops and fetched back after
+            # them -- inside a loop a reload would wait for every load in flight
+            assert m["private_segment_fixed_size"] <= 8 and m["vgpr_spill_count"] <= 1, f"{kname}: scratch / spills {m}"
+            assert not scratch_inside_loops(k["body"]), f"{kname}: scratch access inside a loop"
+        else:
+            assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{kname}: scratch / spills {m}"
         # (delogo_kernel and the staging / prologue blocks of the generic fused kernel park scalars in VGPR lanes -- v_writelane, no
         # memory, none inside the fade loop: tolerated there; the tile kernels and the frame metrics must have none)
         if name not in ("erase_scan_kernels.hip", "eval_fused_kernels.hip"):
             assert m["sgpr_spill_count"] == 0, f"{kname}: scalar spills {m}"
         assert not any(re.match(r"^\s*v_(mfma|smfmac)", l) for l in k["body"]), f"{kname}: MFMA in a kernel that must not have any"
-        assert not any("scratch_" in l for l in k["body"]), f"{kname}: scratch instructions"
+        if "logo_eval_linear_kernel16" not in kname:
+            assert not any("scratch_" in l for l in k["body"]), f"{kname}: scratch instructions"
         for sub in sorted(budgets, key=len, reverse=True):          # the longest matching name decides (kernel16 before kernel)
             if sub in kname:
                 assert m["vgpr_count"] + m["agpr_count"] <= budgets[sub], f"{kname}: {m['vgpr_count']} VGPRs (+{m['agpr_count']} AGPRs) > {budgets[sub]}"
