@@ -10,6 +10,9 @@ VARIANTS = {"r03_form": ["AMT_STATS_LEAN=0"], "lean_no_nt": ["AMT_STATS_NT=0"], 
             # taller tiles: the halo rows are 2 / ROWS of the traffic
             "rows24": ["AMT_STATS_ROWS=24"], "rows24_8B": ["AMT_STATS_ROWS=24", "AMT_STATS_COLB=8"], "rows32_8B": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8"],
             "rows32_8B_run64": ["AMT_STATS_ROWS=32", "AMT_STATS_COLB=8", "AMT_STATS_RUN=64"],
+            "w3_r16_r12": ["AMT_STATS_WAVES=3", "AMT_STATS_ROWS8=16", "AMT_STATS_ROWS=12"], "w3_r12_r12": ["AMT_STATS_WAVES=3", "AMT_STATS_ROWS8=12", "AMT_STATS_ROWS=12"],
+            "w3_r16_r8": ["AMT_STATS_WAVES=3", "AMT_STATS_ROWS8=16", "AMT_STATS_ROWS=8"], "w4_r8_r8": ["AMT_STATS_WAVES=4", "AMT_STATS_ROWS8=8", "AMT_STATS_ROWS=8"],
+            "w3_r14_r10": ["AMT_STATS_WAVES=3", "AMT_STATS_ROWS8=14", "AMT_STATS_ROWS=10"],
             "deal2": ["AMT_STATS_DEAL=2"], "deal2_rows16": ["AMT_STATS_DEAL=2", "AMT_STATS_ROWS8=16"], "deal2_rows20": ["AMT_STATS_DEAL=2", "AMT_STATS_ROWS8=20"],
             "deal1": ["AMT_STATS_DEAL=1"], "deal1_no_nt": ["AMT_STATS_DEAL=1", "AMT_STATS_NT=0"], "deal1_run64": ["AMT_STATS_DEAL=1", "AMT_STATS_RUN=64"],
             "deal1_rows16": ["AMT_STATS_DEAL=1", "AMT_STATS_ROWS8=16"], "run64": ["AMT_STATS_RUN=64"], "no_nt": ["AMT_STATS_NT=0"],
