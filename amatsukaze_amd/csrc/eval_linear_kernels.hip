@@ -229,7 +229,11 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             for (int r = 0; r < 4; ++r) {
                 const int f = 4 * q + r;
                 if (f < NFMAX) {
+#ifdef AMT_LIN_GATHER4
+                    float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * __builtin_amdgcn_rcpf(psc[f].x + 2.0f), -1.0f, 1.0f) * __builtin_fminf(1.0f, psc[f].x * 0.37f);
+#else
                     float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;   // (LogoScan.hpp:305-308)
+#endif
                     t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
                     t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
                     asm volatile("" : "+v"(t));       // (left alone the add sinks into the lane-0 branch below and its DPP operand stays a v_mov_b32_dpp)
@@ -326,6 +330,8 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #pragma unroll
 #ifdef AMT_LIN_NO_GATHER
         for (int f = 0; f < NFMAX; ++f) { asm volatile("" :: "v"(goff[f])); psc[f] = f2{1e-3f, 1.0f}; }
+#elif defined(AMT_LIN_GATHER4)                                 // (ablation, wrong results: what 4-byte gathers from a table half the size would cost)
+        for (int f = 0; f < NFMAX; ++f) { const float c = gld<float>(gSc, goff[f] >> 1); psc[f] = f2{c, c}; }
 #else
         for (int f = 0; f < NFMAX; ++f) psc[f] = gld<f2>(gSc, goff[f]);
 #endif

@@ -11,7 +11,7 @@ DEFS = {"lin16_g8_occ2": ["AMT_LIN_G16=8", "AMT_LIN_OCC16=2"], "lin16_g8_occ3": 
         "stats_copying": ["AMT_STATS_PINGPONG=0"], "lin16_g5": ["AMT_LIN_G16=5"], "lin_prev_occ3_g8": ["AMT_LIN_FLUSH_FIRST=0", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3", "AMT_LIN_G=8", "AMT_LIN_G16=8"], "lin_ff_occ3": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"], "lin_ff_occ4_g7": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=7"],
         "lin_ff_occ4_g6": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=6"],
         "lin_ff_occ4_g7_16too": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=7", "AMT_LIN_OCC16=4", "AMT_LIN_G16=7"],
-        "pair_early_reads": ["AMT_PAIR_EARLY_READS=1"], "abl_lin_raw_sameframe": ["AMT_LIN_RAW_SAMEFRAME"], "abl_lin_no_gather": ["AMT_LIN_NO_GATHER"],
+        "pair_early_reads": ["AMT_PAIR_EARLY_READS=1"], "abl_lin_raw_sameframe": ["AMT_LIN_RAW_SAMEFRAME"], "abl_lin_no_gather": ["AMT_LIN_NO_GATHER"], "abl_lin_gather4": ["AMT_LIN_GATHER4"],
         "abl_lin_no_flush": ["AMT_LIN_NO_FLUSH"], "abl_lin_no_fixup": ["AMT_LIN_NO_FIXUP"], "lin_two_trips": ["AMT_LIN_WINDOW_ONE_TRIP=0"], "lin_ab_lds": ["AMT_LIN_AB_LDS=1"], "lin_g8": ["AMT_LIN_G=8", "AMT_LIN_G16=8"],
         "lin_g10": ["AMT_LIN_G=10", "AMT_LIN_G16=10"], "lin_g7": ["AMT_LIN_G=7", "AMT_LIN_G16=7"], "lin_g5": ["AMT_LIN_G=5"], "lin_g4": ["AMT_LIN_G=4"]}
 for k in DEFS:
