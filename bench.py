@@ -533,6 +533,14 @@ def main():
                     "config": {"workload": r["workload"], "frames_total": r["frames_total"], "logo": f"{LW}x{LH}@(1600,64)", "maskratio": MASKRATIO,
                                "analysis_mode": args.analysis_mode, "parallelism": f"frames sharded x{world}"},
                     "collectives": rccl, "e2e10": r}
+            # the dominant 16-bit kernel of rank 0's chunk loop (HIP events on the launch stream; traffic from the committed PMC passes)
+            r16 = r.get("roofline16") or {}
+            if r16:
+                dom = max(r16, key=lambda k: r16[k]["total_ms"])
+                k = r16[dom]
+                line["roofline"] = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
+                                    "traffic": k["traffic_bytes_per_frame"], "traffic_source": k["traffic_source"], "avg_launch_ms": k["total_ms"] / max(1, k["launches"]),
+                                    "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_frame"] * r["frames_per_gpu"] / max(1, k["launches"])}
             emit(line)
         if world > 1:
             dist.barrier()
