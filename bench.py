@@ -539,7 +539,7 @@ def main():
                 dom = max(r16, key=lambda k: r16[k]["total_ms"])
                 k = r16[dom]
                 line["roofline"] = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
-                                    "traffic": k["traffic_bytes_per_frame"], "traffic_source": k["traffic_source"], "avg_launch_ms": k["total_ms"] / max(1, k["launches"]),
+                                    "traffic": (k["traffic_bytes_per_frame"] * r["frames_per_gpu"] / max(1, k["launches"])) if k["traffic_bytes_per_frame"] else None, "traffic_source": k["traffic_source"], "avg_launch_ms": k["total_ms"] / max(1, k["launches"]),
                                     "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_frame"] * r["frames_per_gpu"] / max(1, k["launches"])}
             emit(line)
         if world > 1:
