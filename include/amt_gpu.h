@@ -27,10 +27,12 @@
 extern "C" {
 #endif
 
-#define AMTGPU_ABI_VERSION 3      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers
+#define AMTGPU_ABI_VERSION 4      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers
                                    * 3: additions only -- device-side CalcFade (amtgpu_erase_calc_fades_device, *_dfades), sharded frame
                                    *    metrics (amtgpu_framestats_allgather / _sharded), registered host frames (amtgpu_frames_register),
-                                   *    amtgpu_download_scatter, owned markers */
+                                   *    amtgpu_download_scatter, owned markers
+                                   * 4: amtgpu_logoframe_decide_host returns -1 (was 0) when the text buffer is too small and refuses
+                                   *    num_candidates > num_logos; additions: amtgpu_logoframe_dump_result, amtgpu_host_set_parallelism */
 #define AMTGPU_NUM_FADE 11            /* LogoAnalyzeFrame p/t/b[11]  (LogoScan.hpp:1100-1103) */
 #define AMTGPU_ANALYZE_FLOATS 33      /* floats per source frame in an analysis record */
 

@@ -33,7 +33,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(binding.SIGNATURES), declared ^ set(binding.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.amtgpu_abi_version() == 3
+    assert lib.amtgpu_abi_version() == 4
 
 
 def test_hip_runtime_count_is_reported(lib):
