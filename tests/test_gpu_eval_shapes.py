@@ -304,3 +304,34 @@ def test_linear_mode_under_adversarial_coefficients(gpu, bits, maskratio):
     guarded = AMTAnalyzeLogo(gpu["ctx"], logo, maskratio, mode="linear").analyze(dclip)
     er = AMTEraseLogo(gpu["ctx"], logo, "", 0, 16)
     assert er.calc_fades(guarded, N).tobytes() == er.calc_fades(exact, N).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 10])
+def test_linear_mode_at_its_largest_frame_group(gpu, bits):
+    """Enough frames that the linear kernel's workgroups take their maximum of 7 frames (frames x 3 logos / 2048 >= 7) with a short last
+    group (5003 = 714 x 7 + 5): the guarded mode against the exact GPU kernel -- records within 1e-4 and inside the kernel's own bound,
+    identical CalcFade output for every frame -- at both sample sizes (four waves per SIMD each since round 5; the 16-bit kernel parks a
+    register outside its loops)."""
+    import torch
+    import amt_synth as S
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Logo
+    W, H, LW, LH, X, Y0, N = 352, 240, 96, 48, 224, 18, 5003
+    data, alpha, alphaUV = S.make_logo(LW, LH)
+    clip = S.make_clip_torch(N, W, H, 0x5EED0019, alpha, alphaUV, X, Y0, gpu["dev"], period=61, fade=7, chroma=False, bits=bits)
+    Yd = clip["Y"]
+    ctx = gpu["ctx"]
+    logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
+    exact = torch.empty((N, 33), dtype=torch.float32, device=gpu["dev"])
+    lin = torch.empty_like(exact)
+    AMTAnalyzeLogo(ctx, logo, 0.35).analyze_device(Yd, bits, exact)
+    an = AMTAnalyzeLogo(ctx, logo, 0.35, mode="linear")
+    an.analyze_device(Yd, bits, lin)
+    torch.cuda.synchronize()
+    e, l = exact.cpu().numpy(), lin.cpu().numpy()
+    err = np.abs(e - l).reshape(N, 3, 11).max(axis=(0, 2))
+    assert err.max() <= 1e-4, err
+    assert all(err[k] <= an.error_bound(k, bits) for k in range(3)), (err, [an.error_bound(k, bits) for k in range(3)])
+    assert an.last_refined() <= N // 20
+    er = AMTEraseLogo(ctx, logo, "", 0, 16)
+    assert er.calc_fades(e, N).tobytes() == er.calc_fades(l, N).tobytes()

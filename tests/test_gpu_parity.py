@@ -92,6 +92,10 @@ def test_logoframe_scan_bit_exact(gpu, tmp_path, cfgname, bits, pad):
     from amatsukaze_amd.api import logoframe_decide_host
     hbest, hratio, htext = logoframe_decide_host(got, 30000, 1001, numCandidates=2)
     assert hbest == best.value and np.float32(hratio).tobytes() == np.float32(ratio.value).tobytes() and htext == buf.raw[:ln]
+    # LogoFrame::dumpResult (LogoScan.hpp:1632-1643): "<base><logo>", one "%f,%f" line {corr0, corr1} per frame
+    lf.dumpResult(tmp_path / "dump_")
+    for i in range(3):
+        assert (tmp_path / f"dump_{i}").read_text() == "".join("%f,%f\n" % (float(a), float(b)) for a, b in got[:, i])
 
 
 def test_logoframe_scan_kernel_choice(gpu):
