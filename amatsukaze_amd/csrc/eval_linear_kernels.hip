@@ -279,6 +279,8 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         //      of all (pixel, fade) pairs -- the mean is evaluated exactly as the reference does and ITS bin is taken ----
         const float m0q = M.x * qscale, m1q = M.y * qscale;         // (exact: powers of two)
         const float dMq = m1q - m0q;
+        const float m0qd = m0q + dqf;                               // (the window's half-width rides in the multiply-add's addend: one rounding
+                                                                    //  for the sum, one for the FMA -- the two the bound counted for FMA and add)
         unsigned emin = qmask;
         const unsigned slot8 = px.slotbase8 + (unsigned)lane * 8u;     // (not kept: one instruction instead of a register)
         unsigned goff[NFMAX];                                      // byte offset of the fade's {scale, scale2} in the slot table
@@ -288,7 +290,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #pragma unroll
         for (int f = 0; f < NFMAX; ++f) {
             const bool end = f == 0 || f == NFMAX - 1;
-            const int qd = (int)(end ? (f == 0 ? m0q : m1q) : __builtin_fmaf(fd[f], dMq, m0q) + dqf);
+            const int qd = (int)(end ? (f == 0 ? m0q : m1q) : __builtin_fmaf(fd[f], dMq, m0qd));
             if (!end) emin = min(emin, (unsigned)qd & qmask);
             goff[f] = __umul24((unsigned)clamp_bin(qd >> qshift), nslots8) + slot8;
         }
@@ -309,7 +311,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #pragma unroll 1
             for (int f = 1; f < nfades - 1; ++f) {
                 const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fadev), f));
-                const int qd = (int)(__builtin_fmaf(fade, dMq, m0q) + dqf);
+                const int qd = (int)__builtin_fmaf(fade, dMq, m0qd);
                 if (near_edge && ((unsigned)qd & qmask) <= qwin) {
                     const unsigned go = __umul24((unsigned)score_bin_dev(exact_blend_mean_2trips(wrow, fade)), nslots8) + px.slotbase8 + (unsigned)lane * 8u;
 #pragma unroll
