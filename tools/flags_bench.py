@@ -6,7 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 NOSLP = ["-fno-slp-vectorize"]
 VARIANTS = {"noslp_all": {f: NOSLP for f in ("eval_linear_kernels.hip", "eval_pair_kernels.hip", "eval_fused_kernels.hip", "stats_kernels.hip", "erase_scan_kernels.hip")},
-            "noslp_linear": {"eval_linear_kernels.hip": NOSLP}, "noslp_fused": {"eval_fused_kernels.hip": NOSLP}}
+            "noslp_linear": {"eval_linear_kernels.hip": NOSLP}, "noslp_fused": {"eval_fused_kernels.hip": NOSLP},
+            "lin_maxilp": {"eval_linear_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
+            "lin_maxmem": {"eval_linear_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]},
+            "pair_maxilp": {"eval_pair_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}}
 DEFS = {"lin16_g8_occ2": ["AMT_LIN_G16=8", "AMT_LIN_OCC16=2"], "lin16_g8_occ3": ["AMT_LIN_G16=8"], "lin16_g4": ["AMT_LIN_G16=4"],
         "stats_copying": ["AMT_STATS_PINGPONG=0"], "lin16_g5": ["AMT_LIN_G16=5"], "lin_prev_occ3_g8": ["AMT_LIN_FLUSH_FIRST=0", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3", "AMT_LIN_G=8", "AMT_LIN_G16=8"], "lin_ff_occ3": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"], "lin_ff_occ4_g7": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=7"],
         "lin_ff_occ4_g6": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=6"],
