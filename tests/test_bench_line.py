@@ -69,3 +69,16 @@ def test_emit_prints_the_compact_line_last(capsys, tmp_path, monkeypatch):
     assert len(last) < bench.LINE_LIMIT and json.loads(last)["roofline"]["kernel"] == full["roofline"]["kernel"]
     assert json.loads(cap.err.strip().splitlines()[-1])["bench_detail"]["kernels"] == full["kernels"]      # the detail goes to stderr ...
     assert json.load(open(tmp_path / bench.DETAIL_NAME))["ingest"] == full["ingest"]                      # ... and next to the script
+
+
+def test_round5_detail_compacts_to_the_committed_line():
+    """profiles/r05_bench_detail.json is what bench.py wrote next to the line profiles/r05_bench.json in the same run: the line builder must
+    reproduce the printed line from the detail, under the limit, with the full-batch verification in it"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail.json")))
+    printed = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench.json")).read().strip().splitlines()[-1])
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert line == printed
+    assert line["verified"]["ok"] is True and line["verified"]["frames"] == line["config"]["frames_per_gpu"] == 10000
+    assert line["roofline"]["bound"] in ("hbm", "fp32-valu") and 0 < line["roofline"]["frac"] < 1
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
