@@ -482,7 +482,8 @@ int amtgpu_logoframe_decide_host(const float* evals, int num_frames, int num_log
         const std::string t = li < 0 ? std::string() : logoframe_text(evals, num_frames, num_logos, li, fps_num, fps_den);
         if (text_len) *text_len = (int)t.size();
         if (!text && cap == 0) return 1;                        // a length query
-        if (!text || cap < (int)t.size()) return -1;            // buffer too small: *text_len says how much it takes
+        if (!text || cap < (int)t.size()) return 0;             // buffer too small: a failure like any other (the library's int 1/0
+                                                                // convention, `if (!call) fail;` keeps working) -- *text_len > cap tells it apart
         std::memcpy(text, t.data(), t.size());
         return 1;
     } catch (...) { return 0; }
@@ -521,12 +522,13 @@ int amtgpu_logoframe_dump_result(AmtGpuLogoFrame* lf, const char* basepath)
         logoframe_sync_results(lf);
         const int nl = (int)lf->logos.size();
         std::string sb;
-        char line[96];
+        char line[128];                                          // two "%f" of -FLT_MAX take 47 characters each: 96 in all with ",\n"
         for (int i = 0; i < nl; ++i) {
             sb.clear();
             for (int n = 0; n < lf->numFrames; ++n) {
                 const float* r = lf->results.data() + ((size_t)n * nl + i) * 2;
-                sb.append(line, (size_t)std::snprintf(line, sizeof line, "%f,%f\n", r[0], r[1]));
+                const int len = std::snprintf(line, sizeof line, "%f,%f\n", r[0], r[1]);
+                sb.append(line, (size_t)std::min<int>(std::max(len, 0), (int)sizeof line - 1));
             }
             const std::string path = std::string(basepath) + std::to_string(i);
             std::ofstream f(path, std::ios::binary);

@@ -34,9 +34,10 @@ LogoSelection select_logo(const float* evals, int numFrames, int numLogos, int n
         hitsOf[i] = hits;
         scoreOf[i] = hits == 0 ? std::numeric_limits<float>::infinity() : (residue / hits) * (numFrames / (float)hits);
     };
-    if (numCandidates > 1 && parallel_parts(numFrames) > 1) {
-        // (candidates as "ranges" of one: parallel_ranges joins its threads and forwards exceptions)
-        parallel_ranges(numCandidates, numCandidates, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) one(i); });
+    const int parts = std::min(numCandidates, parallel_parts(numFrames));   // never more threads than amtgpu_host_set_parallelism allows
+    if (parts > 1) {
+        // (ranges of candidates: parallel_ranges joins its threads and forwards exceptions)
+        parallel_ranges(numCandidates, parts, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) one(i); });
     } else {
         for (int i = 0; i < numCandidates; ++i) one(i);
     }

@@ -52,6 +52,9 @@ FLOPS_PER_RECT_PIXEL = 6               # EvaluateLogo's unblend per rectangle pi
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3               # fp32 vector peak (FMA counted as 2)
 STRONG_FRAMES = 107892                 # BASELINE configs[3]: 60 min at 29.97 fps
+SCANLOGO_MAX_FRAMES = 20000            # ScanLogo's numMaxFrames (LogoScan.hpp:885)
+SCANLOGO_FLAT_EVERY = 4                # one frame in four passes AddFrame's border test: 26 9xx of 107 892 > numMaxFrames, so the stream-order
+                                       # quota closes the stream early (round 5: one in eight, 13 486 accepted -- the quota was never reached)
 PMC_TRAFFIC = os.path.join("profiles", "r05_pmc_traffic.json")
 EVAL = "logo_eval_fused_kernel"
 
@@ -80,6 +83,9 @@ def parse_args():
                                                               "frames per rank = one GPU's share of the 4-hour stream, so N = 8 runs the whole 431 568-frame "
                                                               "stream of configs[4] (weak scaling)")
     ap.add_argument("--e2e-chunk", type=int, default=4096, help="frames generated and processed per chunk of the e2e10 stream")
+    ap.add_argument("--e2e-verify-seconds", type=float, default=300.0,
+                    help="wall-time budget per rank for holding every frame of its e2e10 share against the CPU oracle (one share of 53 946 frames takes "
+                         "about a minute of a 256-core host); chunks beyond it are left to the probe blocks and the line says so")
     ap.add_argument("--metrics-cus", type=int, default=0,
                     help="N > 0: N compute units are given to the frame metrics, which then run BESIDE the analysis + scan on the other units (two contexts "
                          "on CU-range streams, amtgpu_stream_create_cu_range).  Measured (profiles/r04_notes.md): no gain on MI355X -- the logo kernels lose "
@@ -342,7 +348,7 @@ def _pick(d, *keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
 
 
-def _short(s, n=120):
+def _short(s, n=160):
     return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
 
 
@@ -400,18 +406,22 @@ def compact_line(full):
     if e2e:
         line["e2e10"] = (_pick(e2e, "error") or
                          {**_pick(e2e, "value", "frames_total", "n_gpus", "scaling", "timed_s"), "verified_ok": g(e2e, "verified", "ok"),
-                          "verified_frames": g(e2e, "verified", "frames_compared_with_cpu_oracle"),
+                          "verified_frames": g(e2e, "verified", "frames_compared_with_cpu_oracle"), "verified_whole_stream": g(e2e, "verified", "whole_stream"),
                           "decisions_sha256": (e2e.get("decisions_sha256") or "")[:16]})
     cf = full.get("configs")
     if cf:
         line["configs"] = {n: (_pick(c, "error") or {**_pick(c, "value", "frames"), **({"verified_frames": g(c, "verified", "frames")}
-                                                                                         if g(c, "verified", "frames") else {})})
+                                                                                         if g(c, "verified", "frames") else {}),
+                                                     **({"quota_hit": g(c, "verified", "quota_hit")} if g(c, "verified", "quota_hit") is not None else {})})
                            for n, c in cf.items() if isinstance(c, dict)}
     ss = full.get("strong_scan")
     if ss:
         line["strong_scan"] = (_pick(ss, "error") or
                                {**_pick(ss, "value", "frames_total", "n_gpus", "ms_per_step"), "records_sha256": (ss.get("records_sha256") or "")[:16],
-                                "scanlogo_value": g(ss, "scanlogo", "value"), "lgd_sha256": (g(ss, "scanlogo", "lgd_sha256") or "")[:16]})
+                                "verified_frames": g(ss, "verified", "frames"), "verified_ok": g(ss, "verified", "equals_cpu_oracle"),
+                                "scanlogo_value": g(ss, "scanlogo", "value"), "lgd_sha256": (g(ss, "scanlogo", "lgd_sha256") or "")[:16],
+                                "lgd_verified_frames": g(ss, "scanlogo", "verified", "frames"), "lgd_equals_cpu_oracle": g(ss, "scanlogo", "verified", "lgd_equals_cpu_oracle"),
+                                "scanlogo_quota_hit": g(ss, "scanlogo", "verified", "quota_hit")})
     ing = full.get("ingest")
     if ing:
         line["ingest"] = _pick(ing, "error") or {"y_plane": _pick(ing.get("y_plane") or {}, "pipelined_fps", "ingest_GBs"),
@@ -519,7 +529,7 @@ def main():
         # N = 8) -- per-GPU work fixed as N grows, i.e. weak scaling; an explicit --e2e-frames fixes the total instead (strong)
         nt = args.e2e_frames or bench_e2e.SHARE_FRAMES * world
         return bench_e2e.run(E, nt=nt, chunk=args.e2e_chunk, verify=not args.no_verify, mode=args.analysis_mode,
-                             scaling="strong" if args.e2e_frames else "weak")
+                             scaling="strong" if args.e2e_frames else "weak", verify_budget_s=args.e2e_verify_seconds)
 
     if args.workload == "e2e10":
         r = e2e10()
@@ -585,26 +595,39 @@ def main():
         el = max_over_ranks(time.perf_counter() - t0)
         prof = ctx.profile_report()
         ctx.profile(False)
+        # ---- EVERY record of this rank's shard against the CPU oracle (threaded; only the logo rectangle's rows travel to the host):
+        #      LogoScan.hpp:1543-1568.  Flags and frame counts are reduced over the ranks. ----
+        vall = None
+        if not args.no_verify:
+            import bench_verify as BV
+            ol = OracleLogos(logos_np)
+            vr = BV.verify_scan_records(torch, ol, 8, f0, f1, lambda lo, hi: Yl[lo - f0:hi - f0, IMGY:IMGY + LH], lf.evalResults, IMGY,
+                                        threads=max(1, BV.host_threads() // (world if shared_gpu or world > 1 else 1)))
+            vt = torch.tensor([int(vr["records_equal_oracle"]), vr["frames"]], dtype=torch.int64, device="cpu" if shared_gpu else dev)
+            if world > 1:
+                vmin = vt.clone(); dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+                dist.all_reduce(vt, op=dist.ReduceOp.SUM)
+                vt[0] = vmin[0]
+            vall = {"frames": int(vt[1]), "records_equal_oracle": bool(vt[0]), "seconds_rank0": vr["seconds"], "threads_per_rank": vr["threads"]}
+            if not vall["records_equal_oracle"]:
+                raise SystemExit(f"strong_scan verification FAILED: scan records differ from the CPU oracle ({vr.get('mismatching_chunks')} on rank {rank})")
         out = None
         if rank == 0:
             rec = lf.evalResults                                      # (NT, 3, 2): the whole clip's records on rank 0
             # sharded == unsharded on sampled frames: regenerate blocks that straddle shard boundaries (frames are a function
-            # of their absolute index), scan them in one single-GPU launch, compare bytes; and with the CPU oracle
+            # of their absolute index), scan them in one single-GPU launch, compare bytes
             probes = sorted({0, NT - 16} | {max(0, min(NT - 16, SH.shard_range(NT, r, world)[0] - 8)) for r in range(1, world)} |
                             {max(0, min(NT - 16, (NT * k) // 8 - 8)) for k in range(1, 8)})
             lf2 = LogoFrame(ctx, logos, MASKRATIO)
             lf2.begin(W, H, 8, 16)
-            same, same_cpu = True, True
-            ol = OracleLogos(logos_np) if not args.no_verify else None
+            same = True
             for p0 in probes:
                 Yp = S.make_clip_torch(16, W, H, 0x5EED0004, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12, pitchY=PITCH_Y,
                                        start=p0, chroma=False)["Y"]
                 lf2.scan_batch(Yp, 8, 0, 16)
                 same &= lf2.evalResults.tobytes() == np.ascontiguousarray(rec[p0:p0 + 16]).tobytes()
-                if ol is not None:
-                    same_cpu &= ol.scan(Yp.cpu().numpy(), 16).tobytes() == np.ascontiguousarray(rec[p0:p0 + 16]).tobytes()
-            if not (same and same_cpu):
-                raise SystemExit(f"strong_scan verification FAILED: sharded == single-launch: {same}, == CPU oracle: {same_cpu}")
+            if not same:
+                raise SystemExit("strong_scan verification FAILED: the sharded records differ from a single-launch scan of the same frames")
             calls, ms = prof.get("logo_eval_pair_kernel.scan", prof.get(EVAL + ".scan", (0, 0.0)))
             out = {"workload": f"BASELINE configs[3]: {NT}-frame (60 min) 1440x1080i Y-only LogoFrame scan, 3 logos, frames sharded "
                                f"over {world} GPU(s) by contiguous range, all_gather of the records, selectLogo on rank 0",
@@ -613,8 +636,10 @@ def main():
                    "scaling": "strong", "scan_kernel_ms_rank0": ms / max(1, calls),
                    "records_sha256": hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest(),
                    "best_logo": lf.getBestLogo(), "logo_ratio": lf.getLogoRatio(),
-                   "verified": {"probe_blocks": len(probes), "frames": 16 * len(probes), "sharded_equals_single_launch": bool(same),
-                                "equals_cpu_oracle": bool(same_cpu) if ol is not None else None},
+                   "verified": {"frames": vall["frames"] if vall else 0, "equals_cpu_oracle": vall["records_equal_oracle"] if vall else None,
+                                "all_frames": vall, "probe_blocks": len(probes), "sharded_equals_single_launch": bool(same),
+                                "how": "every record of every rank's shard against the threaded CPU oracle (bytes); sampled blocks across the "
+                                       "shard boundaries against a single-launch scan"},
                    "clip_generation_s": gen_s,
                    "note": "records_sha256 is the hash of all gathered {corr0,corr1} records: identical at every N means the sharded "
                            "scan reproduces the single-GPU scan bit for bit"}
@@ -622,7 +647,7 @@ def main():
         torch.cuda.empty_cache()
         # ---- the "full LogoScan" of the same configuration: ScanLogo (LogoScan.hpp:917-1079) over the sharded stream -- an all-gather of
         #      per-rank valid counts hands out the numMaxFrames quota in stream order (:885), three exact int64 all-reduces ----
-        sl = sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT)
+        sl = sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT, verify=not args.no_verify)
         if out is not None:
             out["scanlogo"] = sl
         return out
@@ -1014,8 +1039,16 @@ def main():
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {N} frames 1440x1080i 8-bit in HBM; AMTAnalyzeLogo + LogoFrame scan x3 + CM/KFM metrics + CalcFade + AMTEraseLogo",
-                       "analysis_mode": args.analysis_mode, "calc_fade": args.fades,
+            # (`workload` must survive the compact line's 120-character cut: the list of passes, no prose)
+            "config": {"workload": f"configs[1]: {N}x 1440x1080i 8-bit in HBM: AMTAnalyzeLogo, LogoFrame scan x3, CM/KFM metrics, CalcFade, AMTEraseLogo",
+                       "analysis_mode": args.analysis_mode,
+                       # the headline is NOT the drop-in default: the library and the plugin's "AMTAnalyzeLogo" evaluate in exact mode (every record
+                       # bit-identical); the linear-guarded mode is opt-in (amtgpu_analyze_set_mode / AMTAnalyzeLogoFast).  exact_mode.value is
+                       # the same step at the default
+                       "library_default_mode": "exact",
+                       "value_is_in_mode": ("linear-guarded (opt-in; identical fades and erased frames, scores within 1e-4): see exact_mode.value for the library default"
+                                            if args.analysis_mode == "linear" else "exact (the library default)"),
+                       "calc_fade": args.fades,
                        "device_partition": ({"metrics_cus": MCU, "logo_cus": NCU - MCU, "how": "two contexts on CU-range streams (amtgpu_stream_create_cu_range): the "
                                              "frame metrics run beside the analysis + scan; erase waits for both"} if MCU else None),
                        "frames_per_gpu": N, "logo": f"{LW}x{LH}@({IMGX},{IMGY})", "maskratio": MASKRATIO,
@@ -1232,9 +1265,60 @@ class _DevPtr:
         return self.addr
 
 
-def sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT, max_frames=20000, reps=3):
+_ORACLE_LGD = {}
+
+
+def scanlogo_oracle_lgd(dev, alpha, alphaUV, NT, max_frames, clip=None, chunk=8192):
+    """The CPU oracle's ScanLogo (orc_scanlogo_mt: LogoScan.hpp:794-1080, the ReMakeLogo rounds' per-frame evaluations dealt over the host's
+    cores, quota and accumulations in stream order) over the WHOLE configs[3] stream -> the .lgd bytes it writes.  Only the logo rectangle
+    of every frame travels to the host (49 152 B per frame).  clip: the resident rect_rows clip of frames [0, NT) if the caller has one,
+    else the frames are regenerated here (they are a function of their absolute index).  Cached per (NT, max_frames) in this process."""
+    import tempfile
+    import torch
+    import amt_synth as S
+    import bench_verify as BV
+    from amtlib import Oracle
+    key = (NT, max_frames)
+    if key in _ORACLE_LGD:
+        return _ORACLE_LGD[key]
+    t0 = time.perf_counter()
+    hY = np.empty((NT, LH, LW), np.uint8)
+    hU = np.empty((NT, LH // 2, LW // 2), np.uint8)
+    hV = np.empty_like(hU)
+    for c0 in range(0, NT, chunk):
+        c1 = min(NT, c0 + chunk)
+        c = ({k: clip[k][c0:c1] for k in "YUV"} if clip is not None else
+             S.make_clip_torch(c1 - c0, W, H, 0x5EED0004, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12, pitchY=PITCH_Y, pitchUV=PITCH_UV,
+                               start=c0, rows=(IMGY, IMGY + LH), flat_every=SCANLOGO_FLAT_EVERY))
+        hY[c0:c1] = c["Y"][:, :, IMGX:IMGX + LW].cpu().numpy()
+        hU[c0:c1] = c["U"][:, :, IMGX // 2:(IMGX + LW) // 2].cpu().numpy()
+        hV[c0:c1] = c["V"][:, :, IMGX // 2:(IMGX + LW) // 2].cpu().numpy()
+        del c
+    t1 = time.perf_counter()
+    orc = Oracle()
+    nvalid, nread = C.c_int(), C.c_int()
+    T = BV.host_threads()
+    # the oracle addresses the rectangle as plane + scanx + scany * pitch (LogoScan.hpp:888-893): hand it the address a full plane of pitch
+    # LW would start at (never dereferenced outside the rectangle)
+    lo = orc.lib.orc_scanlogo_mt(C.c_void_p(hY.ctypes.data - (IMGX + IMGY * LW)), C.c_void_p(hU.ctypes.data - (IMGX // 2 + (IMGY // 2) * (LW // 2))),
+                                 C.c_void_p(hV.ctypes.data - (IMGX // 2 + (IMGY // 2) * (LW // 2))), LW * LH, (LW // 2) * (LH // 2), LW, LW // 2,
+                                 W, H, NT, IMGX, IMGY, LW, LH, 12, max_frames, 1, C.byref(nvalid), None, T, C.byref(nread))
+    if not lo:
+        raise RuntimeError("oracle ScanLogo: insufficient logo frames")
+    with tempfile.TemporaryDirectory() as td:
+        o = os.path.join(td, "oracle.lgd")
+        orc.lib.orc_logo_save(lo, o.encode(), b"No Name", 1)                 # the name ScanLogo writes (LogoScan.hpp:1076), serviceid 1
+        lgd = open(o, "rb").read()
+    out = {"lgd": lgd, "valid_frames": int(nvalid.value), "frames_read": int(nread.value), "threads": T,
+           "seconds": {"rectangles_to_host": t1 - t0, "oracle_scanlogo": time.perf_counter() - t1}}
+    _ORACLE_LGD[key] = out
+    return out
+
+
+def sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT, max_frames=SCANLOGO_MAX_FRAMES, reps=3, verify=True):
     """every rank: the rectangle rows of its frames [f0, f0 + nloc) of the 60-minute stream; amtgpu_scanlogo_sharded through
-    torch.distributed (RCCL) -- plain amtgpu_scanlogo at world 1.  lgd_sha256 must not depend on the world size."""
+    torch.distributed (RCCL) -- plain amtgpu_scanlogo at world 1.  lgd_sha256 must not depend on the world size; rank 0 compares the
+    file with the CPU oracle's ScanLogo of the whole stream (bytes)."""
     import tempfile
     import torch
     import torch.distributed as dist
@@ -1242,7 +1326,7 @@ def sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT, max_fr
     from amatsukaze_amd import ScanLogo
     from amatsukaze_amd import sharding as SH
     c = S.make_clip_torch(nloc, W, H, 0x5EED0004, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12, pitchY=PITCH_Y, pitchUV=PITCH_UV,
-                          start=f0, rows=(IMGY, IMGY + LH), flat_every=8)
+                          start=f0, rows=(IMGY, IMGY + LH), flat_every=SCANLOGO_FLAT_EVERY)
     view = _RectView(c, nloc)
     out = os.path.join(tempfile.mkdtemp(), "scan.lgd") if rank == 0 else None
     coll = SH.TorchCollectives() if world > 1 else None
@@ -1270,13 +1354,24 @@ def sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT, max_fr
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    orc = None
+    if rank == 0 and verify:
+        orc = scanlogo_oracle_lgd(dev, alpha, alphaUV, NT, max_frames, clip=c if world == 1 else None)
     del c
     torch.cuda.empty_cache()
     if rank != 0:
         return None
     lgd = open(out, "rb").read()
+    verified = None
+    if orc is not None:
+        verified = {"frames": NT, "lgd_equals_cpu_oracle": lgd == orc["lgd"], "valid_frames": orc["valid_frames"],
+                    "frames_read_before_quota": orc["frames_read"], "quota_hit": orc["valid_frames"] >= max_frames and orc["frames_read"] < NT,
+                    "oracle_seconds": orc["seconds"], "oracle_threads": orc["threads"]}
+        if not verified["lgd_equals_cpu_oracle"]:
+            raise SystemExit(f"sharded ScanLogo verification FAILED at N = {world}: the .lgd of the {NT}-frame stream differs from the CPU oracle's")
     return {"workload": f"ScanLogo over the {NT}-frame stream, frames sharded over {world} GPU(s) by contiguous range, numMaxFrames {max_frames}",
             "value": NT / el, "unit": "frames/sec", "ms_per_scanlogo": el * 1e3, "n_gpus": world, "lgd_sha256": hashlib.sha256(lgd).hexdigest(),
+            "verified": verified,
             "note": "lgd_sha256 identical at every N (and to configs.scanlogo_60min.lgd_sha256 of the default line) means the sharded "
                     "ScanLogo writes the single-GPU .lgd byte for byte"}
 
@@ -1292,25 +1387,28 @@ class _RectView:
         self.strideY, self.strideUV, self.pitchY, self.pitchUV = LH * PITCH_Y, (LH // 2) * PITCH_UV, PITCH_Y, PITCH_UV
 
 
-def config_scanlogo(ctx, dev, logos_np, alpha, alphaUV, args, NT=STRONG_FRAMES, max_frames=20000):
+def config_scanlogo(ctx, dev, logos_np, alpha, alphaUV, args, NT=STRONG_FRAMES, max_frames=SCANLOGO_MAX_FRAMES):
     """BASELINE configs[3]'s 'full LogoScan': the exported ScanLogo (LogoScan.hpp:1083-1098, 917-1079) over the 60-minute stream at
-    N = 1 -- border test + accumulation over all frames (the first numMaxFrames valid ones), two ReMakeLogo rounds, .lgd written."""
+    N = 1 -- border test + accumulation over all frames (the first numMaxFrames valid ones), two ReMakeLogo rounds, .lgd written --
+    and the .lgd of the WHOLE stream compared with the CPU oracle's ScanLogo (bytes)."""
     import tempfile
     import torch
     import amt_synth as S
     from amatsukaze_amd import ScanLogo
     t0 = time.perf_counter()
     c = S.make_clip_torch(NT, W, H, 0x5EED0004, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12, pitchY=PITCH_Y, pitchUV=PITCH_UV,
-                          rows=(IMGY, IMGY + LH), flat_every=8)
+                          rows=(IMGY, IMGY + LH), flat_every=SCANLOGO_FLAT_EVERY)
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
     view = _RectView(c, NT)
     tmp = tempfile.mkdtemp()
     out = os.path.join(tmp, "scan.lgd")
-    state = {"ngather": 0}
+    state = {"ngather": 0, "nread": 0}
 
     def cb(progress, nread, total, ngather):
         state["ngather"] = max(state["ngather"], ngather)
+        if total == 0:                                                # MakeInitialLogo's progress calls (LogoScan.hpp:904-909): frames read so far
+            state["nread"] = max(state["nread"], nread)
         return 1
 
     def run():
@@ -1319,34 +1417,23 @@ def config_scanlogo(ctx, dev, logos_np, alpha, alphaUV, args, NT=STRONG_FRAMES, 
 
     wall, kern = _prof(ctx, run, 3)
     lgd = open(out, "rb").read()
-    # ---- the same entry point on the stream's first 1 024 frames against the CPU oracle's ScanLogo: the .lgd files' logo planes ----
     verified = None
     if not args.no_verify:
-        from amtlib import Oracle
-        n_small = 1024
-        o2 = os.path.join(tmp, "small.lgd")
-        v2 = _RectView(c, n_small)
-        ok = ScanLogo(ctx, v2, 1, o2, IMGX, IMGY, LW, LH, 12, max_frames)
-        hY = np.zeros((n_small, H, PITCH_Y), np.uint8); hU = np.zeros((n_small, H // 2, PITCH_UV), np.uint8); hV = np.zeros_like(hU)
-        hY[:, IMGY:IMGY + LH] = c["Y"][:n_small].cpu().numpy()
-        hU[:, IMGY // 2:(IMGY + LH) // 2] = c["U"][:n_small].cpu().numpy()
-        hV[:, IMGY // 2:(IMGY + LH) // 2] = c["V"][:n_small].cpu().numpy()
-        orc = Oracle()
-        nvalid = C.c_int()
-        lo = orc.lib.orc_scanlogo(_ptr_np(hY), _ptr_np(hU), _ptr_np(hV), hY.strides[0], hU.strides[0], PITCH_Y, PITCH_UV, W, H, n_small,
-                                  IMGX, IMGY, LW, LH, 12, max_frames, 1, C.byref(nvalid), None)
-        same = False
-        if ok and lo:
-            o3 = os.path.join(tmp, "oracle.lgd")
-            orc.lib.orc_logo_save(lo, o3.encode(), b"No Name", 1)            # the name ScanLogo writes (LogoScan.hpp:1076), serviceid 1
-            same = open(o2, "rb").read() == open(o3, "rb").read()
-        verified = {"frames": n_small, "valid_frames": int(nvalid.value), "lgd_equals_cpu_oracle": bool(same)}
-        if not same:
-            raise SystemExit("ScanLogo verification FAILED: the .lgd of the stream's first 1 024 frames differs from the CPU oracle's")
+        orc = scanlogo_oracle_lgd(dev, alpha, alphaUV, NT, max_frames, clip=c)
+        verified = {"frames": NT, "lgd_equals_cpu_oracle": lgd == orc["lgd"], "valid_frames": orc["valid_frames"],
+                    "frames_read_before_quota": orc["frames_read"], "quota_hit": orc["valid_frames"] >= max_frames and orc["frames_read"] < NT,
+                    "accepted_equals_oracle": state["ngather"] == orc["valid_frames"],
+                    "oracle_seconds": orc["seconds"], "oracle_threads": orc["threads"],
+                    "how": "the whole stream through the CPU oracle's ScanLogo (quota and accumulations in stream order, the ReMakeLogo rounds' "
+                           "per-frame evaluations over the host's cores); .lgd files compared as bytes"}
+        if not (verified["lgd_equals_cpu_oracle"] and verified["accepted_equals_oracle"]):
+            print(json.dumps({"scanlogo_verified": verified}), file=sys.stderr, flush=True)
+            raise SystemExit(f"ScanLogo verification FAILED: the .lgd of the {NT}-frame stream differs from the CPU oracle's")
     del c
     rect_bytes = LW * LH + 2 * (LW // 2) * (LH // 2)
     return {"workload": f"BASELINE configs[3] at N = 1: ScanLogo over the {NT}-frame (60 min) 1440x1080i stream, 256x128 rectangle, thy 12, "
-                        f"numMaxFrames {max_frames} (one frame in eight has a flat rectangle: {state['ngather']} accepted)",
+                        f"numMaxFrames {max_frames} (one frame in {SCANLOGO_FLAT_EVERY} has a flat rectangle: {state['ngather']} accepted"
+                        + (", the stream-order quota closes the stream early" if state["ngather"] >= max_frames else "") + ")",
             "frames": NT, "accepted_frames": state["ngather"], "value": NT / wall, "unit": "frames/sec", "ms_per_scanlogo": wall * 1e3,
             "kernels_ms_per_call": kern, "algorithmic_bytes": {"border_test_and_accumulate": rect_bytes * NT},
             "lgd_sha256": hashlib.sha256(lgd).hexdigest(), "lgd_bytes": len(lgd), "verified": verified, "clip_generation_s": gen_s,

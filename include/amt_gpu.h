@@ -27,12 +27,14 @@
 extern "C" {
 #endif
 
-#define AMTGPU_ABI_VERSION 4      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers
+#define AMTGPU_ABI_VERSION 5      /* 2: amtgpu_framestats_create lost two unused parameters; *W entry points, logo header access, markers
                                    * 3: additions only -- device-side CalcFade (amtgpu_erase_calc_fades_device, *_dfades), sharded frame
                                    *    metrics (amtgpu_framestats_allgather / _sharded), registered host frames (amtgpu_frames_register),
                                    *    amtgpu_download_scatter, owned markers
                                    * 4: amtgpu_logoframe_decide_host returns -1 (was 0) when the text buffer is too small and refuses
-                                   *    num_candidates > num_logos; additions: amtgpu_logoframe_dump_result, amtgpu_host_set_parallelism */
+                                   *    num_candidates > num_logos; additions: amtgpu_logoframe_dump_result, amtgpu_host_set_parallelism
+                                   * 5: amtgpu_logoframe_decide_host is back to 1 / 0 like every other entry point (a too-small text buffer
+                                   *    is 0 with *text_len > cap: `if (!call) fail;` written against ABI <= 3 is right again) */
 #define AMTGPU_NUM_FADE 11            /* LogoAnalyzeFrame p/t/b[11]  (LogoScan.hpp:1100-1103) */
 #define AMTGPU_ANALYZE_FLOATS 33      /* floats per source frame in an analysis record */
 
@@ -240,8 +242,8 @@ int  amtgpu_logoframe_best_logo(const AmtGpuLogoFrame* lf);
 /* The same two decisions -- LogoFrame::selectLogo and the text LogoFrame::writeResult writes (LogoScan.hpp:1647-1827) -- from scan
  * records alone, on the host, no device and no LogoFrame object: what a rank (or a tool) that only holds the gathered
  * records [num_frames][num_logos]{corr0, corr1} needs.  logo_index -1 = the selected logo.  text may be NULL (cap 0) to ask for
- * the length.  Returns 1 = done, 0 = bad arguments (NULL records, logo_index or num_candidates > num_logos, fps <= 0), -1 = cap
- * too small (text_len is still set).  O(1) work per frame.  Evidence that is NaN (corr0 = +inf with corr1 = -inf) sorts after
+ * the length.  Returns 1 = done, 0 = failed: bad arguments (NULL records, logo_index or num_candidates > num_logos, fps <= 0) or cap
+ * too small -- then *text_len (set whenever the arguments are good) is > cap and says how much it takes.  O(1) work per frame.  Evidence that is NaN (corr0 = +inf with corr1 = -inf) sorts after
  * every number in the median window -- the reference's std::sort over it is undefined. */
 int  amtgpu_logoframe_decide_host(const float* evals, int num_frames, int num_logos, int num_candidates, int logo_index,
                                   int fps_num, int fps_den, int* best_logo, float* logo_ratio, char* text, int cap, int* text_len);

@@ -29,6 +29,7 @@
 #include <numeric>
 #include <regex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -891,19 +892,24 @@ OrcLogo* orc_scan_get_logo(OrcScan* s, int maxv, int clean, int imgw, int imgh, 
 }
 
 // LogoScan.hpp:794-1080 without the codec/file plumbing: valid crops are kept raw in memory
-OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V, int64_t strideY, int64_t strideUV,
-                      int pitchY, int pitchUV, int imgw, int imgh, int nframes_total, int scanx, int scany,
-                      int scanw, int scanh, int thy, int numMaxFrames, int use_avx, int* num_valid_out, int* minfades_out)
+// The two ReMakeLogo rounds evaluate every kept frame at 20 fades independently of every other frame (:957-984): with threads > 1 the
+// frames are dealt over host threads, each with its own memDeint / memWork (evaluate_logo keeps no state).  Everything that is ordered in
+// the reference stays ordered here: the quota of the first numMaxFrames valid frames in stream order (:885), both AddFrame accumulations.
+static OrcLogo* scanlogo_impl(const uint8_t* Y, const uint8_t* U, const uint8_t* V, int64_t strideY, int64_t strideUV,
+                              int pitchY, int pitchUV, int imgw, int imgh, int nframes_total, int scanx, int scany,
+                              int scanw, int scanh, int thy, int numMaxFrames, int use_avx, int* num_valid_out, int* minfades_out,
+                              int threads, int* frames_read_out)
 {
     const int logUVx = 1, logUVy = 1;                       // YUV420 (:866-867)
     const int uvw = scanw >> logUVx, uvh = scanh >> logUVy;
     const size_t ysz = (size_t)scanw * scanh, csz = (size_t)uvw * uvh, fsz = ysz + 2 * csz;
     std::vector<uint8_t> crops;
-    int numFrames = 0;
+    int numFrames = 0, nread = 0;
     std::unique_ptr<OrcScan> scan(orc_scan_create(scanw, scanh, logUVx, logUVy, thy));
     // MakeInitialLogo :917-921 / onFrame :881-914
     for (int n = 0; n < nframes_total; ++n) {
         if (numFrames >= numMaxFrames) break;
+        ++nread;
         int offY = scanx + scany * pitchY;
         int offUV = (scanx >> logUVx) + (scany >> logUVy) * pitchUV;
         const uint8_t* sy = Y + n * strideY + offY;
@@ -922,25 +928,36 @@ OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V, int6
         }
     }
     if (num_valid_out) *num_valid_out = numFrames;
+    if (frames_read_out) *frames_read_out = nread;
     std::unique_ptr<OrcLogo> logodata(scan_get_logo(*scan, 255, false, imgw, imgh, scanx, scany));  // :845-846
     if (!logodata) return nullptr;
     std::vector<int> minFades(numFrames);
-    std::vector<float> memDeint(ysz + 8), memWork(ysz + 8);
+    const int T = std::max(1, std::min(threads, numFrames));
     for (int round = 0; round < 2; ++round) {               // ReMakeLogo x2 (:1067-1069), body :923-1036
         std::unique_ptr<OrcLogo> deint(orc_logo_deint(logodata.get()));
         deint->imgw = scanw; deint->imgh = scanh;
         orc_logo_create_mask(deint.get(), 0.1f, use_avx);
         const int numFade = 20;
-        for (int i = 0; i < numFrames; ++i) {
-            deint_y(memDeint.data(), &crops[(size_t)i * fsz], scanw, scanw, scanh);
-            float minResult = FLT_MAX;
-            int minFadeIndex = 0;
-            for (int fi = 0; fi < numFade; ++fi) {
-                float fade = 0.1f * fi;
-                float result = std::abs(evaluate_logo(*deint, memDeint.data(), 255.0f, fade, memWork.data(), -1));
-                if (result < minResult) { minResult = result; minFadeIndex = fi; }
+        auto eval_frames = [&](int first, int step) {
+            std::vector<float> memDeint(ysz + 8), memWork(ysz + 8);
+            for (int i = first; i < numFrames; i += step) {
+                deint_y(memDeint.data(), &crops[(size_t)i * fsz], scanw, scanw, scanh);
+                float minResult = FLT_MAX;
+                int minFadeIndex = 0;
+                for (int fi = 0; fi < numFade; ++fi) {
+                    float fade = 0.1f * fi;
+                    float result = std::abs(evaluate_logo(*deint, memDeint.data(), 255.0f, fade, memWork.data(), -1));
+                    if (result < minResult) { minResult = result; minFadeIndex = fi; }
+                }
+                minFades[i] = minFadeIndex;
             }
-            minFades[i] = minFadeIndex;
+        };
+        if (T == 1) {
+            eval_frames(0, 1);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back(eval_frames, t, T);
+            for (auto& x : th) x.join();
         }
         std::unique_ptr<OrcScan> rescan(orc_scan_create(scanw, scanh, logUVx, logUVy, thy));
         for (int i = 0; i < numFrames; ++i)
@@ -953,6 +970,23 @@ OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V, int6
     }
     if (minfades_out) std::memcpy(minfades_out, minFades.data(), sizeof(int) * numFrames);
     return logodata.release();
+}
+
+OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V, int64_t strideY, int64_t strideUV,
+                      int pitchY, int pitchUV, int imgw, int imgh, int nframes_total, int scanx, int scany,
+                      int scanw, int scanh, int thy, int numMaxFrames, int use_avx, int* num_valid_out, int* minfades_out)
+{
+    return scanlogo_impl(Y, U, V, strideY, strideUV, pitchY, pitchUV, imgw, imgh, nframes_total, scanx, scany, scanw, scanh, thy,
+                         numMaxFrames, use_avx, num_valid_out, minfades_out, 1, nullptr);
+}
+
+OrcLogo* orc_scanlogo_mt(const uint8_t* Y, const uint8_t* U, const uint8_t* V, int64_t strideY, int64_t strideUV,
+                         int pitchY, int pitchUV, int imgw, int imgh, int nframes_total, int scanx, int scany,
+                         int scanw, int scanh, int thy, int numMaxFrames, int use_avx, int* num_valid_out, int* minfades_out,
+                         int threads, int* frames_read_out)
+{
+    return scanlogo_impl(Y, U, V, strideY, strideUV, pitchY, pitchUV, imgw, imgh, nframes_total, scanx, scany, scanw, scanh, thy,
+                         numMaxFrames, use_avx, num_valid_out, minfades_out, threads, frames_read_out);
 }
 
 

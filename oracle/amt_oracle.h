@@ -109,6 +109,14 @@ OrcLogo* orc_scanlogo(const uint8_t* Y, const uint8_t* U, const uint8_t* V,
                       int imgw, int imgh, int nframes_total,
                       int imgx, int imgy, int w, int h, int thy, int numMaxFrames,
                       int use_avx, int* num_valid_out, int* minfades_out);
+/* the same, the ReMakeLogo rounds' per-frame evaluations (:957-984, independent per frame) dealt over `threads` host threads; the
+ * stream-order quota (:885) and both accumulations stay sequential.  frames_read_out (optional): frames consumed before the quota
+ * closed the stream (readCount, :883).  Byte-identical to orc_scanlogo for any thread count (tests/test_oracle_vs_ref.py). */
+OrcLogo* orc_scanlogo_mt(const uint8_t* Y, const uint8_t* U, const uint8_t* V,
+                         int64_t strideY, int64_t strideUV, int pitchY, int pitchUV,
+                         int imgw, int imgh, int nframes_total,
+                         int imgx, int imgy, int w, int h, int thy, int numMaxFrames,
+                         int use_avx, int* num_valid_out, int* minfades_out, int threads, int* frames_read_out);
 
 /* ---- SELF-SPECIFIED whole-frame metrics -- PARITY UNPINNED: the reference has no
  * in-tree arithmetic for them.  C restatement of oracle/frame_stats_oracle.py, used as

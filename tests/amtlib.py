@@ -90,6 +90,7 @@ class Oracle:
         d("orc_frame_metrics", None, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
         d("orc_merge_field", None, [c_p] * 6 + [c_i] * 6 + [c_p] * 3 + [c_i] * 2)
         d("orc_scanlogo", c_p, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p])
+        d("orc_scanlogo_mt", c_p, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p])
 
     # ---- helpers ----
     def logo_info(self, h):

@@ -33,7 +33,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(binding.SIGNATURES), declared ^ set(binding.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.amtgpu_abi_version() == 4
+    assert lib.amtgpu_abi_version() == 5
 
 
 def test_hip_runtime_count_is_reported(lib):
@@ -253,7 +253,7 @@ def test_logoframe_decisions_on_the_host_match_the_oracle(lib, fps):
     assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, nl + 1, -1, fps[0], fps[1], None, None, None, 0, None) == 0   # more candidates than logos
     small = C.create_string_buffer(4)
     tl = C.c_int()
-    assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, -1, fps[0], fps[1], None, None, small, 4, C.byref(tl)) == (-1 if tl.value > 4 else 1)
+    assert lib.amtgpu_logoframe_decide_host(_ptr(ev), n, nl, -1, -1, fps[0], fps[1], None, None, small, 4, C.byref(tl)) == (0 if tl.value > 4 else 1)
 
 
 def test_logoframe_text_survives_nan_evidence(lib):

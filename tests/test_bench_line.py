@@ -39,7 +39,7 @@ def test_compact_line_is_small_and_round_trips():
     assert c["all_cores"]["cores"] == 256 and c["reference_check"]["oracle_equals_reference"] is True
     assert back["verified"]["ok"] is True and back["exact_mode"]["value"] > 0
     assert back["e2e10"]["value"] > 0 and back["strong_scan"]["value"] > 0 and back["ingest"]["y_plane"]["pipelined_fps"] > 0
-    assert all(len(v) <= 120 for v in back["config"].values() if isinstance(v, str))
+    assert all(len(v) <= 160 for v in back["config"].values() if isinstance(v, str))
 
 
 def test_compact_line_sheds_optional_parts_before_it_outgrows_the_reader():
@@ -78,7 +78,20 @@ def test_round5_detail_compacts_to_the_committed_line():
     printed = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench.json")).read().strip().splitlines()[-1])
     line = bench.compact_line(full)
     assert len(json.dumps(line)) < bench.LINE_LIMIT
-    assert line == printed
+
+    def within(a, b, path=""):
+        """everything round 5 printed is still in the line, unchanged (round 6 added keys -- verified frame counts of the attached
+        configurations, the quota flag -- which a round-5 detail file leaves null); strings may only have been cut at a different length"""
+        if isinstance(a, dict):
+            assert isinstance(b, dict), path
+            for k in a:
+                assert k in b, path + "/" + k
+                within(a[k], b[k], path + "/" + k)
+        elif isinstance(a, str) and a.endswith("..."):
+            assert b.startswith(a[:-3]), path
+        else:
+            assert a == b, path
+    within(printed, line)
     assert line["verified"]["ok"] is True and line["verified"]["frames"] == line["config"]["frames_per_gpu"] == 10000
     assert line["roofline"]["bound"] in ("hbm", "fp32-valu") and 0 < line["roofline"]["frac"] < 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1

@@ -44,8 +44,11 @@ def test_verify_range_agrees_with_the_serial_oracle(bits):
     assert (fades != 0).any() and (fades == 0).any()          # the clip fades the logo in and out: the erase path is exercised
     pr = lambda lo, hi: tuple(t[lo:hi] for t in P)
     er = lambda lo, hi: tuple(t[lo:hi] for t in E)
-    for (v0, v1, chunk) in ((0, N, 16), (0, N, 512), (16, 48, 8), (24, N, 16), (0, 40, 24)):
-        r = BV.verify_range(torch, ol, bits, N, v0, v1, pr, er, ev[v0:], an[v0:], fades[v0:], st[v0:], base=v0, tol=0.0, chunk=chunk, threads=4)
+    # (range starts that are no multiple of 8 -- a rank's shard of a ragged split, e2e10 -- and one that ends with the clip)
+    cache = {}
+    for (v0, v1, chunk) in ((0, N, 16), (0, N, 512), (16, 48, 8), (24, N, 16), (0, 40, 24), (13, 50, 16), (37, N, 8), (9, 10, 8)):
+        r = BV.verify_range(torch, ol, bits, N, v0, v1, pr, er, ev[v0:], an[v0:], fades[v0:], st[v0:], base=v0, tol=0.0, chunk=chunk, threads=4,
+                            stage_cache=cache)
         assert r["ok"] and r["frames"] == v1 - v0, (v0, v1, chunk, r)
     # the linear mode's comparison: records within a tolerance, everything else bytes
     r = BV.verify_range(torch, ol, bits, N, 0, N, pr, er, ev, an + np.float32(3e-6), fades, st, tol=1e-4, chunk=32, threads=3)
@@ -70,3 +73,19 @@ def test_verify_range_notices_one_wrong_value():
     r = run(fades=f2); assert not r["fades"] and not r["ok"]
     E2 = (E[0].clone(), E[1], E[2]); E2[0][39, H - 1, W - 1] ^= 1          # a byte OUTSIDE the logo rectangle
     r = run(er=lambda lo, hi: tuple(t[lo:hi] for t in E2)); assert not r["erase"] and r["fades"] and not r["ok"]
+
+
+@pytest.mark.parametrize("bits", [8, 10])
+def test_verify_scan_records_from_the_logo_rows_alone(bits):
+    """the full-stream check of BASELINE configs[3] ships only the logo rectangle's rows of every frame to the host"""
+    N = 41
+    ol, P, E, ev, an, fades, st = _serial(bits, N)
+    LH = 128
+    rows = lambda lo, hi: P[0][lo:hi, Y0:Y0 + LH]
+    r = BV.verify_scan_records(torch, ol, bits, 0, N, rows, ev, Y0, chunk=16, threads=3)
+    assert r["records_equal_oracle"] and r["frames"] == N
+    r = BV.verify_scan_records(torch, ol, bits, 5, 30, rows, ev, Y0, chunk=7, threads=5)
+    assert r["records_equal_oracle"] and r["frames"] == 25
+    ev2 = ev.copy(); ev2[29, 0, 1] = np.nextafter(ev2[29, 0, 1], np.float32(2))
+    r = BV.verify_scan_records(torch, ol, bits, 0, N, rows, ev2, Y0, chunk=16, threads=3)
+    assert not r["records_equal_oracle"] and r["mismatching_chunks"] == [[16, 32]]

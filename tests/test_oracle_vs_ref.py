@@ -258,6 +258,20 @@ def test_scanlogo_full_pipeline(env):
     out = str(env["tmp"] / "scanned_o.lgd").encode()
     assert orc.lib.orc_logo_save(lo, out, b"No Name", 1041) == 1
     assert open(dst, "rb").read() == open(out, "rb").read()
+    # the frame-parallel driver (bench.py's full-stream check of BASELINE configs[3]): same bytes for any thread count, and it reports
+    # how many frames the stream-order quota (LogoScan.hpp:885) let through -- 25 valid frames are reached before the clip ends
+    for threads in (1, 3, 8):
+        nv2, nread = C.c_int(), C.c_int()
+        mf1, mf2 = np.zeros(25, np.int32), np.zeros(25, np.int32)
+        lo1 = orc.lib.orc_scanlogo(_ptr(Y), _ptr(U), _ptr(V), Y.strides[0], U.strides[0], Y.shape[2], U.shape[2],
+                                   W, H, Y.shape[0], IMGX, IMGY, LW, LH, 12, 25, 1, None, _ptr(mf1))
+        lo2 = orc.lib.orc_scanlogo_mt(_ptr(Y), _ptr(U), _ptr(V), Y.strides[0], U.strides[0], Y.shape[2], U.shape[2],
+                                      W, H, Y.shape[0], IMGX, IMGY, LW, LH, 12, 25, 1, C.byref(nv2), _ptr(mf2), threads, C.byref(nread))
+        assert lo1 and lo2 and nv2.value == 25 and 25 <= nread.value < Y.shape[0]
+        assert mf1.tobytes() == mf2.tobytes()
+        out2 = str(env["tmp"] / f"scanned_mt{threads}.lgd").encode()
+        assert orc.lib.orc_logo_save(lo2, out2, b"No Name", 1041) == 1
+        assert open(dst, "rb").read() == open(out2, "rb").read()
     # the recovered logo resembles the true one where alpha is significant
     data = orc.logo_arrays(lo)[0]
     aY = data[:LW * LH].reshape(LH, LW)

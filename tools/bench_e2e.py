@@ -50,7 +50,7 @@ def _generate(S, torch, dev, a0, a1, alpha, alphaUV, seed=0x5EED0006):
     return cat(Ys), cat(Us), cat(Vs)
 
 
-def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="strong"):
+def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="strong", verify_budget_s=300.0):
     """E: namespace with torch, dist, rank, world, dev, ctx, logos_np, alpha, alphaUV, fence(), max_over_ranks(x), OracleLogos, rccl"""
     torch, dist, rank, world, dev, ctx = E.torch, E.dist, E.rank, E.world, E.dev, E.ctx
     import amt_synth as S
@@ -85,15 +85,15 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
         probes = [(0, nt)]
     stash = {}                                         # frame index -> erased (Y, U, V) of probe frames this rank owns
     is_probe = lambda n: any(p <= n < p + k for p, k in probes)
-    # ... and one CONTIGUOUS range of up to 4 096 frames per rank, straddling the rank's first chunk boundary where it has one, every
-    # frame of which is compared with the oracle (tools/bench_verify.py); its erased frames stay on the device until then
-    VR = 4096
-    vr0 = -(-max(f0, f0 + chunk - VR // 2) // 8) * 8 if nloc > chunk else -(-f0 // 8) * 8
-    vr1 = min(f1, vr0 + VR)
-    if not verify or vr1 - vr0 < 16:
-        vr0 = vr1 = 0
-    vstash = []                                        # (first frame, Y, U, V) pieces of [vr0, vr1), erased
-
+    # ... and EVERY frame of the rank's share, chunk by chunk right behind the chunk's timed calls (tools/bench_verify.py: the oracle on this
+    # rank's part of the host's cores, a pristine copy of the chunk + halo kept on the device for it).  `verify_budget_s` bounds the wall
+    # time a rank spends in it (the whole 53 946-frame share of one GPU takes about a minute of a 256-core host; eight ranks sharing that
+    # host take eight times as long for the 4-hour stream): once it is used up the remaining chunks are left to the probe blocks, and the
+    # line says how many frames were compared.
+    import bench_verify as BV
+    vstate = {"spent": 0.0, "frames": 0, "max_an": 0.0, "ok": {k: True for k in ("scan", "analysis", "fades", "erase", "metrics")}, "mismatches": [],
+              "stage": {}, "ol": None, "skipped_chunks": 0}
+    vthreads = max(1, BV.host_threads() // max(1, world))
     # warm-up, untimed (the headline's warm-up steps): the first use of every object builds its tile plans and tables, uploads them and
     # loads the 16-bit kernels -- per-logo set-up like the reference's constructors (CreateLogoMask, LogoScan.hpp:1164-1201), ~9 ms.
     # Everything it writes is overwritten by the rank's first chunk.
@@ -131,6 +131,11 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
         Y, U, V = _generate(S, torch, dev, a0, a1, E.alpha, E.alphaUV)
         torch.cuda.synchronize()
         gen_s += time.perf_counter() - t0
+        vchunk = verify and vstate["spent"] < verify_budget_s
+        if vchunk:
+            pY, pU, pV = Y.clone(), U.clone(), V.clone()          # what the oracle is fed: the chunk + halo before the erase rewrites it
+        elif verify:
+            vstate["skipped_chunks"] += 1
         own = DeviceClip(Y[c0 - a0:c1 - a0], U[c0 - a0:c1 - a0], V[c0 - a0:c1 - a0], W, H, BITS)
         nown = c1 - c0
         # ---------------- timed: the hot path over one resident chunk ----------------
@@ -160,9 +165,27 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
             for n in range(c0, c1):
                 if is_probe(n):
                     stash[n] = tuple(t[n - c0].cpu().numpy().view(np.uint16) for t in (own.Y, own.U, own.V))
-            s0, s1 = max(c0, vr0), min(c1, vr1)
-            if s0 < s1:
-                vstash.append((s0,) + tuple(t[s0 - c0:s1 - c0].clone() for t in (own.Y, own.U, own.V)))
+        if vchunk:
+            tv = time.perf_counter()
+            if vstate["ol"] is None:
+                vstate["ol"] = E.OracleLogos(E.logos_np, W, H, LX, LY, BITS)
+
+            def pristine(lo, hi, a0=a0, a1=a1):
+                if a0 <= lo and hi <= a1:
+                    return pY[lo - a0:hi - a0], pU[lo - a0:hi - a0], pV[lo - a0:hi - a0]
+                return _generate(S, torch, dev, lo, hi, E.alpha, E.alphaUV)       # (the few frames the group-of-8 alignment reaches back)
+            rr = BV.verify_range(torch, vstate["ol"], BITS, nt, c0, c1, pristine,
+                                 lambda lo, hi: (own.Y[lo - c0:hi - c0], own.U[lo - c0:hi - c0], own.V[lo - c0:hi - c0]),
+                                 lf.evalResults[c0:c1], rec[c0 - a0:c1 - a0].cpu().numpy(), d_fades[c0 - f0:c1 - f0].cpu().numpy(),
+                                 d_stats[c0 - f0:c1 - f0].cpu().numpy().view(np.uint64), base=c0, tol=1e-4 if mode == "linear" else 0.0,
+                                 chunk=256, threads=vthreads, stage_cache=vstate["stage"])
+            for k in vstate["ok"]:
+                vstate["ok"][k] &= rr[k]
+            vstate["frames"] += rr["frames"]
+            vstate["max_an"] = max(vstate["max_an"], rr["analysis_max_abs_err"])
+            vstate["mismatches"] += rr.get("mismatches", [])[:4]
+            del pY, pU, pV
+            vstate["spent"] += time.perf_counter() - tv
         del Y, U, V, own
     prof = ctx.profile_report()
     ctx.profile(False)
@@ -239,21 +262,13 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
                     ol.erase(Yb, Ub, Vb, i, ft, fb)
                     eY, eU, eV = stash[n]
                     ok["erase"] &= bool(np.array_equal(Yb[i], eY) and np.array_equal(Ub[i], eU) and np.array_equal(Vb[i], eV))
-        if vr1 > vr0:
-            import bench_verify as BV
-            eY, eU, eV = (torch.cat([p[k] for p in vstash], 0) for k in (1, 2, 3))
-            assert vstash[0][0] == vr0 and eY.shape[0] == vr1 - vr0
-            vstash.clear()
-            rr = BV.verify_range(torch, ol, BITS, nt, vr0, vr1, lambda lo, hi: _generate(S, torch, dev, lo, hi, E.alpha, E.alphaUV),
-                                 lambda lo, hi: (eY[lo - vr0:hi - vr0], eU[lo - vr0:hi - vr0], eV[lo - vr0:hi - vr0]),
-                                 ev, an_all, fades, metrics, tol=tol, chunk=256)
-            del eY, eU, eV
-            for k in ("scan", "analysis", "fades", "erase", "metrics"):
-                ok[k] &= rr[k]
-            ok["frames"] += rr["frames"]
-            max_an = max(max_an, rr["analysis_max_abs_err"])
-    flags = torch.tensor([int(ok[k]) for k in ("scan", "analysis", "fades", "erase", "metrics")] + [ok["frames"]], dtype=torch.int64)
-    mx = torch.tensor([max_an], dtype=torch.float64)
+        for k in vstate["ok"]:
+            ok[k] &= vstate["ok"][k]
+        max_an = max(max_an, vstate["max_an"])
+        vstate["stage"].clear()
+    flags = torch.tensor([int(ok[k]) for k in ("scan", "analysis", "fades", "erase", "metrics")] + [ok["frames"], vstate["frames"], vstate["skipped_chunks"]],
+                         dtype=torch.int64)
+    mx = torch.tensor([max_an, vstate["spent"]], dtype=torch.float64)
     gen_t = torch.tensor([gen_s, timed_s, tail_s], dtype=torch.float64)
     if world > 1:
         tdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -273,9 +288,14 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
     cuts = set(range(97, nt, 97))
     det = set(int(x) for x in sc.tolist())
     verified = dict(zip(("scan", "analysis", "fades", "erase", "metrics"), (bool(v) for v in flags[:5].tolist())))
-    verified.update({"frames_compared_with_cpu_oracle": int(flags[5]), "probe_blocks": [[p, k] for p, k in probes],
-                     "contiguous_range_rank0": [vr0, vr1],
+    verified.update({"frames_compared_with_cpu_oracle": int(flags[6]), "frames_total": nt, "whole_stream": bool(int(flags[6]) == nt),
+                     "probe_frames_compared_again": int(flags[5]), "probe_blocks": [[p, k] for p, k in probes],
+                     "chunks_left_to_the_probe_blocks_by_the_time_budget": int(flags[7]), "verify_budget_s_per_rank": verify_budget_s,
+                     "verify_seconds_max_over_ranks": float(mx[1]), "oracle_threads_per_rank": vthreads,
+                     "how": "every chunk of every rank's share right behind its timed calls: scan records, frame metrics, fades and the erased Y/U/V "
+                            "planes as bytes, analysis records " + ("within 1e-4" if mode == "linear" else "as bytes") + " (tools/bench_verify.py)",
                      "analysis_max_abs_err": float(mx[0]), "analysis_compare": "abs <= 1e-4" if mode == "linear" else "bytes",
+                     **({"mismatches_rank0": vstate["mismatches"][:8]} if vstate["mismatches"] else {}),
                      "ok": bool(all(flags[:5].tolist())) if verify else None})
     byts = W * H * 2
     fsk = kern.get("frame_stats_kernel")

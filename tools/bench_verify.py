@@ -46,16 +46,18 @@ class _Stage:
         return b
 
 
-def verify_range(torch, ol, bits, NT, v0, v1, pristine, erased, ev_g, an_g, fades_g, st_g, base=0, tol=0.0, erase=True, chunk=512, threads=None):
+def verify_range(torch, ol, bits, NT, v0, v1, pristine, erased, ev_g, an_g, fades_g, st_g, base=0, tol=0.0, erase=True, chunk=512, threads=None,
+                 stage_cache=None):
     """pristine(lo, hi) / erased(lo, hi) -> (Y, U, V) device tensors of frames [lo, hi) before / after the step (U, V may be None when
     erase is False).  ev_g (n, nlogos, 2), an_g (n, 33), fades_g (n, 2), st_g (n, 8): the step's outputs, row i = frame base + i.
-    v0 must be a multiple of 8 unless it is 0 (CalcFade2 addresses the analysis clip in groups of eight and clamps at the clip's end)."""
-    assert v0 == 0 or v0 % 8 == 0, "range start must be a multiple of 8"
+    The oracle's analysis records start at a multiple of 8 at or before v0 - 8 (CalcFade2 addresses the analysis clip in groups of eight,
+    LogoScan.hpp:1271-1276, and clamps the GROUP number at the clip's end: the oracle's array must be cut where the clip's groups are),
+    so pristine() is asked for up to 15 frames before v0.  stage_cache: a dict that keeps the pinned landing buffers between calls."""
     assert chunk % 8 == 0
     lib = ol.orc.lib
     nl = len(ol.deints)
     T = threads or host_threads()
-    a0, a1 = max(0, v0 - HALO), min(NT, v1 + HALO)
+    a0, a1 = max(0, v0 - HALO) // 8 * 8, min(NT, v1 + HALO)
     an_o = np.zeros((a1 - a0, 33), np.float32)               # the oracle's records of [a0, a1)
     done_an = a0
     res = {"frames": 0, "range": [v0, v1], "scan": True, "analysis": True, "fades": True, "erase": True, "metrics": True,
@@ -76,10 +78,15 @@ def verify_range(torch, ol, bits, NT, v0, v1, pristine, erased, ev_g, an_g, fade
             if erase:
                 eY, eU, eV = erased(c0, c1)
             if stage is None:
-                n_y = chunk + 2 * HALO + 2
+                n_y = chunk + 3 * HALO + 2
                 shp = lambda t, n: (n,) + tuple(t.shape[1:])
-                stage = _Stage(torch, [shp(pY, n_y)] + ([shp(pU, n_y), shp(pV, n_y), shp(eY, chunk), shp(eU, chunk), shp(eV, chunk)] if erase else []),
-                               pY.dtype)
+                shapes = [shp(pY, n_y)] + ([shp(pU, n_y), shp(pV, n_y), shp(eY, chunk), shp(eU, chunk), shp(eV, chunk)] if erase else [])
+                key = (tuple(shapes), str(pY.dtype))
+                stage = stage_cache.get(key) if stage_cache is not None else None
+                if stage is None:
+                    stage = _Stage(torch, shapes, pY.dtype)
+                    if stage_cache is not None:
+                        stage_cache[key] = stage
             hY = stage.fetch(0, pY)
             if erase:
                 hU, hV = stage.fetch(1, pU), stage.fetch(2, pV)
@@ -183,3 +190,45 @@ def verify_metrics(torch, lib, bits, W, H, N, getY, st_g, chunk=1024, threads=No
             list(ex.map(work, range(T)))
             ok &= st_o.tobytes() == np.ascontiguousarray(st_g[c0:c1]).astype(np.uint64).tobytes()
     return {"frames": N, "metrics_equal_oracle": bool(ok), "seconds": time.perf_counter() - t0, "threads": T}
+
+
+def verify_scan_records(torch, ol, bits, v0, v1, rows, rec, imgy, chunk=4096, threads=None):
+    """EVERY LogoFrame scan record of frames [v0, v1) against the oracle (LogoScan.hpp:1543-1568; bytes).  rows(lo, hi) -> device tensor
+    (hi - lo, logo rows, pitch): the Y rows [imgy, imgy + h) of those frames -- ScanFrame reads nothing else of a frame, so only the logo
+    rectangle's rows travel to the host (the oracle is handed the address the full plane would start at and never looks outside the
+    rows).  rec: (n, nlogos, 2) records, row i = frame i."""
+    lib = ol.orc.lib
+    nl = len(ol.deints)
+    T = threads or host_threads()
+    view = (lambda t: t.numpy()) if bits <= 8 else (lambda t: t.numpy().view(np.uint16))
+    stage, ok, bad, t0 = None, True, [], time.perf_counter()
+    with ThreadPoolExecutor(T) as ex:
+        for c0 in range(v0, v1, chunk):
+            c1 = min(v1, c0 + chunk)
+            d = rows(c0, c1)
+            if stage is None:
+                stage = _Stage(torch, [(chunk,) + tuple(d.shape[1:])], d.dtype)
+            h = stage.fetch(0, d)
+            if stage.gpu:
+                torch.cuda.synchronize()
+            del d
+            Y = view(h)
+            sY, pitch = Y.strides[0], Y.shape[2]
+            fake = Y.ctypes.data - imgy * pitch * Y.itemsize       # where row 0 of frame c0 would be
+            ev_o = np.zeros((c1 - c0, nl, 2), np.float32)
+            per = -(-(c1 - c0) // T)
+
+            def work(t):
+                a, b = t * per, min(c1 - c0, (t + 1) * per)
+                if a < b:
+                    lib.orc_logoframe_scan(ol.deint_arr, nl, C.c_void_p(fake + a * sY), sY, pitch, bits, ol.W, ol.H, b - a,
+                                           C.c_void_p(ev_o.ctypes.data + a * nl * 8))
+            list(ex.map(work, range(T)))
+            same = ev_o.tobytes() == np.ascontiguousarray(rec[c0:c1], np.float32).tobytes()
+            ok &= same
+            if not same and len(bad) < 8:
+                bad.append([c0, c1])
+    out = {"frames": v1 - v0, "records_equal_oracle": bool(ok), "seconds": time.perf_counter() - t0, "threads": T}
+    if bad:
+        out["mismatching_chunks"] = bad
+    return out
