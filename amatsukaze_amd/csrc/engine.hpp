@@ -141,12 +141,14 @@ public:
 // tile plan of one evaluation logo resident in HBM (eval_tiles.hpp; eval_pair_kernels.hip).  slot = (band * kTileWaves + wave) * 64 + lane
 struct TileLogoDev {
     const float2* kp;            // [13][nslots]  taps of the slot's mask pixel as pairs {k[2j], k[2j+1]} (k[25] = 0), pair-major
-    const float2* sc;            // [32][nslots]  bin-major {scale, scale2} of the slot's mask pixel
+    const float2* sc;            // [32][nslots]  bin-major {scale, scale2} of the slot's mask pixel (the exact scan kernel)
+    const float2* pq;            // [nslots]      {P, Q}: the pixel's response on flat level c is |P + Q c| (the linear analysis kernel: no gathers)
     const uint32_t* sinfo;       // [nslots]      tile_slot_info
     const TileDesc* tiles;       // [nbands * 8]
     const TileBandDesc* bands;   // [nbands]
     const int* tlist;            // [ntlist]  indices of the tiles that hold pixels (kernels that need no band order walk these)
     int nbands, nslots, ntlist;
+    float floorResp;             // limitCorr of the logo (LogoScan.hpp:203)
 };
 
 // one evaluation logo + where its source pixels come from
@@ -210,7 +212,7 @@ private:
     // tile plans (eval_tiles.hpp), built when the pair kernel is chosen
     void ensure_tiles();
     bool tiles_ready_ = false;
-    std::vector<DevBuf<float2>> d_tkp_, d_tsc_;
+    std::vector<DevBuf<float2>> d_tkp_, d_tsc_, d_tpq_;
     std::vector<DevBuf<uint32_t>> d_tinfo_;
     std::vector<DevBuf<TileDesc>> d_tiles_;
     std::vector<DevBuf<TileBandDesc>> d_tbands_;
@@ -221,6 +223,8 @@ private:
     bool linear_ready_ = false;
     float vmax_unit_ = 1.0f;                       // max over logos / pixels of max(1, |a| + |b|) (x 2 for fades outside [0, 1]): window values are <= this * maxv
     std::vector<double> lin_err_corr_, lin_err_sum_;   // per logo: the two parts of the error bound, in units of (u * vmax) and u
+    std::vector<double> lin_err_formula_;              // ... and what evaluating |P + Q c| instead of looking the scale up adds (absolute)
+    bool lin_formula_ok_ = true;                       // every logo's responses fit the formula's preconditions (finite, floorResp > 0)
 };
 
 // kernel launcher (eval_fused_kernels.hip).  dnframes (device, optional): the number of frames actually present (<= nframes,

@@ -53,6 +53,20 @@ namespace amt {
 
 namespace {
 int lds_pitch(int w) { return ((w + 31) & ~31) + 8; }
+
+// The composite of a flat level c with the logo, (8 c - 255 b) / a (or 8 c where a <= 0: AddLogo, LogoScan.hpp:320-333), is affine in c
+// at every pixel, and CalcCorrelation5x5 is linear in its window: a mask pixel's response on level c is P + Q c in real arithmetic, and
+// the reference's table holds |that| with the rounding of its fp32 evaluation.  Least-squares line through the 32 signed responses.
+void fit_response(const float* resp32, float& P, float& Q)
+{
+    double sy = 0, sxy = 0;
+    for (int c = 0; c < 32; ++c) { sy += resp32[c]; sxy += (c - 15.5) * resp32[c]; }
+    const double q = sxy / 2728.0;                      // sum (c - 15.5)^2, c = 0..31
+    Q = (float)q;
+    P = (float)(sy / 32.0 - q * 15.5);
+}
+// |P + Q c| as the linear kernel forms it: one fp32 FMA of the bin number
+float formula_response(float P, float Q, int c) { return std::fabs(std::fmaf(Q, (float)c, P)); }
 }
 
 EvalEngine::EvalEngine(AmtGpuContext* ctx, std::vector<EvalLogoSpec> specs, std::vector<float> fades, bool take_abs,
@@ -262,16 +276,17 @@ void EvalEngine::ensure_tiles()
     ctx_->bind();
     const int nl = (int)specs_.size();
     std::vector<TileLogoDev> hl(nl);
-    d_tkp_.resize(nl); d_tsc_.resize(nl); d_tinfo_.resize(nl); d_tiles_.resize(nl); d_tbands_.resize(nl); d_tlist_.resize(nl);
+    d_tkp_.resize(nl); d_tsc_.resize(nl); d_tpq_.resize(nl); d_tinfo_.resize(nl); d_tiles_.resize(nl); d_tbands_.resize(nl); d_tlist_.resize(nl);
     for (int i = 0; i < nl; ++i) {
         const EvalLogoSpec& S = specs_[i];
         const MaskTables& T = S.tables;
         const TilePlan P = build_tile_plan(T.pos, T.count, S.planes.w, S.planes.h);
         const size_t ns = (size_t)P.nslots();
-        std::vector<float2> kp(13 * ns, float2{0.0f, 0.0f}), sc((size_t)kNumBins * ns, float2{0.0f, 0.0f});
+        std::vector<float2> kp(13 * ns, float2{0.0f, 0.0f}), sc((size_t)kNumBins * ns, float2{0.0f, 0.0f}), pq(ns, float2{0.0f, 0.0f});
         for (size_t s = 0; s < ns; ++s) {
             const int m = P.slot_pixel[s];
-            if (m < 0) continue;
+            if (m < 0) continue;                               // (an idle lane: zero taps and a zero response -> its terms are 0 / floorResp)
+            fit_response(&T.resp[(size_t)m * 32], pq[s].x, pq[s].y);
             const float* k = &T.kernels[(size_t)m * 25];
             float ksum = 0.0f;
             for (int t = 0; t < 25; ++t) ksum += k[t];
@@ -281,14 +296,15 @@ void EvalEngine::ensure_tiles()
         }
         d_tkp_[i].upload(kp, ctx_->stream);
         d_tsc_[i].upload(sc, ctx_->stream);
+        d_tpq_[i].upload(pq, ctx_->stream);
         d_tinfo_[i].upload(P.sinfo, ctx_->stream);
         d_tiles_[i].upload(P.tiles, ctx_->stream);
         d_tbands_[i].upload(P.bands, ctx_->stream);
         std::vector<int> tlist;
         for (size_t t = 0; t < P.tiles.size(); ++t) if (P.tiles[t].npix > 0) tlist.push_back((int)t);
         d_tlist_[i].upload(tlist, ctx_->stream);
-        hl[i] = TileLogoDev{d_tkp_[i].get(), d_tsc_[i].get(), d_tinfo_[i].get(), d_tiles_[i].get(), d_tbands_[i].get(), d_tlist_[i].get(),
-                            (int)P.bands.size(), (int)ns, (int)tlist.size()};
+        hl[i] = TileLogoDev{d_tkp_[i].get(), d_tsc_[i].get(), d_tpq_[i].get(), d_tinfo_[i].get(), d_tiles_[i].get(), d_tbands_[i].get(), d_tlist_[i].get(),
+                            (int)P.bands.size(), (int)ns, (int)tlist.size(), T.floorResp};
     }
     d_tls_.upload(hl, ctx_->stream);
     tiles_ready_ = true;
@@ -301,7 +317,8 @@ void EvalEngine::ensure_linear()
 {
     if (linear_ready_) return;
     const int nl = (int)specs_.size();
-    lin_err_corr_.assign(nl, 0.0); lin_err_sum_.assign(nl, 0.0);
+    lin_err_corr_.assign(nl, 0.0); lin_err_sum_.assign(nl, 0.0); lin_err_formula_.assign(nl, 0.0);
+    lin_formula_ok_ = true;
     double vunit = 1.0;
     for (int i = 0; i < nl; ++i) {
         const EvalLogoSpec& S = specs_[i];
@@ -323,16 +340,38 @@ void EvalEngine::ensure_linear()
             if (!(ab < 1e30)) throw std::runtime_error("logo coefficients are not finite: the linear mode has no error bound for them");   // (NaN fails the comparison)
             vunit = std::max(vunit, ab);
         }
-        double ecorr = 0, tsum = 0;
+        // ---- the scale of a term.  The reference looks {scale, scale2} = {1 / r, min(1, r / L)} up by bin, r = |response on that flat level|,
+        // L = floorResp, and forms  t = clamp(x * scale, -1, 1) * scale2  (LogoScan.hpp:302-308), which is  clamp(x, -r, r) / max(r, L).
+        // The linear kernel forms r' = |fma(Q, bin, P)| from the pixel's fitted line (fit_response) and  t' = med3(x, -r', r') * rcp(max(r', L)):
+        // no gather.  Both are odd, monotone and piecewise linear in x with breakpoints at r and r': sup_x |t - t'| is reached at a
+        // breakpoint or at infinity, and is evaluated HERE for every (pixel, bin) from the reference's own table floats and the kernel's
+        // own fp32 r' (std::fmaf is the device's v_fma_f32) -- no estimate.  v_rcp_f32 is good to 1 ulp and the product rounds once: 4 u t'.
+        const double L = T.floorResp;
+        if (!(L > 1e-20 && L < 1e30) || T.resp.size() != (size_t)T.count * 32) lin_formula_ok_ = false;
+        double ecorr = 0, tsum = 0, eformula = 0;
         for (int m = 0; m < T.count; ++m) {
             double sk = 0;
             for (int t = 0; t < 25; ++t) sk += std::fabs(T.kernels[(size_t)m * 25 + t]);
-            double smax = 0, s2max = 0;
+            double smax = 0, s2max = 0, devmax = 0;
+            float Pf = 0.0f, Qf = 0.0f;
+            if (lin_formula_ok_) fit_response(&T.resp[(size_t)m * 32], Pf, Qf);
+            if (!(std::fabs(Pf) < 1e30f && std::fabs(Qf) < 1e30f)) lin_formula_ok_ = false;
             for (int c = 0; c < kNumBins; ++c) {
                 const double sc = std::fabs(T.scales[((size_t)m * 32 + c) * 2]), s2 = std::fabs(T.scales[((size_t)m * 32 + c) * 2 + 1]);
                 smax = std::max(smax, sc * s2);
                 s2max = std::max(s2max, s2);
+                if (!lin_formula_ok_) continue;
+                const double rk = formula_response(Pf, Qf, c), dk = std::max(rk, L);
+                const auto tref = [&](double x) { return std::min(1.0, x * sc) * s2; };      // x >= 0
+                const auto tker = [&](double x) { return std::min(x, rk) / dk; };
+                double dev = std::fabs((sc > 0 ? s2 : 0.0) - rk / dk);                        // x -> infinity
+                dev = std::max(dev, std::fabs(tref(rk) - tker(rk)));
+                if (sc > 0) dev = std::max(dev, std::fabs(tref(1.0 / sc) - tker(1.0 / sc)));
+                devmax = std::max(devmax, dev);
+                smax = std::max(smax, 1.0 / dk);                                              // the kernel's own slope in x
+                s2max = std::max(s2max, rk / dk);
             }
+            eformula += devmax;
             // (+ 24 u v sum|k|: the host's fp32 sum of the 25 taps that multiplies the mean, kp[12].y in ensure_tiles, carries up to
             // 24 roundings of partial sums <= sum|k|, times a mean <= v)
             ecorr += smax * sk * (58.0 + 24.0);
@@ -340,7 +379,8 @@ void EvalEngine::ensure_linear()
         }
         const double black = std::max(1e-30, (double)std::fabs(T.blackScore));
         lin_err_corr_[i] = ecorr / black;                                       // x u x v
-        lin_err_sum_[i] = ((double)T.count + 40.0) * tsum / black + 8.0;        // x u  (+ the final division / abs, results are O(1))
+        lin_err_sum_[i] = ((double)T.count + 44.0) * tsum / black + 8.0;        // x u  (+ the final division / abs, results are O(1); + 4 u |t'| for rcp and its product)
+        lin_err_formula_[i] = eformula / black;
     }
     // v, the bound on window values in units of maxv: a blend with fades in [0, 1] is convex, so max(1, |a| + |b|) holds; fades
     // outside that range (ReMakeLogo's reach 1.9: |f| + |1 - f| <= 3) get a factor 2
@@ -364,7 +404,7 @@ float EvalEngine::linear_error_bound(int logo, int bits) const
 {
     const_cast<EvalEngine*>(this)->ensure_linear();
     const double u = 1.0 / 16777216.0, maxv = (double)((1 << bits) - 1);
-    return (float)(1.25 * u * (lin_err_corr_[logo] * vmax_unit_ * maxv + lin_err_sum_[logo]));
+    return (float)(1.25 * (u * (lin_err_corr_[logo] * vmax_unit_ * maxv + lin_err_sum_[logo]) + lin_err_formula_[logo]));
 }
 
 void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout, const int* dframe_map)
@@ -376,6 +416,7 @@ void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitc
     // the linear kernel is written for AMTAnalyzeLogo's fades: eleven, from exactly 0 to exactly 1
     if ((int)fades_.size() != 11 || fades_.front() != 0.0f || fades_.back() != 1.0f || !tiles_usable(pitch * es)) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }
     ensure_linear();
+    if (!lin_formula_ok_) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }      // (a degenerate logo: the exact kernel)
     ensure_tiles();
     ctx_->bind();
     if (frame_stride_bytes % es) throw std::runtime_error("frame stride not a multiple of the sample size");

@@ -32,23 +32,15 @@ namespace amt {
 using namespace lin;
 using namespace tile;
 
-#ifndef AMT_LIN_FLUSH_FIRST
-#define AMT_LIN_FLUSH_FIRST 1
-#endif
-#ifndef AMT_LIN_AB_LDS
-#define AMT_LIN_AB_LDS 0
-#endif
 #ifndef AMT_LIN_WAVES
 #define AMT_LIN_WAVES 4
 #endif
-constexpr int kLinWaves = AMT_LIN_WAVES;     // waves per workgroup: one per SIMD, so that three workgroups always fit a CU at <= 168 registers
+constexpr int kLinWaves = AMT_LIN_WAVES;     // waves per workgroup: one per SIMD
 constexpr int kLinWgThreads = kLinWaves * 64;
 // A wave's running sums of one frame: 48 bytes per quad of lanes (twelve floats: the eleven fades' sums over the quad's mask pixels),
 // i.e. 16 partial sums per fade that are added up at the very end.  (Tried and not kept: the same sums on the matrix pipe,
 // v_mfma_f32_16x16x4_f32 with row selectors -- tools/ubench/mfma_rowsum.hip, profiles/r03_notes.md.)
 constexpr int kLinAccFrameBytes = 16 * 48;
-
-__device__ __forceinline__ int clamp_bin(int b) { return min(max(b, 0), 31); }      // (v_med3_i32)
 
 // mean of the blended window exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it (LogoScan.hpp:244-251, ComputeKernel.cpp:88-98):
 // the uncommon path of the bin select.  Two LDS round trips (rows 0-2, rows 3-4) instead of one per row: what this path costs
@@ -99,21 +91,17 @@ struct LinLaunch {
 #ifndef AMT_LIN_OCC
 #define AMT_LIN_OCC 4
 #endif
-#define AMT_LIN_OCC_ATTR __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC, AMT_LIN_OCC)))
-// NF fades (11 for AMTAnalyzeLogo, the only caller of this mode: no per-fade branches; NF == 0 would take nfades <= kLinMaxFades
-// at run time -- kept in the source for the record, not instantiated: it spills scalar registers).
+#ifndef AMT_LIN_OCC16
+#define AMT_LIN_OCC16 4
+#endif
+// NF fades (11 for AMTAnalyzeLogo, the only caller of this mode: no per-fade branches)
 template <typename pix_t, int NF>
 __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 {
-    constexpr int NFMAX = NF > 0 ? NF : kLinMaxFades;
-    const int nfades = NF > 0 ? NF : A.nfades;
+    static_assert(NF >= 3 && NF <= 12, "the running sums hold rows 0..11 of the 16x16 accumulator");
     extern __shared__ float lds[];
-    // AMT_LIN_AB_LDS = 1 (rounds 3-4): a second plane per wave holds the tile's {a, b*maxv} -- the kernel was short of registers.  Since the
-    // taps' broadcasts moved into the multiply-adds it has 36 to spare: the coefficients of a lane's two staging units stay in 16 registers,
-    // two 16-byte LDS reads per unit and frame less in a kernel that the LDS bounds, and half the plane memory (more frames per workgroup).
-    constexpr int kPlanesPerWave = AMT_LIN_AB_LDS ? 2 : 1;
-    f2* const planes = reinterpret_cast<f2*>(lds);                 // [kLinWaves][kPlanesPerWave][kTileCap] a wave's own tile: {s, bg} (and the logo's {a, b*maxv})
-    float* const wacc = lds + kLinWaves * kPlanesPerWave * kTileCap * 2;   // [kLinWaves][G][48 lanes][4] a wave's running sums (kLinAccFrameBytes per frame)
+    f2* const planes = reinterpret_cast<f2*>(lds);                 // [kLinWaves][kTileCap] a wave's own tile: {s, bg}
+    float* const wacc = lds + kLinWaves * kTileCap * 2;            // [kLinWaves][G][48 lanes][4] a wave's running sums (kLinAccFrameBytes per frame)
 
     const int G = A.G;
     const int logo = blockIdx.x / A.ngroups;
@@ -126,20 +114,21 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     const TileLogoDev* const Xp = A.tls + logo;
     const int ntl = Xp->ntlist;                                    // tiles that hold pixels
     const const_int_ptr tlist = (const_int_ptr)Xp->tlist;
-    const gptr_t gSc = (gptr_t)Xp->sc;
-    const unsigned nslots8 = (unsigned)Xp->nslots * 8u;
+    const gptr_t gPq = (gptr_t)Xp->pq;
+    const float floorResp = Xp->floorResp;                         // (wave-uniform) L: scale2 = min(1, r / L)
     const const_tile_ptr tiles = (const_tile_ptr)Xp->tiles;
-    // Bin edges in fixed point, Q = 2^qlog2 units per gray level.  qd = floor(mean * Q + dq) with dq = e + 1, e = ceil(bin_eps * Q):
-    // an edge within bin_eps ABOVE the mean has been crossed by qd (low bits in [0, dq]), one within bin_eps BELOW leaves low bits
-    // in [dq - 1, dq + e]; so "low bits <= qwin = dq + e" flags every (pixel, fade) whose exact mean might fall in another bin, and for
-    // all others qd >> (qlog2 + 3) is the bin of the exact mean.
+    // Bin edges in fixed point.  Q = 2^qlog2 units per gray level; a bin is 8 gray levels = 2^(qlog2+3) units = one unit of y below:
+    // y = (mean * Q + dq) / 2^(qlog2+3) with dq = e + 1, e = ceil(bin_eps * Q).  floor(y) is the bin of mean + dq / Q; an edge within bin_eps
+    // ABOVE the mean has been crossed by y (fract(y) * 2^(qlog2+3) in [0, dq]), one within bin_eps BELOW it leaves fract(y) * 2^(qlog2+3)
+    // in [dq - 1, dq + e + 1): so "fract(y) < ywin = (dq + e + 1) / 2^(qlog2+3)" flags every (pixel, fade) whose exact mean might fall in
+    // another bin, and for all others floor(y) is the bin of the exact mean.  Scaling by powers of two is exact, so y comes straight out
+    // of the multiply-add that interpolates the mean (the scale sits in its operands).
     const float qscale = __builtin_amdgcn_ldexpf(1.0f, A.qlog2);
     const int qe = (int)__builtin_ceilf(A.bin_eps * qscale);
     const int dq = qe + 1;
-    const unsigned qwin = (unsigned)(dq + qe);
-    const int qshift = A.qlog2 + 3;
-    const unsigned qmask = (1u << qshift) - 1u;
-    const float dqf = (float)dq;
+    const float yscale = __builtin_amdgcn_ldexpf(1.0f, -3);                          // mean (gray levels) -> bins
+    const float ydq = __builtin_amdgcn_ldexpf((float)dq, -(A.qlog2 + 3));
+    const float ywin = __builtin_amdgcn_ldexpf((float)(dq + qe + 1), -(A.qlog2 + 3));
 
 #ifdef AMT_LIN_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -149,27 +138,27 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #define AMT_LTICK(k) do { } while (0)
 #endif
     // the fades, wave-uniform (scalar registers)
-    float fd[NFMAX];
+    float fd[NF];
     {
         typedef const __attribute__((address_space(4))) float* const_float_ptr;
         const const_float_ptr fp = (const_float_ptr)(A.fades + A.fade0);
 #pragma unroll
-        for (int f = 0; f < NFMAX; ++f) fd[f] = fp[min(f, nfades - 1)];
+        for (int f = 0; f < NF; ++f) fd[f] = fp[f];
     }
-    static_assert(NFMAX <= 12, "the running sums hold rows 0..11 of the 16x16 accumulator");
     float* const myacc = wacc + wave * G * (kLinAccFrameBytes / 4);
     for (int i = lane; i < G * (kLinAccFrameBytes / 4); i += 64) myacc[i] = 0.0f;
     const unsigned myacc_base = __builtin_amdgcn_readfirstlane(lds_address(myacc));
     // the wave's own copy of the fades, lane f <-> fade f (read back by the bin fix-up; a wave's LDS operations complete in order)
     float* const myfades = wacc + kLinWaves * G * (kLinAccFrameBytes / 4) + wave * 16;
-    if (lane < 16) myfades[lane] = A.fades[A.fade0 + min(lane, nfades - 1)];
+    if (lane < 16) myfades[lane] = A.fades[A.fade0 + min(lane, NF - 1)];
     const unsigned myfades_base = __builtin_amdgcn_readfirstlane(lds_address(myfades));
 
-    f2* const myplane = planes + wave * kPlanesPerWave * kTileCap;
+    f2* const myplane = planes + wave * kTileCap;
     const unsigned plane_base = lds_address(myplane);
-    TileStager<pix_t, AMT_LIN_AB_LDS != 0, true> st;
-    st.init(Lp, A.pitch, A.maxv, myplane, AMT_LIN_AB_LDS ? myplane + kTileCap : nullptr);
+    TileStager<pix_t, false, true> st;
+    st.init(Lp, A.pitch, A.maxv, myplane, nullptr);
     TilePixel px;
+    f2 PQ;                                                       // this lane's pixel: its response on flat level c is |PQ.x + PQ.y * c|
     TileDesc T;
 
     // this wave's tiles: entries wave, wave + 4, ... of the logo's list of tiles.  (i, g) = (list position, frame) of an iteration
@@ -178,17 +167,16 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         g = last ? 0 : g + 1;
         i = last ? i + kLinWaves : i;
     };
-    // Pipeline: while iteration i is evaluated, the raw samples of i + 1 sit in registers, those of i + 2 travel, and so do the
-    // scale gathers of i - 1.
+    // Pipeline: while iteration i is evaluated, the raw samples of i + 1 sit in registers and those of i + 2 travel.
     //   A. window reads of i from the plane, means and correlations of s and bg
-    //   D. the 11 terms of iteration i - 1 (its gathers have had a whole iteration to arrive), their sums over the wave, added to
-    //      the wave's running sums
     //   B. the fades' bins (a mean next to a bin edge: the reference's exact mean decides, rare)
-    //   E. the 11 gathers of i go straight into the registers the terms of i - 1 were read from
-    //   C. raw(i + 1) -> plane; request raw(i + 2)   (the pixel / taps of i + 1, if its tile is a new one, are requested before D)
+    //   T. the 11 terms, their sums over the quads of lanes, added to the wave's running sums of the frame in LDS.  No table is looked
+    //      up: the scale of a term is a function of the bin number and two per-pixel constants (see "T." below)
+    //   C. raw(i + 1) -> plane; request raw(i + 2)   (the pixel / taps of i + 1, if its tile is a new one, are requested first)
     int i0 = wave, g0 = 0;                                       // iteration i
     int i1 = i0, g1 = 0;                                         // iteration i + 1 (its raw samples are in the registers)
     int iu = -1;                                                 // the list position whose tile the staging units describe
+    PQ = f2{0.0f, 0.0f};
     if (i0 < ntl) {
         const int t0 = tlist[i0];
         fetch_tile(T, tiles + t0);
@@ -197,6 +185,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0));
         asm volatile("" ::: "memory");                             // (see eval_pair_kernels.hip: the raw loads stay ahead of the tap loads)
         px.load(Xp, (unsigned)t0 * 64u + (unsigned)lane, T, plane_base);
+        PQ = gld<f2>(gPq, px.slot8);
         st.convert();
         // (the first taps have arrived before the loop: the wait the compiler places at the loop head is the merge of this path and
         //  the back edge, and on the back edge the taps of a new tile are the OLDEST loads in flight -- see step B')
@@ -208,54 +197,8 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + g1));
         }
     }
-    // the pending iteration: scales (in flight), correlation of s and its slope over the fades, frame.  (Before the first one: zero
-    // scales, i.e. zero terms, added to frame 0 -- no branch around the flush, whose registers the gathers are issued into.)
-    f2 psc[NFMAX];
-    float pR0 = 0.0f, pdR = 0.0f;
-    int pg = 0;                                                  // (scalar)
-#pragma unroll
-    for (int f = 0; f < NFMAX; ++f) psc[f] = f2{0.0f, 0.0f};
-    // Sum over the wave: two DPP steps add the four lanes of every quad, lane 0 of the quad adds the eleven sums to the
-    // quad's running sums of the frame in LDS (48 bytes per quad: 16 partial sums per fade, added up at the very end).  A lane's
-    // cells are its own and LDS operations of a wave complete in order: no barrier, no atomics.
-    auto flush_terms = [&]() {
-        typedef __attribute__((address_space(3))) f4* lds_quad;
-        const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)pg * (unsigned)kLinAccFrameBytes + (unsigned)(lane >> 2) * 48u);
-        // (four fades at a time, fenced: left alone the scheduler computes all eleven terms first -- eleven registers too many)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float term[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 4 * q + r;
-                if (f < NFMAX) {
-#ifdef AMT_LIN_GATHER4
-                    float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * __builtin_amdgcn_rcpf(psc[f].x + 2.0f), -1.0f, 1.0f) * __builtin_fminf(1.0f, psc[f].x * 0.37f);
-#else
-                    float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(fd[f], pdR, pR0) * psc[f].x, -1.0f, 1.0f) * psc[f].y;   // (LogoScan.hpp:305-308)
-#endif
-                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
-                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
-                    asm volatile("" : "+v"(t));       // (left alone the add sinks into the lane-0 branch below and its DPP operand stays a v_mov_b32_dpp)
-                    term[r] = t;
-                } else term[r] = 0.0f;
-            }
-            if ((lane & 3) == 0) {
-                const f4 o = cell[q];
-                cell[q] = f4{o[0] + term[0], o[1] + term[1], o[2] + term[2], o[3] + term[3]};
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
     while (i0 < ntl) {
         AMT_LTICK(0);
-#if AMT_LIN_FLUSH_FIRST && !defined(AMT_LIN_NO_FLUSH)
-        // The previous iteration's terms leave their 22 registers BEFORE the window evaluation, the loop's register peak: 148 -> 126 VGPRs,
-        // i.e. FOUR waves per SIMD (the kernel waits more than it issues: ~40 % of the issue slots and of the LDS cycles used at three).
-        // The price -- less time for the scale gathers to arrive: at three waves 4.97 ms against 4.73 per 16 448 frames -- is more than
-        // paid back by the fourth wave: 4.58 (profiles/r05_notes.md section 9).
-        flush_terms();
-#endif
         // ---- A. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
         // (the taps' {k, k} broadcasts live in the multiply-adds' op_sel: eval_tile_stage.h pk_fma_tap)
         f2 R, M;
@@ -269,38 +212,32 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #endif
         }
         AMT_LTICK(2);
-        // ---- D. the previous iteration's terms (their scales arrived long ago) leave their registers to this iteration's gathers ----
-#if !defined(AMT_LIN_NO_FLUSH) && !AMT_LIN_FLUSH_FIRST
-        flush_terms();
-#endif
-        AMT_LTICK(4);
-        // ---- B. bins.  qd = interpolated mean in 1/4096 units + dq: its low 15 bits are the distance (+ dq) from the bin edge below,
-        //      qd >> 15 the bin.  The bin select is discontinuous (LogoScan.hpp:304): for a mean within dq of an edge -- about 1e-4
-        //      of all (pixel, fade) pairs -- the mean is evaluated exactly as the reference does and ITS bin is taken ----
-        const float m0q = M.x * qscale, m1q = M.y * qscale;         // (exact: powers of two)
-        const float dMq = m1q - m0q;
-        const float m0qd = m0q + dqf;                               // (the window's half-width rides in the multiply-add's addend: one rounding
+        // ---- B. bins, as floats: y = position of the interpolated mean in bins (+ the window's half-width), floor(y) its bin, fract(y)
+        //      its distance from the bin edge below.  The bin select is discontinuous (LogoScan.hpp:304): for a mean within bin_eps of an
+        //      edge -- about 3e-4 of all (pixel, fade) pairs -- the mean is evaluated exactly as the reference does and ITS bin is taken ----
+        const float y0 = M.x * yscale, y1 = M.y * yscale;           // (exact: powers of two)
+        const float dy = y1 - y0;
+        const float y0d = y0 + ydq;                                 // (the window's half-width rides in the multiply-add's addend: one rounding
                                                                     //  for the sum, one for the FMA -- the two the bound counted for FMA and add)
-        unsigned emin = qmask;
-        const unsigned slot8 = px.slotbase8 + (unsigned)lane * 8u;     // (not kept: one instruction instead of a register)
-        unsigned goff[NFMAX];                                      // byte offset of the fade's {scale, scale2} in the slot table
+        float emin = 1.0f;
+        float binf[NF];                                            // the fade's bin, 0..31
         // Fade 0 blends to s and fade 1 to bg exactly (0 * x + y == y), and M holds their means in the reference's own order (column
         // sums, hsum, /25: window_eval_streamed): those two bins are the reference's without any test.  (The caller guarantees that the
         // first fade is 0 and the last is 1.)  It matters: mean(s) is an integer / 25 and sits exactly ON a bin edge once in 200 pixels.
 #pragma unroll
-        for (int f = 0; f < NFMAX; ++f) {
-            const bool end = f == 0 || f == NFMAX - 1;
-            const int qd = (int)(end ? (f == 0 ? m0q : m1q) : __builtin_fmaf(fd[f], dMq, m0qd));
-            if (!end) emin = min(emin, (unsigned)qd & qmask);
-            goff[f] = __umul24((unsigned)clamp_bin(qd >> qshift), nslots8) + slot8;
+        for (int f = 0; f < NF; ++f) {
+            const bool end = f == 0 || f == NF - 1;
+            const float y = end ? (f == 0 ? y0 : y1) : __builtin_fmaf(fd[f], dy, y0d);
+            if (!end) emin = __builtin_fminf(emin, __builtin_amdgcn_fractf(y));
+            binf[f] = __builtin_amdgcn_fmed3f(__builtin_floorf(y), 0.0f, 31.0f);       // (int)clamp(mean, 0, 255) >> 3; a NaN mean gives bin 0 like the reference's (int)NaN = INT_MIN
         }
-        // (uncommon -- one wave iteration in ten has such a pixel -- and kept small in code and registers: rolled loops; unrolled, the
-        //  eleven inlined window re-reads cost the whole kernel 40 registers.  The fades come out of a vector register by v_readlane,
-        //  filled from the wave's copy in LDS: a scalar load per fade would put eleven memory latencies in a row.)
+        // (uncommon -- one wave iteration in five has such a pixel -- and kept small in code and registers: a rolled loop; unrolled, the
+        //  inlined window re-reads cost the whole kernel its occupancy.  The fades come out of a vector register by v_readlane,
+        //  filled from the wave's copy in LDS: a scalar load per fade would put memory latencies in a row.)
 #ifdef AMT_LIN_NO_FIXUP
         const bool near_edge = false;
 #else
-        const bool near_edge = px.act && emin <= qwin;
+        const bool near_edge = px.act && emin < ywin;
 #endif
         if (__builtin_amdgcn_ballot_w64(near_edge) != 0) {         // wave-uniform: every lane reads the fades (v_readlane needs lanes 0..10)
             unsigned wrow[5];
@@ -309,35 +246,64 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             asm volatile("" : "+v"(lane_here));                    //  reload waits for every load in flight)
             const float fadev = *(const __attribute__((address_space(3))) float*)(unsigned long long)(myfades_base + (unsigned)(lane_here & 15) * 4u);
 #pragma unroll 1
-            for (int f = 1; f < nfades - 1; ++f) {
+            for (int f = 1; f < NF - 1; ++f) {
                 const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fadev), f));
-                const int qd = (int)__builtin_fmaf(fade, dMq, m0qd);
-                if (near_edge && ((unsigned)qd & qmask) <= qwin) {
-                    const unsigned go = __umul24((unsigned)score_bin_dev(exact_blend_mean_2trips(wrow, fade)), nslots8) + px.slotbase8 + (unsigned)lane * 8u;
+                if (near_edge && __builtin_amdgcn_fractf(__builtin_fmaf(fade, dy, y0d)) < ywin) {
+                    const float nb = (float)score_bin_dev(exact_blend_mean_2trips(wrow, fade));
 #pragma unroll
-                    for (int ff = 0; ff < NFMAX; ++ff) goff[ff] = ff == f ? go : goff[ff];
+                    for (int ff = 0; ff < NF; ++ff) binf[ff] = ff == f ? nb : binf[ff];
                 }
             }
         }
         AMT_LTICK(3);
-        // ---- B'. a new tile next: its pixel and taps are requested BEFORE the gathers and the raw samples -- vector-memory loads
-        //      return in order, and the taps are what the next iteration needs first ----
+        // ---- B'. a new tile next: its pixel and taps are requested BEFORE the raw samples -- vector-memory loads return in order, and
+        //      the taps are what the next iteration needs first ----
+        f2 PQn = PQ;
         if (i1 < ntl && i1 != i0) {
             const int t1 = tlist[i1];
             TileDesc Tn;
             fetch_tile(Tn, tiles + t1);
             px.load(Xp, (unsigned)t1 * 64u + (unsigned)lane, Tn, plane_base);
+            PQn = gld<f2>(gPq, px.slot8);                           // (this iteration's terms below still need the CURRENT pixel's response line)
         }
-        // ---- E. this iteration's gathers, into the registers the previous terms were read from ----
+        // ---- T. the terms.  The reference looks {scale, scale2} = {1 / r, min(1, r / L)} up by bin, r = |response of the pixel's kernel on
+        //      that flat level| (LogoScan.hpp:190-207), and forms clamp(x * scale, -1, 1) * scale2 (:305-308) = clamp(x, -r, r) / max(r, L).
+        //      r is |P + Q bin| up to the rounding of the table's fp32 evaluation (the composite of a flat level is affine in the level):
+        //      one multiply-add instead of an 8-byte gather per fade; what the difference can do to a term is computed per (pixel, bin)
+        //      on the host and is part of the error bound (eval_engine.hip ensure_linear).  Then the sum over each quad of lanes by two
+        //      DPP steps; lane 0 of the quad adds the sums to the quad's running sums of the frame in LDS (48 bytes per quad: 16 partial
+        //      sums per fade, added up at the very end).  A lane's cells are its own and LDS operations of a wave complete in order: no
+        //      barrier, no atomics. ----
+#ifndef AMT_LIN_NO_FLUSH
+        {
+            typedef __attribute__((address_space(3))) f4* lds_quad;
+            const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)g0 * (unsigned)kLinAccFrameBytes + (unsigned)(lane >> 2) * 48u);
+            const float R0 = R.x, dR = R.y - R.x;
 #pragma unroll
-#ifdef AMT_LIN_NO_GATHER
-        for (int f = 0; f < NFMAX; ++f) { asm volatile("" :: "v"(goff[f])); psc[f] = f2{1e-3f, 1.0f}; }
-#elif defined(AMT_LIN_GATHER4)                                 // (ablation, wrong results: what 4-byte gathers from a table half the size would cost)
-        for (int f = 0; f < NFMAX; ++f) { const float c = gld<float>(gSc, goff[f] >> 1); psc[f] = f2{c, c}; }
-#else
-        for (int f = 0; f < NFMAX; ++f) psc[f] = gld<f2>(gSc, goff[f]);
+            for (int q = 0; q < 3; ++q) {
+                float term[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 4 * q + r;
+                    if (f < NF) {
+                        const float resp = __builtin_fabsf(__builtin_fmaf(PQ.y, binf[f], PQ.x));
+                        const float x = __builtin_fmaf(fd[f], dR, R0);
+                        float t = __builtin_amdgcn_fmed3f(x, -resp, resp) * __builtin_amdgcn_rcpf(__builtin_fmaxf(resp, floorResp));
+                        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+                        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+                        asm volatile("" : "+v"(t));       // (left alone the add sinks into the lane-0 branch below and its DPP operand stays a v_mov_b32_dpp)
+                        term[r] = t;
+                    } else term[r] = 0.0f;
+                }
+                if ((lane & 3) == 0) {
+                    const f4 o = cell[q];
+                    cell[q] = f4{o[0] + term[0], o[1] + term[1], o[2] + term[2], o[3] + term[3]};
+                }
+            }
+        }
 #endif
-        pR0 = R.x; pdR = R.y - R.x; pg = g0;
+        AMT_LTICK(4);
+        PQ = PQn;
         AMT_LTICK(5);
         // ---- C. the next iteration's tile into the plane, its pixel if the tile changes, the raw samples of the one after ----
         if (i1 < ntl) {
@@ -359,7 +325,6 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         i0 = i1; g0 = g1;
         advance(i1, g1);
     }
-    flush_terms();
     __syncthreads();
 #ifdef AMT_LIN_TIMING
     if (lane == 0 && blockIdx.x == gridDim.x / 6 && wave < 4) {      // a workgroup of logo 0 (the deint logo)
@@ -370,8 +335,8 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     // the waves' sums, in order: per wave the 16 partial sums of a fade, front to back
     // (the thread index is re-derived: kept across the loop it would be one register too many)
     const int tid_end = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (tid_end < gcount * nfades) {
-        const int gg = tid_end / nfades, f = tid_end - gg * nfades;
+    if (tid_end < gcount * NF) {
+        const int gg = tid_end / NF, f = tid_end - gg * NF;
         float r = 0.0f;
         for (int q = 0; q < kLinWaves; ++q) {
             const float* const cells = wacc + (q * G + gg) * (kLinAccFrameBytes / 4) + f;      // quad j: 12 floats at 12 j
@@ -386,14 +351,10 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     }
 }
 
-// Four waves per SIMD (<= 128 registers) for both sample sizes: 126 registers at 8 bits; the 16-bit kernel, whose raw samples in flight take
-// twice the room, parks ONE value in scratch before the loop and fetches it back after it (tests/test_isa_guards.py: nothing inside).
+// Four waves per SIMD (<= 128 registers) for both sample sizes.
 // (Inside the loop a spilled register would be reloaded with a wait for EVERY load in flight -- the pipeline's whole point.)
-__global__ __launch_bounds__(kLinWgThreads) AMT_LIN_OCC_ATTR
+__global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC, AMT_LIN_OCC)))
 void logo_eval_linear_kernel(const LinLaunch A) { logo_eval_linear_body<uint8_t, 11>(A); }
-#ifndef AMT_LIN_OCC16
-#define AMT_LIN_OCC16 4
-#endif
 __global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC16, AMT_LIN_OCC16)))
 void logo_eval_linear_kernel16(const LinLaunch A) { logo_eval_linear_body<uint16_t, 11>(A); }
 
@@ -412,8 +373,8 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     A.nfades = nfades; A.fade0 = fade0;
     A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
     A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs; A.bin_eps = bin_eps; A.qlog2 = qlog2;
-    const size_t lds = (size_t)kLinWaves * (AMT_LIN_AB_LDS ? 2 : 1) * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * 16 * sizeof(float);
-    if (lds * AMT_LIN_OCC > 160 * 1024) return hipErrorInvalidValue;      // (the workgroups that share a CU must fit its LDS)
+    const size_t lds = (size_t)kLinWaves * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * 16 * sizeof(float);
+    if (lds * (bits > 8 ? AMT_LIN_OCC16 : AMT_LIN_OCC) > 160 * 1024) return hipErrorInvalidValue;      // (the workgroups that share a CU must fit its LDS)
     dim3 grid((unsigned)((long long)A.ngroups * nlogos));
     if (bits <= 8) hipLaunchKernelGGL(logo_eval_linear_kernel, grid, dim3(kLinWgThreads), lds, st, A);
     else hipLaunchKernelGGL(logo_eval_linear_kernel16, grid, dim3(kLinWgThreads), lds, st, A);

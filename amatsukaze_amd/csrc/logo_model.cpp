@@ -262,6 +262,7 @@ MaskTables build_mask_tables(const LogoPlanes& L, float maskratio)
     T.count = (int)T.pos.size();
     T.kernels.resize((size_t)T.count * 25);
     T.scales.assign((size_t)T.count * 64, 0.0f);
+    T.resp.assign((size_t)T.count * 32, 0.0f);
 
     // expected response of every kernel on every flat level; running mean in visiting order
     float total = 0.0f;
@@ -273,13 +274,16 @@ MaskTables build_mask_tables(const LogoPlanes& L, float maskratio)
         for (int c = 0; c < 32; ++c) {
             gather_window(level(c), w, x, y, v);
             float mean;
-            const float r = std::abs(corr5x5(k, v, &mean));
+            const float signedResp = corr5x5(k, v, &mean);
+            const float r = std::abs(signedResp);
+            T.resp[(size_t)n * 32 + c] = signedResp;
             T.scales[((size_t)n * 32 + c) * 2] = r;
             total += r;
         }
     }
     const float meanResp = total / (T.maskpixels * 32);
     const float floorResp = meanResp * 0.2f;
+    T.floorResp = floorResp;
     for (size_t i = 0; i < (size_t)T.count * 32; ++i) {
         const float r = T.scales[i * 2];
         T.scales[i * 2] = (r > 0) ? (1.0f / r) : 0.0f;

@@ -46,6 +46,10 @@ struct MaskTables {
     std::vector<uint32_t> pos;       // count: (y << 16) | x
     std::vector<float> kernels;      // count*25 (row-major 5x5, mean removed)
     std::vector<float> scales;       // count*32*{scale, scale2}
+    std::vector<float> resp;         // count*32: the SIGNED response of the pixel's kernel on flat level c (scale = 1 / |resp|); the
+                                     // composite of a flat level is affine in the level, so resp is P + Q c up to rounding -- what the
+                                     // linear analysis kernel evaluates instead of gathering scales (eval_engine.hip ensure_linear)
+    float floorResp = 0;             // limitCorr (LogoScan.hpp:203): scale2 = min(1, |resp| / floorResp)
     float blackScore = 0;
 };
 MaskTables build_mask_tables(const LogoPlanes& evalLogo, float maskratio);

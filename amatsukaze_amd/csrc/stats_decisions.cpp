@@ -63,6 +63,10 @@ void classify_cadence(const uint64_t* metrics, int nframes, int width, int heigh
     std::vector<uint64_t> motion_of(nframes);
     const uint64_t still = (uint64_t)width * height / 2;      // < 0.5 per pixel of field difference: nothing moves
     constexpr uint8_t kStill = 0xFF;                           // first pass: "nothing moves in this frame's window"
+    static_assert(kStill != kCadence60i && kStill != kCadence24p && kStill != kCadence30p, "the sentinel must not be a cadence");
+    // the first pass's classes live in buffers of this function: the caller's arrays only ever receive finished decisions (a worker
+    // that throws -- an allocation, a thread that cannot be started -- leaves them untouched, never holding the sentinel)
+    std::vector<uint8_t> cls1(nframes), ph1(nframes);
     // First pass, frame ranges in parallel: everything that depends on the frame's window only.  Second pass, in order: a still window
     // keeps the cadence of the frame before it (and advances its 3:2 phase).
     parallel_ranges(nframes, parallel_parts(nframes), [&](int lo, int hi, int) {
@@ -111,18 +115,15 @@ void classify_cadence(const uint64_t* metrics, int nframes, int width, int heigh
             else if (nC * 10 >= span * 7) { cls = kCadence30p; }
             else if (nDecided * 10 >= span * 7 && best * 10 >= span * 5) { cls = kCadence24p; ph = (uint8_t)((n - a + bestPhase) % 5); }
             else { cls = kCadence60i; }
-            cadence[n] = cls;
-            phase[n] = ph;
+            cls1[n] = cls;
+            ph1[n] = ph;
         }
     });
     uint8_t last = kCadence60i, lastPhase = 0;
     for (int n = 0; n < nframes; ++n) {
-        if (cadence[n] == kStill) {
-            cadence[n] = last;
-            phase[n] = last == kCadence24p ? (uint8_t)((lastPhase + 1) % 5) : 0;
-        }
-        last = cadence[n];
-        lastPhase = phase[n];
+        const bool keep = cls1[n] == kStill;
+        cadence[n] = last = keep ? last : cls1[n];
+        phase[n] = lastPhase = keep ? (last == kCadence24p ? (uint8_t)((lastPhase + 1) % 5) : (uint8_t)0) : ph1[n];
     }
 }
 

@@ -25,14 +25,9 @@
 
 namespace amt {
 
-#ifndef AMT_STATS_VG
-#define AMT_STATS_VG 1
-#endif
-// kStatVG > 1: the waves of a workgroup sit on top of one another (wave w owns tile VG * supertile + w of the same columns), so that a
-// tile's halo rows are rows a sibling wave reads at the same moment.  Measured: no gain over VG = 1 (the halo re-reads already hit the
-// XCD's L2 thanks to the tile order below); kept as a build knob.
-constexpr int kStatVG = AMT_STATS_VG;
-constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
+// (tried and closed, profiles/r04_notes.md: waves of a workgroup stacked on vertically adjacent tiles -- the halo re-reads already hit
+//  the XCD's L2 thanks to the tile order below -- and a third row set with the next frame's loads issued before the evaluation)
+constexpr int kStatThreads = 128;
 #ifndef AMT_STATS_ROWS
 #define AMT_STATS_ROWS 16
 #endif
@@ -41,9 +36,6 @@ constexpr int kStatThreads = kStatVG > 1 ? 64 * kStatVG : 128;
 #endif
 #ifndef AMT_STATS_COLB
 #define AMT_STATS_COLB 16
-#endif
-#ifndef AMT_STATS_PREFETCH
-#define AMT_STATS_PREFETCH 0
 #endif
 #ifndef AMT_STATS_LEAN
 #define AMT_STATS_LEAN 1
@@ -187,11 +179,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         if (i < P * G) { tile = b * P + i / G; col = (i % G) * 64 + lane; }
         else { const int sub = lane / r; tile = b * P + sub; col = sub < P ? G * 64 + (lane - sub * r) : cols; }
         xb = col < cols ? col * kStatColBytes : row_bytes;
-    } else if (kStatVG > 1) {
-        const int gid = wg * 64 + (threadIdx.x & 63);
-        const int st = gid / cols;
-        tile = st * kStatVG + (threadIdx.x >> 6);
-        xb = (gid - st * cols) * kStatColBytes;
     } else {
         const int gid = wg * kStatThreads + threadIdx.x;
         tile = gid / cols;
@@ -306,25 +293,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
         return ve;
     };
     const uint8_t* const before = n0 > 0 ? Y + (long long)(n0 - 1) * frame_stride : (prevY ? prevY : Y);
-#if AMT_STATS_PREFETCH
-    // three row sets in rotation: the loads of frame n + 1 are issued BEFORE frame n is evaluated, so that every wave always has a
-    // whole tile in flight
-    Chunk A[R], B[R], D[R];
-    load_rows(before, A);
-    load_rows(Y + (long long)n0 * frame_stride, B);
-    unsigned ve = vert_even(A);
-    for (int n = n0;;) {
-        if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, D);
-        ve = compute(B, A, n, ve);
-        if (++n >= n1) break;
-        if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, A);
-        ve = compute(D, B, n, ve);
-        if (++n >= n1) break;
-        if (n + 1 < n1) load_rows(Y + (long long)(n + 1) * frame_stride, B);
-        ve = compute(A, D, n, ve);
-        if (++n >= n1) break;
-    }
-#else
     // two row sets that swap roles every frame (the loop body holds two frames): copying cur -> prev was 4 R register moves per frame,
     // 7 % of the kernel's vector instructions
     Chunk A[R], B[R];
@@ -347,7 +315,6 @@ void frame_stats_kernel(const uint8_t* __restrict__ Y, long long frame_stride /*
             for (int r = 0; r < R; ++r) A[r] = B[r];
         }
     }
-#endif
 }
 
 hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long long frame_stride_bytes, int pitch_elems, int W,
@@ -368,7 +335,7 @@ hipError_t launch_frame_stats(hipStream_t st, int bits, const void* dY, long lon
     const int dG = col_groups / 64, dR = col_groups % 64, dP = dR ? 64 / dR : 1, dWpb = dP * dG + (dR ? 1 : 0);
     const int wgs = AMT_STATS_DEAL == 2 ? ((tiles + dP - 1) / dP * dWpb + kStatThreads / 64 - 1) / (kStatThreads / 64)
                   : AMT_STATS_DEAL == 1 ? (tiles * wpt + kStatThreads / 64 - 1) / (kStatThreads / 64)
-                  : kStatVG > 1 ? ((tiles + kStatVG - 1) / kStatVG * col_groups + 63) / 64 : (tiles * col_groups + kStatThreads - 1) / kStatThreads;
+                  : (tiles * col_groups + kStatThreads - 1) / kStatThreads;
     dim3 grid((unsigned)((wgs + kStatXcds - 1) / kStatXcds * kStatXcds), (unsigned)((nframes + kStatRun - 1) / kStatRun)),
         block(kStatThreads);                                      // surplus workgroups of the round-up find nvalid <= 0
     const bool ragged = row_bytes % kStatColBytes != 0;

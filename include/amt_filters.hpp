@@ -213,8 +213,21 @@ class AMTEraseLogo : public GenericVideoFilter {
     std::set<int> inflight_;                      /* first frames of the blocks being fetched */
     std::vector<float> analysis_;                 /* [num_frames][33], filled on demand from analyzeclip */
     std::vector<char> have_;                      /* per analysis frame */
-    int cache_first_ = -1;
-    std::vector<PVideoFrame> cache_;              /* the erased frames of the current block */
+    /* the erased frames of the most recently used blocks.  The reference's filter works frame by frame and has no block to lose
+     * (LogoScan.hpp:1343-1419, MT_NICE_FILTER); here Prefetch threads whose requests straddle a block boundary alternate between
+     * blocks k and k + 1, and with a single cached block each such request would evict the other's block and redo its upstream
+     * GetFrames and its launch.  Two entries, least recently used replaced. */
+    struct CachedBlock { int first = -1; std::vector<PVideoFrame> frames; uint64_t used = 0; };
+    static constexpr int kCacheBlocks = 2;
+    CachedBlock cache_[kCacheBlocks];
+    uint64_t tick_ = 0;
+    /* (mu_ held) */
+    const PVideoFrame* lookup(int n)
+    {
+        for (CachedBlock& b : cache_)
+            if (b.first >= 0 && n >= b.first && n < b.first + (int)b.frames.size()) { b.used = ++tick_; return &b.frames[n - b.first]; }
+        return nullptr;
+    }
 
     /* what one block needs from upstream, fetched WITHOUT the filter's lock (under Prefetch the child clip's work -- AMTSource decode,
      * the analysis filter -- then runs on as many threads as the host gives this filter, as with the reference's per-frame filter) */
@@ -334,8 +347,12 @@ class AMTEraseLogo : public GenericVideoFilter {
             }
             if (!amtgpu_download_scatter(g, dbuf_.at(0), per * m, pieces.data(), (int)pieces.size())) env->ThrowError("[AMTEraseLogo] %s", ctx_->error());
         }
-        cache_.swap(frames);
-        cache_first_ = first;
+        CachedBlock* victim = &cache_[0];
+        for (CachedBlock& b : cache_)
+            if (b.first < 0 || (victim->first >= 0 && b.used < victim->used)) victim = &b;
+        victim->frames.swap(frames);
+        victim->first = first;
+        victim->used = ++tick_;
     }
 
 public:
@@ -360,11 +377,10 @@ public:
         const int es = vi.ComponentSize();
         if (es != 1 && es != 2) env->ThrowError("[AMTEraseLogo] Unsupported pixel format");
         n = std::max(0, std::min(vi.num_frames - 1, n));
-        auto cached = [&]() { return cache_first_ >= 0 && n >= cache_first_ && n < cache_first_ + (int)cache_.size(); };
         const int first = n - n % block_;
         std::unique_lock<std::mutex> lock(mu_);
         for (;;) {
-            if (cached()) return cache_[n - cache_first_];
+            if (const PVideoFrame* hit = lookup(n)) return *hit;
             if (!inflight_.count(first)) break;
             cv_.wait(lock);                               /* another thread is pulling this block's upstream frames: wait for it */
         }
@@ -376,8 +392,8 @@ public:
         } done{this, first, lock};
         Fetched f = fetch(first, env);                    /* upstream work: not under the lock */
         lock.lock();
-        if (!cached()) process(f, env);
-        return cache_[n - cache_first_];
+        if (!lookup(n)) process(f, env);
+        return *lookup(n);
     }
     int SetCacheHints(int cachehints, int) override { return cachehints == AMT_AVS_NS CACHE_GET_MTMODE ? AMT_AVS_NS MT_NICE_FILTER : 0; }
 };

@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "amt_filters.hpp"
@@ -367,6 +369,38 @@ int main(int argc, char** argv)
                 }
             }
             cf << "upstream_frames_pulled_once " << (once ? 1 : 0) << "\nframes_equal_serial " << (same ? 1 : 0) << "\n";
+
+            // 3d. two Prefetch threads whose requests straddle a block boundary: thread 0 walks block k, thread 1 block k + 1, turn and
+            //     turn about.  Each block's upstream frames must be pulled ONCE -- a one-block cache would evict k for k + 1 and back
+            //     with every request (the reference's per-frame filter has no such cliff, LogoScan.hpp:1343-1419).
+            auto counted2 = std::make_shared<CountingClip>(src);
+            PClip er2 = std::make_shared<amtgpu::AMTEraseLogo>(counted2, an, logo, "", 0, 16, &env, ctx, blk);
+            bool once2 = true, same2 = true;
+            for (int b0 = 0; b0 + blk < vi.num_frames; b0 += 2 * blk) {
+                const int nb1 = std::min(blk, vi.num_frames - (b0 + blk)), before = counted2->calls.load();
+                std::vector<PVideoFrame> got0(blk), got1(nb1);
+                std::mutex tm; std::condition_variable tcv; int turn = 0;       // strict alternation: the worst case for one cached block
+                auto walk = [&](int me, int base, int cnt, std::vector<PVideoFrame>& gotv) {
+                    IScriptEnvironment e2;
+                    for (int i = 0; i < blk; ++i) {
+                        { std::unique_lock<std::mutex> lk(tm); tcv.wait(lk, [&] { return turn == me; }); }
+                        if (i < cnt) gotv[i] = er2->GetFrame(base + i, &e2);
+                        { std::lock_guard<std::mutex> lk(tm); turn = 1 - me; }
+                        tcv.notify_all();
+                    }
+                };
+                std::thread t0(walk, 0, b0, blk, std::ref(got0)), t1(walk, 1, b0 + blk, nb1, std::ref(got1));
+                t0.join(); t1.join();
+                once2 = once2 && counted2->calls.load() - before == blk + nb1;
+                for (int i = 0; i < blk + nb1; ++i) {
+                    PVideoFrame want = serial->GetFrame(b0 + i, &env), have = i < blk ? got0[i] : got1[i - blk];
+                    for (int plane : {PLANAR_Y, PLANAR_U, PLANAR_V})
+                        for (int y = 0; y < want->GetHeight(plane); ++y)
+                            same2 = same2 && !std::memcmp(want->GetReadPtr(plane) + (size_t)y * want->GetPitch(plane),
+                                                          have->GetReadPtr(plane) + (size_t)y * have->GetPitch(plane), want->GetRowSize(plane));
+                }
+            }
+            cf << "alternating_blocks_pulled_once " << (once2 ? 1 : 0) << "\nalternating_frames_equal_serial " << (same2 ? 1 : 0) << "\n";
         }
 
         // 3b. the same graph built the way AviSynth builds it: through the factories the plugin registered with the

@@ -109,8 +109,10 @@ def test_cpp_filters_match_oracle(tmp_path, bits):
             assert np.array_equal(g[W * H:W * H + (W // 2) * (H // 2)].reshape(H // 2, W // 2), eU[i, :, :W // 2])
             assert np.array_equal(g[W * H + (W // 2) * (H // 2):].reshape(H // 2, W // 2), eV[i, :, :W // 2])
 
-    # four threads asking for frames of one block: its upstream frames pulled once, frames equal to the serial walk's
-    assert (out / "concurrent.txt").read_text().split() == ["upstream_frames_pulled_once", "1", "frames_equal_serial", "1"]
+    # Prefetch threads inside one block, and two threads alternating between ADJACENT blocks (the two-entry block cache): upstream frames
+    # pulled once per block either way, frames equal to the serial walk's
+    assert (out / "concurrent.txt").read_text().split() == ["upstream_frames_pulled_once", "1", "frames_equal_serial", "1",
+                                                            "alternating_blocks_pulled_once", "1", "alternating_frames_equal_serial", "1"]
 
     errs = (out / "errors.txt").read_text().splitlines()
     assert errs[0].startswith("Failed to read logo file (") and "missing.lgd" in errs[0]
