@@ -372,6 +372,10 @@ class AMTAnalyzeLogo:
     def last_refined(self):
         return self.ctx.lib.amtgpu_analyze_last_refined(self.h)
 
+    def set_fixup_queue(self, entries):
+        """pairs a wave of the linear kernel can list for the exact bin check (a tuning knob; results do not depend on it)"""
+        self.ctx.check(self.ctx.lib.amtgpu_analyze_set_fixup_queue(self.h, int(entries)))
+
     def error_bound(self, group=0, bits=8):
         return self.ctx.lib.amtgpu_analyze_error_bound(self.h, group, bits)
 

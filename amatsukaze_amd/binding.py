@@ -102,6 +102,7 @@ SIGNATURES = {
     "amtgpu_analyze_batch_host": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "amtgpu_analyze_set_mode": (c_i, [c_p, c_i]),
     "amtgpu_analyze_last_refined": (c_i, [c_p]),
+    "amtgpu_analyze_set_fixup_queue": (c_i, [c_p, c_i]),
     "amtgpu_analyze_error_bound": (c_f, [c_p, c_i, c_i]),
     "amtgpu_erase_create": (c_p, [c_p, c_s, c_s, c_i, c_i]),
     "amtgpu_erase_create_from_logo": (c_p, [c_p, c_p, c_s, c_i, c_i]),

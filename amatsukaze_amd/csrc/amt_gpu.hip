@@ -567,19 +567,25 @@ static void analyze_run(AmtGpuAnalyze* an, const void* dY, int64_t frame_stride,
     an->ctx->bind();
     if (an->dList.size() < (size_t)nframes) an->dList.alloc(nframes);
     if (an->dCount.size() < 1) an->dCount.alloc(1);
-    an->engine->run_linear(dY, frame_stride, pitch, bits, nframes, dout);
-    if (an->mode == AMTGPU_ANALYZE_LINEAR_UNGUARDED) return;
+    // frames the linear evaluation must not be trusted on, one byte each: container values above maxv (9..15-bit clips: outside the error
+    // bound's assumption), and -- set by the kernel itself -- the frames of a workgroup whose list of bin checks overflowed
+    const bool guarded = an->mode != AMTGPU_ANALYZE_LINEAR_UNGUARDED;
+    uint8_t* force = nullptr;
+    if (guarded) {
+        if (an->dForce.size() < (size_t)nframes) an->dForce.alloc(nframes);
+        force = an->dForce.get();
+        if (bits > 8 && bits < 16) {
+            const int spf = an->ctx->prof_begin("rect_range_flag_kernel");
+            AMT_HIP(launch_rect_range_flag(an->ctx->stream, dY, frame_stride / 2, pitch, an->logo.imgx, an->logo.imgy, an->logo.w, an->logo.h, bits, nframes, force));
+            an->ctx->prof_end(spf);
+        } else {
+            AMT_HIP(hipMemsetAsync(force, 0, (size_t)nframes, an->ctx->stream));
+        }
+    }
+    an->engine->run_linear(dY, frame_stride, pitch, bits, nframes, dout, nullptr, force);
+    if (!guarded) return;
     float eps[3];
     for (int k = 0; k < 3; ++k) eps[k] = 2.0f * an->engine->linear_error_bound(k, bits);
-    const uint8_t* force = nullptr;
-    if (bits > 8 && bits < 16) {        // container values above maxv are outside the bound's assumption: such frames go to the exact kernel
-        if (an->dForce.size() < (size_t)nframes) an->dForce.alloc(nframes);
-        const int spf = an->ctx->prof_begin("rect_range_flag_kernel");
-        AMT_HIP(launch_rect_range_flag(an->ctx->stream, dY, frame_stride / 2, pitch, an->logo.imgx, an->logo.imgy, an->logo.w, an->logo.h, bits, nframes,
-                                       an->dForce.get()));
-        an->ctx->prof_end(spf);
-        force = an->dForce.get();
-    }
     const int sp = an->ctx->prof_begin("analysis_mark_kernel");
     AMT_HIP(launch_analysis_mark(an->ctx->stream, dout, AMTGPU_ANALYZE_FLOATS, nframes, 3, AMTGPU_NUM_FADE, eps, an->dList.get(), an->dCount.get(), force));
     an->ctx->prof_end(sp);
@@ -646,6 +652,14 @@ int amtgpu_analyze_set_mode(AmtGpuAnalyze* an, int mode)
             throw std::runtime_error("unknown analysis mode");
         if (mode != AMTGPU_ANALYZE_EXACT) (void)an->engine->linear_error_bound(0, 8);   // builds the tables; throws for logos the kernel does not take (wider than 256)
         an->mode = mode;
+    });
+}
+
+int amtgpu_analyze_set_fixup_queue(AmtGpuAnalyze* an, int entries)
+{
+    return guard(an->ctx, [&] {
+        if (entries < 16 || entries > 640) throw std::runtime_error("fix-up queue: 16 .. 640 entries per wave");
+        an->engine->set_linear_queue(entries);
     });
 }
 

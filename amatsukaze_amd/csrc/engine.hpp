@@ -144,11 +144,16 @@ struct TileLogoDev {
     const float2* sc;            // [32][nslots]  bin-major {scale, scale2} of the slot's mask pixel (the exact scan kernel)
     const float2* pq;            // [nslots]      {P, Q}: the pixel's response on flat level c is |P + Q c| (the linear analysis kernel: no gathers)
     const uint32_t* sinfo;       // [nslots]      tile_slot_info
+    const uint32_t* pos;         // [nslots]      (y << 16) | x of the slot's mask pixel in the evaluation logo (the linear kernel's exact bin check)
     const TileDesc* tiles;       // [nbands * 8]
     const TileBandDesc* bands;   // [nbands]
     const int* tlist;            // [ntlist]  indices of the tiles that hold pixels (kernels that need no band order walk these)
     int nbands, nslots, ntlist;
     float floorResp;             // limitCorr of the logo (LogoScan.hpp:203)
+    // the linear kernel's copy of everything it loads per tile, in ONE allocation (one scalar base instead of five: its loop is short of
+    // scalar registers): kp at 0, then pq, sinfo, the evaluation logo's a and b planes at these byte offsets
+    const char* lin;
+    unsigned lin_pq, lin_sinfo, lin_a, lin_b;
 };
 
 // one evaluation logo + where its source pixels come from
@@ -173,8 +178,12 @@ public:
              const int* dframe_map = nullptr);
     // Linear (decision-guarded) evaluation of all fades from one window evaluation of s and one of bg
     // (eval_linear_kernels.hip).  Results are within linear_error_bound(i, bits) of run()'s for logo i; same arguments as run().
+    // dforce (device, optional, nframes bytes): the kernel sets the byte of every frame it could not finish in this mode (its list of
+    // means next to a bin edge overflowed): the caller re-evaluates those frames exactly
     void run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout,
-                    const int* dframe_map = nullptr);
+                    const int* dframe_map = nullptr, uint8_t* dforce = nullptr);
+    // (pixel, frame, fade) pairs a wave of the linear kernel can list for the exact bin check (default 256; amtgpu_analyze_set_fixup_queue)
+    void set_linear_queue(int entries) { lin_queue_ = entries; }
     // rigorous bound on |run_linear - run| for every score of logo i (rounding analysis in eval_engine.hip)
     float linear_error_bound(int logo, int bits) const;
     // exact re-evaluation of the frames listed on the device: batch slot j < *dcount reads source frame dlist[j] and its results
@@ -213,7 +222,9 @@ private:
     void ensure_tiles();
     bool tiles_ready_ = false;
     std::vector<DevBuf<float2>> d_tkp_, d_tsc_, d_tpq_;
-    std::vector<DevBuf<uint32_t>> d_tinfo_;
+    std::vector<DevBuf<uint32_t>> d_tinfo_, d_tpos_;
+    std::vector<DevBuf<char>> d_tlin_;
+    int lin_queue_ = 256;
     std::vector<DevBuf<TileDesc>> d_tiles_;
     std::vector<DevBuf<TileBandDesc>> d_tbands_;
     std::vector<DevBuf<int>> d_tlist_;
@@ -239,7 +250,7 @@ hipError_t launch_logo_eval_fused(hipStream_t st, int bits, const EvalLogoDev* d
 hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                    const float* dfades, int nfades, int fade0, const void* dY, const int* dframe_map,
                                    long long frame_stride_elems, int pitch, int nframes, int G, float* dout, int out_frame_stride,
-                                   int take_abs, float bin_eps, int qlog2);
+                                   int take_abs, float bin_eps, int qlog2, int qcap, uint8_t* dforce);
 // eval_pair_kernels.hip: fades {0, 1} of every logo, bit-exact
 hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                  const void* dY, const int* dframe_map, long long frame_stride_elems, int pitch,

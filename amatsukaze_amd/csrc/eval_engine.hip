@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 int AmtGpuContext::prof_id(const char* name)
 {
@@ -276,17 +277,19 @@ void EvalEngine::ensure_tiles()
     ctx_->bind();
     const int nl = (int)specs_.size();
     std::vector<TileLogoDev> hl(nl);
-    d_tkp_.resize(nl); d_tsc_.resize(nl); d_tpq_.resize(nl); d_tinfo_.resize(nl); d_tiles_.resize(nl); d_tbands_.resize(nl); d_tlist_.resize(nl);
+    d_tkp_.resize(nl); d_tsc_.resize(nl); d_tpq_.resize(nl); d_tinfo_.resize(nl); d_tpos_.resize(nl); d_tlin_.resize(nl); d_tiles_.resize(nl); d_tbands_.resize(nl); d_tlist_.resize(nl);
     for (int i = 0; i < nl; ++i) {
         const EvalLogoSpec& S = specs_[i];
         const MaskTables& T = S.tables;
         const TilePlan P = build_tile_plan(T.pos, T.count, S.planes.w, S.planes.h);
         const size_t ns = (size_t)P.nslots();
         std::vector<float2> kp(13 * ns, float2{0.0f, 0.0f}), sc((size_t)kNumBins * ns, float2{0.0f, 0.0f}), pq(ns, float2{0.0f, 0.0f});
+        std::vector<uint32_t> spos(ns, 0u);
         for (size_t s = 0; s < ns; ++s) {
             const int m = P.slot_pixel[s];
             if (m < 0) continue;                               // (an idle lane: zero taps and a zero response -> its terms are 0 / floorResp)
             fit_response(&T.resp[(size_t)m * 32], pq[s].x, pq[s].y);
+            spos[s] = T.pos[m];
             const float* k = &T.kernels[(size_t)m * 25];
             float ksum = 0.0f;
             for (int t = 0; t < 25; ++t) ksum += k[t];
@@ -297,14 +300,29 @@ void EvalEngine::ensure_tiles()
         d_tkp_[i].upload(kp, ctx_->stream);
         d_tsc_[i].upload(sc, ctx_->stream);
         d_tpq_[i].upload(pq, ctx_->stream);
+        d_tpos_[i].upload(spos, ctx_->stream);
+        // the linear kernel's blob
+        const size_t npx = (size_t)S.planes.w * S.planes.h;
+        const size_t o_pq = kp.size() * sizeof(float2), o_si = o_pq + pq.size() * sizeof(float2), o_a = o_si + P.sinfo.size() * sizeof(uint32_t),
+                     o_b = o_a + npx * sizeof(float), total = o_b + npx * sizeof(float);
+        if (total >= ((size_t)1 << 31)) throw std::runtime_error("logo too large");
+        std::vector<char> blob(total);
+        std::memcpy(blob.data(), kp.data(), o_pq);
+        std::memcpy(blob.data() + o_pq, pq.data(), o_si - o_pq);
+        std::memcpy(blob.data() + o_si, P.sinfo.data(), o_a - o_si);
+        std::memcpy(blob.data() + o_a, S.planes.A(0), npx * sizeof(float));
+        std::memcpy(blob.data() + o_b, S.planes.B(0), npx * sizeof(float));
+        d_tlin_[i].upload(blob, ctx_->stream);
         d_tinfo_[i].upload(P.sinfo, ctx_->stream);
         d_tiles_[i].upload(P.tiles, ctx_->stream);
         d_tbands_[i].upload(P.bands, ctx_->stream);
         std::vector<int> tlist;
         for (size_t t = 0; t < P.tiles.size(); ++t) if (P.tiles[t].npix > 0) tlist.push_back((int)t);
         d_tlist_[i].upload(tlist, ctx_->stream);
-        hl[i] = TileLogoDev{d_tkp_[i].get(), d_tsc_[i].get(), d_tpq_[i].get(), d_tinfo_[i].get(), d_tiles_[i].get(), d_tbands_[i].get(), d_tlist_[i].get(),
+        hl[i] = TileLogoDev{d_tkp_[i].get(), d_tsc_[i].get(), d_tpq_[i].get(), d_tinfo_[i].get(), d_tpos_[i].get(), d_tiles_[i].get(), d_tbands_[i].get(), d_tlist_[i].get(),
                             (int)P.bands.size(), (int)ns, (int)tlist.size(), T.floorResp};
+        hl[i].lin = d_tlin_[i].get();
+        hl[i].lin_pq = (unsigned)o_pq; hl[i].lin_sinfo = (unsigned)o_si; hl[i].lin_a = (unsigned)o_a; hl[i].lin_b = (unsigned)o_b;
     }
     d_tls_.upload(hl, ctx_->stream);
     tiles_ready_ = true;
@@ -379,7 +397,7 @@ void EvalEngine::ensure_linear()
         }
         const double black = std::max(1e-30, (double)std::fabs(T.blackScore));
         lin_err_corr_[i] = ecorr / black;                                       // x u x v
-        lin_err_sum_[i] = ((double)T.count + 44.0) * tsum / black + 8.0;        // x u  (+ the final division / abs, results are O(1); + 4 u |t'| for rcp and its product)
+        lin_err_sum_[i] = ((double)T.count + 52.0) * tsum / black + 8.0;        // x u  (+ the final division / abs, results are O(1); + 4 u |t'| for rcp and its product; + 8 u for a listed pair's correction t(exact bin) - t(tentative bin))
         lin_err_formula_[i] = eformula / black;
     }
     // v, the bound on window values in units of maxv: a blend with fades in [0, 1] is convex, so max(1, |a| + |b|) holds; fades
@@ -395,7 +413,8 @@ bool EvalEngine::tiles_usable(int pitch_bytes) const
 {
     for (const EvalLogoSpec& S : specs_) {
         const int w = S.planes.w, h = S.planes.h;
-        if (w < 6 || (w & 1) || h < 5 || S.tables.count <= 0 || S.tables.count >= (1 << 20)) return false;
+        // (24-bit slot byte offsets; the linear kernel's list entries carry the slot number -- at most 1.1 x count -- in 20 bits)
+        if (w < 6 || (w & 1) || h < 5 || S.tables.count <= 0 || S.tables.count >= 900000) return false;
     }
     return pair_addressable(pitch_bytes);
 }
@@ -407,7 +426,8 @@ float EvalEngine::linear_error_bound(int logo, int bits) const
     return (float)(1.25 * (u * (lin_err_corr_[logo] * vmax_unit_ * maxv + lin_err_sum_[logo]) + lin_err_formula_[logo]));
 }
 
-void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout, const int* dframe_map)
+void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitch, int bits, int nframes, float* dout, const int* dframe_map,
+                            uint8_t* dforce)
 {
     if (nframes <= 0 || specs_.empty()) return;
     const int es = bits <= 8 ? 1 : 2;
@@ -430,13 +450,19 @@ void EvalEngine::run_linear(const void* dY, int64_t frame_stride_bytes, int pitc
     int qlog2 = 24;
     while (qlog2 > 4 && std::ldexp(vwin, qlog2) >= 1073741824.0) --qlog2;
     if (!(std::ldexp(vwin, qlog2) < 1073741824.0)) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }   // (absurd coefficients: the exact kernel)
-    const int gmax = bits > 8 ? kLinMaxFrames16 : kLinMaxFrames;
+    // frames per workgroup: four workgroups of four waves share a CU's 160 KB of LDS -- 16 KB of tile planes, 4 x 8 B x the list's entries,
+    // 3 KB of running sums per frame
+    const int qcap = std::max(16, std::min(640, lin_queue_));
+    const int g_fit = (int)((160 * 1024 / 4 - 16 * 1024 - 4 * 8 * qcap - 16) / (4 * 768));
+    if (g_fit < 1) { run(dY, frame_stride_bytes, pitch, bits, nframes, dout, dframe_map); return; }
+    const int gmax = std::min(g_fit, bits > 8 ? kLinMaxFrames16 : kLinMaxFrames);
     const long long wgs_min = bits > 8 ? AMT_LIN_WGS_MIN16 : 2048;
     const int G = std::min(gmax, group_frames_ > 0 ? group_frames_ : (int)std::max(1LL, std::min(16LL, (long long)nframes * nl / wgs_min)));
     const size_t dot = prof_name_.find('.');
     const int sp = ctx_->prof_begin(("logo_eval_linear_kernel" + (dot == std::string::npos ? std::string() : prof_name_.substr(dot))).c_str());
     AMT_HIP(launch_logo_eval_linear(ctx_->stream, bits, d_logos_.get(), d_tls_.get(), nl, d_fades_.get(), 11, 0, dY, dframe_map,
-                                    frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0, bin_eps, qlog2));
+                                    frame_stride_bytes / es, pitch, nframes, G, dout, out_frame_stride_, take_abs_ ? 1 : 0, bin_eps, qlog2,
+                                    qcap, dforce));
     ctx_->prof_end(sp);
 }
 

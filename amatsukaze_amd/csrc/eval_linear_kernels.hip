@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>
+#include <cmath>
 
 #include "eval_tile_stage.h"
 
@@ -42,34 +43,228 @@ constexpr int kLinWgThreads = kLinWaves * 64;
 // v_mfma_f32_16x16x4_f32 with row selectors -- tools/ubench/mfma_rowsum.hip, profiles/r03_notes.md.)
 constexpr int kLinAccFrameBytes = 16 * 48;
 
-// mean of the blended window exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it (LogoScan.hpp:244-251, ComputeKernel.cpp:88-98):
-// the uncommon path of the bin select.  Two LDS round trips (rows 0-2, rows 3-4) instead of one per row: what this path costs
-// is mostly the latency of its reads.
-__device__ __forceinline__ float exact_blend_mean_2trips(const unsigned (&wrow)[5], float fade)
+// Mean of the blended 5x5 window around logo pixel (x, y) of one frame, exactly as EvaluateLogo + CalcCorrelation5x5_AVX produce it
+// (LogoScan.hpp:244-251, ComputeKernel.cpp:88-98) -- from the frame's samples themselves: s = the sample, or DeintY's (a + 2b + c + 2) / 4
+// (LogoScan.hpp:763-780; an integer sum below 2^24 times 0.25), bg = a*s + b*maxv, the blend, column sums ((r0 + r1) + (r2 + r3)) + r4,
+// hsum256_ps' order, /25.  The uncommon path of the bin select: run once per listed (pixel, frame, fade) after the workgroup's loop.
+template <typename pix_t>
+__device__ __forceinline__ float exact_blend_mean_from_frame(const EvalLogoDev* Lp, const pix_t* frame, int pitch, float maxv, int x, int y, float fade)
 {
-    typedef const __attribute__((address_space(3))) f2* lds_pair;
-    f2 e[3][5];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) e[r][i] = ((lds_pair)(unsigned long long)wrow[r])[i];
-    float t01[5], v2[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        t01[i] = fade_mix(fade, e[0][i].y, e[0][i].x) + fade_mix(fade, e[1][i].y, e[1][i].x);
-        v2[i] = fade_mix(fade, e[2][i].y, e[2][i].x);
-    }
-    __builtin_amdgcn_sched_barrier(0);                             // (the second round of reads goes into the registers of the first)
-    f2 g[2][5];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) g[r][i] = ((lds_pair)(unsigned long long)wrow[3 + r])[i];
+    const int w = Lp->w, h = Lp->h, step = Lp->row_step;
+    const bool deint = Lp->deint != 0;
+    const float* const la = Lp->a + (y - 2) * w + (x - 2);
+    const float* const lb = Lp->b + (y - 2) * w + (x - 2);
+    // the window's source rows: for a deinterlaced logo the rows above and below as well (seven in all), clamped to the logo's own rows
+    // -- the first and the last row are not blended and never look outside
+    const pix_t* const p0 = frame + (long long)(Lp->imgy + Lp->row0) * pitch + Lp->imgx + (x - 2);
     float c[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) c[i] = (t01[i] + (v2[i] + fade_mix(fade, g[0][i].y, g[0][i].x))) + fade_mix(fade, g[1][i].y, g[1][i].x);
+    for (int i = 0; i < 5; ++i) {
+        unsigned raw[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int yy = min(max(y - 3 + r, 0), h - 1);
+            raw[r] = (r == 0 || r == 6) && !deint ? 0u : (unsigned)p0[(long long)yy * step * pitch + i];
+        }
+        float v[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int yy = y - 2 + r;
+            const bool blend = deint && yy > 0 && yy < h - 1;
+            const float sv = blend ? __builtin_amdgcn_ldexpf((float)(((raw[r + 1] << 1) + raw[r]) + (raw[r + 2] + 2u)), -2) : (float)raw[r + 1];
+            const float bmv = lb[r * w + i] * maxv;
+            const float bg = la[r * w + i] * sv + bmv;
+            v[r] = fade_mix(fade, bg, sv);
+        }
+        c[i] = ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
+    }
     return div25(hsum5(c[0], c[1], c[2], c[3], c[4]));
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The raw-sample loads of the loop, with a HAND-PLACED wait.  The loop's point is to have the next frame's raw samples in flight while
+// the current frame is evaluated.  The compiler's wait insertion counts the loads in flight per control-flow path and takes the
+// strictest count where paths meet; with loads that are issued on some trips only (a new tile's taps, its response line, its logo
+// coefficients) it drained EVERY load -- the raw samples included -- at the loop head or in front of the first conditional consumer
+// (rounds 2-5 had that drain in front of their scale gathers).  So:
+//   * the raw-sample loads -- issued on every trip, consumed exactly one trip later -- are inline assembly, which the compiler neither
+//     counts nor waits for; the wait is written out (LinStager::landed) and names the registers it releases as in/out operands, so the
+//     consumers depend on it and nothing can be scheduled across it.  The loads' destinations are in/out operands too ("+v"): the load
+//     lands in the register the variable already lives in.  As plain outputs the compiler is free to give the results fresh registers
+//     and copy them into the loop-carried ones right behind the load -- it believes the value is there -- and the copy reads what the
+//     load has not written yet (seen; tests/test_isa_guards.py walks the code for any read of a register between such a load and the
+//     next vmcnt wait);
+//   * the per-tile loads stay the compiler's (a value loaded on one path and carried on another IS copied where the paths meet, and
+//     only the compiler can protect that copy), but are consumed in the iteration that issues them, behind the terms (LinPixel::landed):
+//     no trip reaches the loop head with one of them in flight, so the compiler has nothing to wait for there.
+// A load the compiler adds to the loop can only make the hand-placed wait stricter (it waits for "at most N outstanding").
+// ------------------------------------------------------------------------------------------------------------------------
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+// buffer descriptor of a source frame: base, stride 0, 2 GiB of records, raw dword format (as __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7FFFFFFF, 0x00020000))
+template <typename pix_t>
+__device__ __forceinline__ u4 frame_desc(const void* Y, const int* frame_map, long long frame_stride, int frame)
+{
+    const int srcFrame = frame_map ? ((const_int_ptr)frame_map)[frame] : frame;
+    const unsigned long long a = (unsigned long long)(reinterpret_cast<const pix_t*>(Y) + (long long)srcFrame * frame_stride);
+    return u4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xFFFFu, 0x7FFFFFFFu, 0x00020000u};
+}
+__device__ __forceinline__ void vm_load_raw(Quad<uint8_t>& q, u4 desc, int voff)
+{
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(q.v) : "v"(voff), "s"(desc) : "memory");
+}
+__device__ __forceinline__ void vm_load_raw(Quad<uint16_t>& q, u4 desc, int voff)
+{
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "+v"(q.v) : "v"(voff), "s"(desc) : "memory");
+}
+// a table base as the scalar register pair the saddr form of a global load takes (the value IS wave-uniform -- it hangs off the
+// workgroup's logo -- but arrives through a vector load where the compiler cannot prove it)
+typedef u2 sbase_t;
+__device__ __forceinline__ sbase_t uniform_base(const void* p)
+{
+    const unsigned long long a = (unsigned long long)p;
+    return sbase_t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32))};
+}
+__device__ __forceinline__ gptr_t table_base(sbase_t b) { return (gptr_t)(((unsigned long long)b.y << 32) | b.x); }
+// at most N vector-memory loads outstanding; releases ...
+template <int N, typename Q> __device__ __forceinline__ void vm_wait_raw(Q (&raw)[kTileUnits][3])   // ... the raw samples of a request
+{
+    static_assert(kTileUnits == 2, "operand list written for two units");
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(raw[0][0].v), "+v"(raw[0][1].v), "+v"(raw[0][2].v), "+v"(raw[1][0].v), "+v"(raw[1][1].v), "+v"(raw[1][2].v)
+                 : "n"(N) : "memory");
+}
+
+// One wave's staging state (eval_tile_stage.h TileStager, SLIM form) with the loads above.  BLEND = false: a field logo, whose rows are
+// the source rows themselves (CopyY): one row load per unit instead of three, no [1 2 1] sums.
+template <typename pix_t, bool BLEND> struct LinStager {
+    static constexpr int ES = (int)sizeof(pix_t);
+    static constexpr int kRowsPerUnit = BLEND ? 3 : 1;
+    static constexpr int kRawLoads = kTileUnits * kRowsPerUnit;      // vector-memory loads of one request()
+    static constexpr int kCoefLoads = 2 * kTileUnits;                // ... of one setup_units()
+    int pitchB;                      // (wave-uniform)
+    float maxv;
+    f2* plane;
+    bool second_pass;                // the tile has more than 64 units
+    bool coef_fresh;                 // ub[] still holds b, not b * maxv (the product -- and with it the wait for the loads -- is left to the
+                                     // first conversion, an iteration later)
+    int ulds[kTileUnits];            // pair offset in the tile plane; sign bit: this row is a [1 2 1] blend
+    int ug[kTileUnits];              // byte offset in a frame of the unit's own row
+    f4 ua[kTileUnits], ub[kTileUnits];                             // the unit's logo coefficients: a, b * maxv
+    Quad<pix_t> raw[kTileUnits][3];
+
+    __device__ __forceinline__ void init(int pitch, float maxv_, f2* plane_)
+    {
+        pitchB = pitch * ES; maxv = maxv_; plane = plane_;
+        second_pass = false; coef_fresh = false;
+#pragma unroll
+        for (int k = 0; k < kTileUnits; ++k)                        // (the raw loads' destinations are in/out operands: they need a value)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) raw[k][j].v = decltype(raw[k][j].v){};
+    }
+    // (the logo's geometry is read again at every new tile -- scalar loads: the loop is short of scalar registers)
+    __device__ __forceinline__ void setup_units(const EvalLogoDev* Lp, const TileLogoDev* Xp, const TileDesc& T, int lane)
+    {
+        typedef const __attribute__((address_space(4))) EvalLogoDev* logo_ptr;
+        typedef const __attribute__((address_space(4))) TileLogoDev* tlogo_ptr;
+        const logo_ptr L = (logo_ptr)Lp;
+        const tlogo_ptr X = (tlogo_ptr)Xp;
+        const int w = L->w, h = L->h, deint = L->deint, srow0 = L->imgy + L->row0, srow_step = L->row_step, scol0 = L->imgx;
+        const gptr_t base = table_base(uniform_base(X->lin));
+        const unsigned oa = X->lin_a, ob = X->lin_b;
+        typedef f4 __attribute__((aligned(8))) f4a8;
+        second_pass = T.nrows * T.ncol4 > 64;
+#pragma unroll
+        for (int k = 0; k < kTileUnits; ++k) {
+            const TileUnit U = tile_unit(T, lane + 64 * k, w);
+            const bool blend = BLEND && deint && U.y > 0 && U.y < h - 1;       // DeintY copies the first and the last row (LogoScan.hpp:763-780)
+            ulds[k] = U.lds | (blend ? (int)0x80000000 : 0);
+            ug[k] = (srow0 + U.y * srow_step) * pitchB + (scol0 + U.xs) * ES;
+            ua[k] = gld<f4a8>(base, (unsigned)(U.y * w + U.xs) * 4u + oa);
+            ub[k] = gld<f4a8>(base, (unsigned)(U.y * w + U.xs) * 4u + ob);
+        }
+        coef_fresh = true;
+    }
+    __device__ __forceinline__ void request(const u4 frame)
+    {
+#pragma unroll
+        for (int k = 0; k < kTileUnits; ++k) {
+            if (!BLEND) {
+                vm_load_raw(raw[k][1], frame, ug[k]);
+            } else {
+                const int d = (ulds[k] >> 31) & pitchB;           // a blended row: the rows above and below; otherwise the row itself
+                vm_load_raw(raw[k][0], frame, ug[k] - d);
+                vm_load_raw(raw[k][1], frame, ug[k]);
+                vm_load_raw(raw[k][2], frame, ug[k] + d);
+            }
+        }
+    }
+    // the samples of the oldest request() have landed when at most N younger loads are outstanding
+    template <int N> __device__ __forceinline__ void landed()
+    {
+        if (!BLEND) {   // (the unused rows must not be operands: they were never written)
+            static_assert(kTileUnits == 2, "operand list written for two units");
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(raw[0][1].v), "+v"(raw[1][1].v) : "n"(N) : "memory");
+        } else {
+            vm_wait_raw<N>(raw);
+        }
+    }
+    __device__ __forceinline__ void convert_unit(int k)
+    {
+        float sv[4];
+        if (BLEND) Quad<pix_t>::blend(raw[k][0], raw[k][1], raw[k][2], (unsigned)(ulds[k] >> 31) & Quad<pix_t>::kBias, sv);
+        else Quad<pix_t>::copy(raw[k][1], sv);
+        f2* dst = plane + (ulds[k] & 0x7FFFFFFF);
+        reinterpret_cast<f4*>(dst)[0] = f4{sv[0], ua[k][0] * sv[0] + ub[k][0], sv[1], ua[k][1] * sv[1] + ub[k][1]};      // {s, bg = a*s + b*maxv} (LogoScan.hpp:247)
+        reinterpret_cast<f4*>(dst)[1] = f4{sv[2], ua[k][2] * sv[2] + ub[k][2], sv[3], ua[k][3] * sv[3] + ub[k][3]};
+    }
+    __device__ __forceinline__ void convert()
+    {
+        if (coef_fresh) {                                           // b * maxv, rounded once, exactly as in a*s + b*maxv
+#pragma unroll
+            for (int k = 0; k < kTileUnits; ++k) ub[k] = ub[k] * maxv;
+            coef_fresh = false;
+        }
+        convert_unit(0);
+        if (second_pass) {
+#pragma unroll
+            for (int k = 1; k < kTileUnits; ++k) convert_unit(k);
+        }
+    }
+};
+
+// this lane's mask pixel of a tile: its taps, its response line and its slot word (window offset in the tile, valid bit)
+struct LinPixel {
+    f2 Kp[13];
+    f2 PQ;                           // the pixel's response on flat level c is |PQ.x + PQ.y * c|
+    unsigned si;                     // tile_slot_info
+    unsigned slot8;
+    unsigned tp8;                    // (wave-uniform) the tile's row pitch in bytes
+    // the taps, the response line and the slot word of `slot` of the logo's blob (TileLogoDev::lin: kp at 0), requested
+    __device__ __forceinline__ void load(gptr_t base, unsigned nslots8, unsigned off_sinfo, unsigned off_pq, unsigned slot, const TileDesc& T)
+    {
+        tp8 = (unsigned)T.tp * 8u;
+        slot8 = slot * 8u;
+        si = gld<unsigned>(base, slot * 4u + off_sinfo);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) Kp[j] = gld<f2>(base, (unsigned)j * nslots8 + slot8);
+        PQ = gld<f2>(base, slot8 + off_pq);
+    }
+    // ... landed: every value is touched, i.e. the compiler places its wait for them HERE (behind the terms, whose duration they had
+    // to arrive) and not at the loop head, where it would wait for the raw samples as well
+    __device__ __forceinline__ void landed()
+    {
+#pragma unroll
+        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(Kp[j]));
+        asm volatile("" : "+v"(PQ), "+v"(si));
+    }
+    __device__ __forceinline__ bool act() const { return (si >> 31) != 0; }
+    // LDS byte addresses of the five rows of the window (idle lanes: the tile's first window -- zero taps, never written out)
+    __device__ __forceinline__ void rows(unsigned plane_base, unsigned (&wrow)[5]) const
+    {
+        const unsigned w0 = plane_base + (si & 0xFFFu) * 8u;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) wrow[r] = w0 + (unsigned)r * tp8;
+    }
+};
 
 struct LinLaunch {
     const EvalLogoDev* logos;
@@ -86,6 +281,9 @@ struct LinLaunch {
     int out_frame_stride, take_abs;
     float bin_eps;      // bound on |interpolated mean - exactly evaluated mean|, fixed-point rounding included (gray levels)
     int qlog2;          // means are compared with the bin edges in units of 2^-qlog2 gray levels (v * 2^qlog2 < 2^31)
+    float ydq, ywin;    // (dq and dq + e + 1) / 2^(qlog2 + 3): see the kernel's comment on bin edges in fixed point
+    int qcap;           // (pixel, frame, fade) pairs a wave can list for the exact bin check
+    uint8_t* force;     // [nframes] (optional) a workgroup whose list overflowed marks its frames: the caller re-evaluates them exactly
 };
 
 #ifndef AMT_LIN_OCC
@@ -95,7 +293,7 @@ struct LinLaunch {
 #define AMT_LIN_OCC16 4
 #endif
 // NF fades (11 for AMTAnalyzeLogo, the only caller of this mode: no per-fade branches)
-template <typename pix_t, int NF>
+template <typename pix_t, int NF, bool BLEND>
 __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 {
     static_assert(NF >= 3 && NF <= 12, "the running sums hold rows 0..11 of the 16x16 accumulator");
@@ -114,7 +312,9 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     const TileLogoDev* const Xp = A.tls + logo;
     const int ntl = Xp->ntlist;                                    // tiles that hold pixels
     const const_int_ptr tlist = (const_int_ptr)Xp->tlist;
-    const gptr_t gPq = (gptr_t)Xp->pq;
+    typedef const __attribute__((address_space(4))) TileLogoDev* tlogo_ptr;
+    const sbase_t gLin = uniform_base(((tlogo_ptr)Xp)->lin);       // the logo's blob: taps at 0, then response lines, slot words, a, b
+    const unsigned nslots8 = (unsigned)((tlogo_ptr)Xp)->nslots * 8u, off_pq = ((tlogo_ptr)Xp)->lin_pq, off_sinfo = ((tlogo_ptr)Xp)->lin_sinfo;
     const float floorResp = Xp->floorResp;                         // (wave-uniform) L: scale2 = min(1, r / L)
     const const_tile_ptr tiles = (const_tile_ptr)Xp->tiles;
     // Bin edges in fixed point.  Q = 2^qlog2 units per gray level; a bin is 8 gray levels = 2^(qlog2+3) units = one unit of y below:
@@ -123,12 +323,9 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     // in [dq - 1, dq + e + 1): so "fract(y) < ywin = (dq + e + 1) / 2^(qlog2+3)" flags every (pixel, fade) whose exact mean might fall in
     // another bin, and for all others floor(y) is the bin of the exact mean.  Scaling by powers of two is exact, so y comes straight out
     // of the multiply-add that interpolates the mean (the scale sits in its operands).
-    const float qscale = __builtin_amdgcn_ldexpf(1.0f, A.qlog2);
-    const int qe = (int)__builtin_ceilf(A.bin_eps * qscale);
-    const int dq = qe + 1;
-    const float yscale = __builtin_amdgcn_ldexpf(1.0f, -3);                          // mean (gray levels) -> bins
-    const float ydq = __builtin_amdgcn_ldexpf((float)dq, -(A.qlog2 + 3));
-    const float ywin = __builtin_amdgcn_ldexpf((float)(dq + qe + 1), -(A.qlog2 + 3));
+    // (dq, e and the two constants below are formed on the host: launch_logo_eval_linear)
+    const float yscale = 0.125f;                                                     // mean (gray levels) -> bins
+    const float ydq = A.ydq, ywin = A.ywin;
 
 #ifdef AMT_LIN_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -148,18 +345,20 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     float* const myacc = wacc + wave * G * (kLinAccFrameBytes / 4);
     for (int i = lane; i < G * (kLinAccFrameBytes / 4); i += 64) myacc[i] = 0.0f;
     const unsigned myacc_base = __builtin_amdgcn_readfirstlane(lds_address(myacc));
-    // the wave's own copy of the fades, lane f <-> fade f (read back by the bin fix-up; a wave's LDS operations complete in order)
-    float* const myfades = wacc + kLinWaves * G * (kLinAccFrameBytes / 4) + wave * 16;
-    if (lane < 16) myfades[lane] = A.fades[A.fade0 + min(lane, NF - 1)];
-    const unsigned myfades_base = __builtin_amdgcn_readfirstlane(lds_address(myfades));
+    // the wave's list of (pixel, frame, fade) pairs whose bin the exact mean must confirm: {slot | frame << 20 | fade << 23 | bin << 27, x}
+    u2* const queues = reinterpret_cast<u2*>(wacc + kLinWaves * G * (kLinAccFrameBytes / 4));          // [kLinWaves][qcap]
+    int* const qcount = reinterpret_cast<int*>(queues + kLinWaves * A.qcap);                          // [kLinWaves] pairs found (may exceed qcap: overflow)
+    u2* const myqueue = queues + wave * A.qcap;
+    int qn = 0;                                                  // (wave-uniform)
 
     f2* const myplane = planes + wave * kTileCap;
     const unsigned plane_base = lds_address(myplane);
-    TileStager<pix_t, false, true> st;
-    st.init(Lp, A.pitch, A.maxv, myplane, nullptr);
-    TilePixel px;
-    f2 PQ;                                                       // this lane's pixel: its response on flat level c is |PQ.x + PQ.y * c|
+    typedef LinStager<pix_t, BLEND> Stager;
+    Stager st;
+    st.init(A.pitch, A.maxv, myplane);
+    LinPixel px;
     TileDesc T;
+    const gptr_t gTab = table_base(gLin);
 
     // this wave's tiles: entries wave, wave + 4, ... of the logo's list of tiles.  (i, g) = (list position, frame) of an iteration
     auto advance = [&](int& i, int& g) {
@@ -167,48 +366,47 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         g = last ? 0 : g + 1;
         i = last ? i + kLinWaves : i;
     };
-    // Pipeline: while iteration i is evaluated, the raw samples of i + 1 sit in registers and those of i + 2 travel.
+    // Pipeline: while iteration i is evaluated, the raw samples of i + 1 travel (requested an iteration ago: hand-written loads, see above).
     //   A. window reads of i from the plane, means and correlations of s and bg
-    //   B. the fades' bins (a mean next to a bin edge: the reference's exact mean decides, rare)
+    //   B. the fades' bins; means next to a bin edge are listed for the exact check after the loop
+    //   B'. a new tile next: its pixel's taps, slot word and response line are requested (the compiler's loads) ...
     //   T. the 11 terms, their sums over the quads of lanes, added to the wave's running sums of the frame in LDS.  No table is looked
     //      up: the scale of a term is a function of the bin number and two per-pixel constants (see "T." below)
-    //   C. raw(i + 1) -> plane; request raw(i + 2)   (the pixel / taps of i + 1, if its tile is a new one, are requested first)
+    //   T'. ... and consumed: the compiler's wait for them sits here, where nothing else is in flight but the raw samples C needs next
+    //   C. raw(i + 1) -> plane; request raw(i + 2)
     int i0 = wave, g0 = 0;                                       // iteration i
-    int i1 = i0, g1 = 0;                                         // iteration i + 1 (its raw samples are in the registers)
+    int i1 = i0, g1 = 0;                                         // iteration i + 1 (its raw samples are in flight)
     int iu = -1;                                                 // the list position whose tile the staging units describe
-    PQ = f2{0.0f, 0.0f};
     if (i0 < ntl) {
         const int t0 = tlist[i0];
         fetch_tile(T, tiles + t0);
-        st.setup_units(T, lane);
+        st.setup_units(Lp, Xp, T, lane);
         iu = i0;
-        st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0));
-        asm volatile("" ::: "memory");                             // (see eval_pair_kernels.hip: the raw loads stay ahead of the tap loads)
-        px.load(Xp, (unsigned)t0 * 64u + (unsigned)lane, T, plane_base);
-        PQ = gld<f2>(gPq, px.slot8);
+        st.request(frame_desc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0));
+        px.load(gTab, nslots8, off_sinfo, off_pq, (unsigned)t0 * 64u + (unsigned)lane, T);
+        px.landed();
+        st.template landed<0>();
         st.convert();
-        // (the first taps have arrived before the loop: the wait the compiler places at the loop head is the merge of this path and
-        //  the back edge, and on the back edge the taps of a new tile are the OLDEST loads in flight -- see step B')
-#pragma unroll
-        for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(px.Kp[j]));
         advance(i1, g1);
-        if (i1 < ntl) {
-            if (i1 != iu) { fetch_tile(T, tiles + tlist[i1]); st.setup_units(T, lane); iu = i1; }
-            st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + g1));
+        {
+            const bool more = i1 < ntl;
+            if (more && i1 != iu) { fetch_tile(T, tiles + tlist[i1]); st.setup_units(Lp, Xp, T, lane); iu = i1; }
+            st.request(frame_desc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + (more ? g1 : g0)));
         }
     }
-    while (i0 < ntl) {
+    if (i0 < ntl) for (;;) {
+        const f2 PQ = px.PQ;                                       // (B' below overwrites the pixel; the terms are this pixel's)
         AMT_LTICK(0);
         // ---- A. ONE window evaluation for both operands: R = {corr(s), corr(bg)}, M = {mean(s), mean(bg)} ----
         // (the taps' {k, k} broadcasts live in the multiply-adds' op_sel: eval_tile_stage.h pk_fma_tap)
         f2 R, M;
         {
             unsigned wrow[5];
-            px.rows(wrow);
+            px.rows(plane_base, wrow);
 #ifdef AMT_LIN_NO_EVAL                                          // (ablations of the instrumented builds: wrong results, timing only)
             R = px.Kp[0]; M = px.Kp[1] + f2{100.0f, 120.0f};
 #else
-            window_eval_streamed(wrow, px.Kp, M, R);         // idle lanes read the tile's first window: finite values, zero taps
+            window_eval_streamed<sizeof(pix_t) == 1>(wrow, px.Kp, M, R);         // idle lanes read the tile's first window: finite values, zero taps
 #endif
         }
         AMT_LTICK(2);
@@ -231,40 +429,42 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             if (!end) emin = __builtin_fminf(emin, __builtin_amdgcn_fractf(y));
             binf[f] = __builtin_amdgcn_fmed3f(__builtin_floorf(y), 0.0f, 31.0f);       // (int)clamp(mean, 0, 255) >> 3; a NaN mean gives bin 0 like the reference's (int)NaN = INT_MIN
         }
-        // (uncommon -- one wave iteration in five has such a pixel -- and kept small in code and registers: a rolled loop; unrolled, the
-        //  inlined window re-reads cost the whole kernel its occupancy.  The fades come out of a vector register by v_readlane,
-        //  filled from the wave's copy in LDS: a scalar load per fade would put memory latencies in a row.)
-#ifdef AMT_LIN_NO_FIXUP
-        const bool near_edge = false;
-#else
-        const bool near_edge = px.act && emin < ywin;
-#endif
-        if (__builtin_amdgcn_ballot_w64(near_edge) != 0) {         // wave-uniform: every lane reads the fades (v_readlane needs lanes 0..10)
-            unsigned wrow[5];
-            px.rows(wrow);
-            int lane_here = lane;                                  // (opaque: hoisted out of the loop this address would be spilled, and its
-            asm volatile("" : "+v"(lane_here));                    //  reload waits for every load in flight)
-            const float fadev = *(const __attribute__((address_space(3))) float*)(unsigned long long)(myfades_base + (unsigned)(lane_here & 15) * 4u);
-#pragma unroll 1
-            for (int f = 1; f < NF - 1; ++f) {
-                const float fade = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fadev), f));
-                if (near_edge && __builtin_amdgcn_fractf(__builtin_fmaf(fade, dy, y0d)) < ywin) {
-                    const float nb = (float)score_bin_dev(exact_blend_mean_2trips(wrow, fade));
+        // A mean within bin_eps of a bin edge (3e-4 of all (pixel, fade) pairs; one wave iteration in five has one): the term below is
+        // formed with the TENTATIVE bin floor(y), and the pair is put on the wave's list {slot, frame, fade, tentative bin; x}.  When the
+        // workgroup has finished, every listed pair is looked at with all threads at once: the mean evaluated exactly as the reference
+        // does (from the frame itself), its bin, and -- where that differs -- the difference of the two terms as a correction to the
+        // frame's sum.  (Rounds 2-5 re-evaluated the mean on the spot, for one or two lanes while sixty-two waited: 14 % of the kernel
+        // and, through the registers its window took, the reason the loop could not carry more.)
+#ifndef AMT_LIN_NO_FIXUP
+        {
+            const bool near_edge = px.act() && emin < ywin;
+            if (__builtin_amdgcn_ballot_w64(near_edge) != 0) {         // wave-uniform
+                const float R0q = R.x, dRq = R.y - R.x;
+                const unsigned code0 = (px.slot8 >> 3) | ((unsigned)g0 << 20);
 #pragma unroll
-                    for (int ff = 0; ff < NF; ++ff) binf[ff] = ff == f ? nb : binf[ff];
+                for (int f = 1; f < NF - 1; ++f) {
+                    const bool flag = near_edge && __builtin_amdgcn_fractf(__builtin_fmaf(fd[f], dy, y0d)) < ywin;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+                    if (m != 0) {
+                        const unsigned pos = (unsigned)qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (flag && pos < (unsigned)A.qcap)
+                            myqueue[pos] = u2{code0 | ((unsigned)f << 23) | ((unsigned)binf[f] << 27), __builtin_bit_cast(unsigned, __builtin_fmaf(fd[f], dRq, R0q))};
+                        qn += __builtin_popcountll(m);
+                    }
                 }
             }
         }
+#endif
         AMT_LTICK(3);
         // ---- B'. a new tile next: its pixel and taps are requested BEFORE the raw samples -- vector-memory loads return in order, and
         //      the taps are what the next iteration needs first ----
-        f2 PQn = PQ;
-        if (i1 < ntl && i1 != i0) {
+        const bool new_tile = i1 < ntl && i1 != i0;
+        if (new_tile) {
             const int t1 = tlist[i1];
             TileDesc Tn;
             fetch_tile(Tn, tiles + t1);
-            px.load(Xp, (unsigned)t1 * 64u + (unsigned)lane, Tn, plane_base);
-            PQn = gld<f2>(gPq, px.slot8);                           // (this iteration's terms below still need the CURRENT pixel's response line)
+            // (the lane number is re-derived where a tile begins: carried through the loop it is the 16-bit kernel's register 129)
+            px.load(gTab, nslots8, off_sinfo, off_pq, (unsigned)t1 * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), Tn);
         }
         // ---- T. the terms.  The reference looks {scale, scale2} = {1 / r, min(1, r / L)} up by bin, r = |response of the pixel's kernel on
         //      that flat level| (LogoScan.hpp:190-207), and forms clamp(x * scale, -1, 1) * scale2 (:305-308) = clamp(x, -r, r) / max(r, L).
@@ -277,8 +477,11 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #ifndef AMT_LIN_NO_FLUSH
         {
             typedef __attribute__((address_space(3))) f4* lds_quad;
-            const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)g0 * (unsigned)kLinAccFrameBytes + (unsigned)(lane >> 2) * 48u);
             const float R0 = R.x, dR = R.y - R.x;
+            // Every lane of a quad ends up with all eleven quad sums; lane j < 3 of the quad keeps the four of fades 4j .. 4j + 3 and adds
+            // them to its 16 bytes of the quad's cell: ONE 16-byte read-modify-write per iteration for the whole wave (a 16-byte LDS store
+            // costs 13 cycles of the CU's store path whatever its exec mask: three of them by lane 0 alone were a fifth of the loop's LDS time)
+            f4 mine;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 float term[4];
@@ -291,40 +494,55 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
                         float t = __builtin_amdgcn_fmed3f(x, -resp, resp) * __builtin_amdgcn_rcpf(__builtin_fmaxf(resp, floorResp));
                         t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
                         t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
-                        asm volatile("" : "+v"(t));       // (left alone the add sinks into the lane-0 branch below and its DPP operand stays a v_mov_b32_dpp)
                         term[r] = t;
                     } else term[r] = 0.0f;
                 }
-                if ((lane & 3) == 0) {
-                    const f4 o = cell[q];
-                    cell[q] = f4{o[0] + term[0], o[1] + term[1], o[2] + term[2], o[3] + term[3]};
+                if (q == 0) mine = f4{term[0], term[1], term[2], term[3]};
+                else {
+                    const bool me = (lane & 3) == q;
+                    mine = f4{me ? term[0] : mine[0], me ? term[1] : mine[1], me ? term[2] : mine[2], me ? term[3] : mine[3]};
                 }
+                __builtin_amdgcn_sched_barrier(0);          // (four fades at a time: left alone the scheduler computes all eleven terms first -- eleven registers too many)
+            }
+            if ((lane & 3) != 3) {
+                const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)g0 * (unsigned)kLinAccFrameBytes + (unsigned)(lane >> 2) * 48u + (unsigned)(lane & 3) * 16u);
+                cell[0] = cell[0] + mine;
             }
         }
 #endif
         AMT_LTICK(4);
-        PQ = PQn;
+        if (new_tile) px.landed();
         AMT_LTICK(5);
-        // ---- C. the next iteration's tile into the plane, its pixel if the tile changes, the raw samples of the one after ----
-        if (i1 < ntl) {
+        // ---- C. the next iteration's tile into the plane, the raw samples of the one after.  The request is issued on EVERY trip round the
+        //      loop (past the wave's last iteration it repeats the previous one): the compiler counts the loads in flight per path, and a
+        //      path without the six requests behind the taps would turn its wait for the taps at the loop head into a wait for everything ----
+        if (i1 >= ntl) break;
+        st.template landed<0>();
 #ifndef AMT_LIN_NO_CONVERT
-            st.convert();
+        st.convert();
 #endif
+        {
             int i2 = i1, g2 = g1;
             advance(i2, g2);
-            if (i2 < ntl) {
-                if (i2 != iu) { fetch_tile(T, tiles + tlist[i2]); st.setup_units(T, lane); iu = i2; }
-#if defined(AMT_LIN_RAW_SAMEFRAME)                              // (ablation: every request hits the cache -- what the raw loads' LATENCY costs)
-                st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, 0));
-#elif !defined(AMT_LIN_NO_RAW)                                    // (ablation: the samples of the first two requests are converted over and over)
-                st.request(frame_rsrc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + g2));
-#endif
+            const bool more = i2 < ntl;
+            if (more && i2 != iu) {
+                fetch_tile(T, tiles + tlist[i2]);
+                st.setup_units(Lp, Xp, T, (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+                iu = i2;
             }
+#if defined(AMT_LIN_RAW_SAMEFRAME)                              // (ablation: every request hits the cache -- what the raw loads' LATENCY costs)
+            st.request(frame_desc<pix_t>(A.Y, A.frame_map, A.frame_stride, 0));
+#else
+            st.request(frame_desc<pix_t>(A.Y, A.frame_map, A.frame_stride, F0 + (more ? g2 : g1)));
+#endif
         }
         AMT_LTICK(1);
         i0 = i1; g0 = g1;
         advance(i1, g1);
     }
+    // the request of the last trip is never converted: its loads must have landed before their registers can mean anything else
+    if (wave < ntl) st.template landed<0>();
+    if (lane == 0) qcount[wave] = qn;
     __syncthreads();
 #ifdef AMT_LIN_TIMING
     if (lane == 0 && blockIdx.x == gridDim.x / 6 && wave < 4) {      // a workgroup of logo 0 (the deint logo)
@@ -332,9 +550,37 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         for (int k = 0; k < 8; ++k) tb[wave * 8 + k] = tacc[k];
     }
 #endif
-    // the waves' sums, in order: per wave the 16 partial sums of a fade, front to back
     // (the thread index is re-derived: kept across the loop it would be one register too many)
     const int tid_end = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    // ---- the listed pairs, all threads at once: exact mean -> exact bin -> where it differs from the tentative one, the correction
+    //      t(exact bin) - t(tentative bin) replaces the pair's x in the list ----
+    bool overflow = false;
+    for (int q = 0; q < kLinWaves; ++q) {
+        const int nq = qcount[q];
+        overflow = overflow || nq > A.qcap;
+        for (int e = tid_end; e < min(nq, A.qcap); e += kLinWgThreads) {
+            const u2 ent = queues[q * A.qcap + e];
+            const unsigned slot = ent.x & 0xFFFFFu;
+            const int g = (int)((ent.x >> 20) & 7u), f = (int)((ent.x >> 23) & 15u), tb = (int)(ent.x >> 27);
+            const unsigned xbits = ent.y;              // (a scalar copy first: __builtin_bit_cast applied to the vector ELEMENT ent.y reads element 0 -- clang 19 / ROCm 7.2)
+            const float x = __builtin_bit_cast(float, xbits);
+            const unsigned pos = Xp->pos[slot];
+            const int srcFrame = A.frame_map ? A.frame_map[F0 + g] : F0 + g;
+            const pix_t* const frame = reinterpret_cast<const pix_t*>(A.Y) + (long long)srcFrame * A.frame_stride;
+            const float mean = exact_blend_mean_from_frame<pix_t>(Lp, frame, A.pitch, A.maxv, (int)(pos & 0xFFFFu), (int)(pos >> 16), A.fades[A.fade0 + f]);
+            const int eb = score_bin_dev(mean);
+            float delta = 0.0f;
+            if (eb != tb) {
+                const float2 pq = Xp->pq[slot];
+                const float re = __builtin_fabsf(__builtin_fmaf(pq.y, (float)eb, pq.x)), rt = __builtin_fabsf(__builtin_fmaf(pq.y, (float)tb, pq.x));
+                delta = __builtin_amdgcn_fmed3f(x, -re, re) * __builtin_amdgcn_rcpf(__builtin_fmaxf(re, floorResp))
+                      - __builtin_amdgcn_fmed3f(x, -rt, rt) * __builtin_amdgcn_rcpf(__builtin_fmaxf(rt, floorResp));
+            }
+            queues[q * A.qcap + e].y = __builtin_bit_cast(unsigned, delta);
+        }
+    }
+    __syncthreads();
+    // the waves' sums, in order: per wave the 16 partial sums of a fade, front to back, then the wave's corrections in list order
     if (tid_end < gcount * NF) {
         const int gg = tid_end / NF, f = tid_end - gg * NF;
         float r = 0.0f;
@@ -343,26 +589,45 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             float rq = 0.0f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) rq += cells[j * 12];
+            const unsigned key = ((unsigned)gg << 20) | ((unsigned)f << 23);
+            const int nq = min(qcount[q], A.qcap);
+            for (int e = 0; e < nq; ++e) {
+                const u2 ent = queues[q * A.qcap + e];
+                const unsigned dbits = ent.y;
+                if ((ent.x & 0x07F00000u) == key) rq += __builtin_bit_cast(float, dbits);
+            }
             r += rq;
         }
         r = r / Lp->blackScore;
         if (A.take_abs) r = fabsf(r);
         A.out[(long long)(F0 + gg) * A.out_frame_stride + Lp->out_off + A.fade0 + f] = r;
     }
+    // a list that did not take every pair: the group's frames are left to the exact kernel (the guard's list; amt_gpu.hip analyze_run)
+    if (overflow && A.force != nullptr && tid_end < gcount) A.force[F0 + tid_end] = 1;
+}
+
+// A workgroup belongs to one logo: the deinterlaced logo's rows are [1 2 1] blends of three source rows (DeintY), a field logo's are
+// the source rows themselves (CopyY) -- a third of the loads and none of the blend arithmetic: two instances of the loop.
+template <typename pix_t>
+__device__ __forceinline__ void logo_eval_linear_split(const LinLaunch& A)
+{
+    if (A.logos[blockIdx.x / A.ngroups].deint) logo_eval_linear_body<pix_t, 11, true>(A);
+    else logo_eval_linear_body<pix_t, 11, false>(A);
 }
 
 // Four waves per SIMD (<= 128 registers) for both sample sizes.
 // (Inside the loop a spilled register would be reloaded with a wait for EVERY load in flight -- the pipeline's whole point.)
 __global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC, AMT_LIN_OCC)))
-void logo_eval_linear_kernel(const LinLaunch A) { logo_eval_linear_body<uint8_t, 11>(A); }
+void logo_eval_linear_kernel(const LinLaunch A) { logo_eval_linear_split<uint8_t>(A); }
 __global__ __launch_bounds__(kLinWgThreads) __attribute__((amdgpu_waves_per_eu(AMT_LIN_OCC16, AMT_LIN_OCC16)))
-void logo_eval_linear_kernel16(const LinLaunch A) { logo_eval_linear_body<uint16_t, 11>(A); }
+void logo_eval_linear_kernel16(const LinLaunch A) { logo_eval_linear_split<uint16_t>(A); }
 
 hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* dlogos, const TileLogoDev* dtls, int nlogos,
                                    const float* dfades, int nfades, int fade0, const void* dY,
                                    const int* dframe_map, long long frame_stride_elems, int pitch, int nframes, int G, float* dout,
-                                   int out_frame_stride, int take_abs, float bin_eps, int qlog2)
+                                   int out_frame_stride, int take_abs, float bin_eps, int qlog2, int qcap, uint8_t* dforce)
 {
+    if (qcap < 1 || qcap > 4096) return hipErrorInvalidValue;
     // (the caller guarantees dfades[fade0] == 0 and dfades[fade0 + nfades - 1] == 1: EvalEngine::run_linear)
     if (nframes <= 0 || nlogos <= 0 || nfades <= 0) return hipSuccess;
     if (qlog2 < 4 || qlog2 > 24 || !(bin_eps >= 0.0f) || bin_eps * (float)(1 << qlog2) > 1048576.0f) return hipErrorInvalidValue;
@@ -373,7 +638,14 @@ hipError_t launch_logo_eval_linear(hipStream_t st, int bits, const EvalLogoDev* 
     A.nfades = nfades; A.fade0 = fade0;
     A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
     A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs; A.bin_eps = bin_eps; A.qlog2 = qlog2;
-    const size_t lds = (size_t)kLinWaves * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * 16 * sizeof(float);
+    {
+        const float qscale = std::ldexp(1.0f, qlog2);
+        const int qe = (int)std::ceil(bin_eps * qscale), dq = qe + 1;
+        A.ydq = std::ldexp((float)dq, -(qlog2 + 3));
+        A.ywin = std::ldexp((float)(dq + qe + 1), -(qlog2 + 3));
+    }
+    A.qcap = qcap; A.force = dforce;
+    const size_t lds = (size_t)kLinWaves * kTileCap * 2 * sizeof(float) + (size_t)kLinWaves * G * kLinAccFrameBytes + (size_t)kLinWaves * qcap * 8 + (size_t)kLinWaves * sizeof(int);
     if (lds * (bits > 8 ? AMT_LIN_OCC16 : AMT_LIN_OCC) > 160 * 1024) return hipErrorInvalidValue;      // (the workgroups that share a CU must fit its LDS)
     dim3 grid((unsigned)((long long)A.ngroups * nlogos));
     if (bits <= 8) hipLaunchKernelGGL(logo_eval_linear_kernel, grid, dim3(kLinWgThreads), lds, st, A);

@@ -35,16 +35,18 @@ struct EvalLogoDev {
 };
 
 constexpr int kLinMaxFades = 12;    // fades the linear kernel's source is written for (11 for AMTAnalyzeLogo, the instantiated case)
+// Most frames a workgroup of the linear kernel takes; how many it does take follows from the LDS its list of bin checks leaves
+// (EvalEngine::run_linear: FOUR workgroups of four waves share a CU's 160 KB).
 #ifndef AMT_LIN_G
 #define AMT_LIN_G 7
 #endif
-constexpr int kLinMaxFrames = AMT_LIN_G;     // frames per workgroup of the linear kernel: bounded by the LDS its running sums take (FOUR workgroups share a CU's 160 KB: 16 KB of tile planes + 3 KB per frame each -> 7 frames; with three workgroups: 6 -> 2.977 ms per 10 000 frames, 7 -> 2.963, 8 -> 2.940, 10 -> 2.944)
+constexpr int kLinMaxFrames = AMT_LIN_G;
 #ifndef AMT_LIN_G16
 #define AMT_LIN_G16 7
 #endif
-constexpr int kLinMaxFrames16 = AMT_LIN_G16; // ... of its 16-bit instantiation: three workgroups per CU as well since round 5 (140 VGPRs; it had 180, two workgroups and 8 frames)
+constexpr int kLinMaxFrames16 = AMT_LIN_G16; // ... of its 16-bit instantiation: the same budget (four workgroups per CU, <= 128 registers)
 #ifndef AMT_LIN_WGS_MIN16
-#define AMT_LIN_WGS_MIN16 2048      /* (round 5, three workgroups per CU: 4 112-frame launches at 10 bits 6 frames 1.542 ms, 5: 1.568, 4: 1.615; 2 500-frame launches 6: 1.022, 4: 0.972 -- enough workgroups for ~3 rounds first) */
+#define AMT_LIN_WGS_MIN16 2048      /* (round 5: 4 112-frame launches at 10 bits 6 frames 1.542 ms, 5: 1.568, 4: 1.615; 2 500-frame launches 6: 1.022, 4: 0.972 -- enough workgroups for ~3 rounds first) */
 #endif
 
 // a band = up to kEvalThreads consecutive run slots (one per thread) and the logo rows their windows touch

@@ -113,9 +113,6 @@ __device__ __forceinline__ f2 pk_fma_tap(int hi, bool first, f2 kp, f2 w, f2 acc
     }
     return r;
 }
-#ifndef AMT_LIN_WINDOW_ONE_TRIP
-#define AMT_LIN_WINDOW_ONE_TRIP 1
-#endif
 // The same evaluation with all 25 window reads issued at once (one LDS round trip; 50 registers of window instead of 30 -- the linear
 // kernel has them since its taps' broadcasts moved into the multiply-adds).  Same operations in the same order: identical results.
 __device__ __forceinline__ void window_eval_one_trip(const unsigned (&wrow)[5], const f2 (&Kp)[13], f2& M, f2& R)
@@ -146,28 +143,32 @@ __device__ __forceinline__ void window_eval_one_trip(const unsigned (&wrow)[5], 
     const f2 sum = acc0 + acc1;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(R) : "v"(Kp[12]), "v"(M), "v"(sum));
 }
+// ONE_TRIP: 50 registers of window at once (the 8-bit kernel has them); otherwise THREE round trips -- rows 0-1, rows 2-3, row 4 -- with
+// at most 20 (the 16-bit kernel, whose raw samples in flight take twice the room).  Same operations in the same order: identical results.
+template <bool ONE_TRIP>
 __device__ __forceinline__ void window_eval_streamed(const unsigned (&wrow)[5], const f2 (&Kp)[13], f2& M, f2& R)
 {
-    if (AMT_LIN_WINDOW_ONE_TRIP) { window_eval_one_trip(wrow, Kp, M, R); return; }
-    f2 ra[10], rb[10], r4[5];
+    if (ONE_TRIP) { window_eval_one_trip(wrow, Kp, M, R); return; }
+    f2 ra[10];
     window_rows_issue2(wrow[0], wrow[1], ra);
-    window_row_issue1(wrow[4], r4);
     f2 acc0 = {0.0f, 0.0f}, acc1 = acc0, c[5];
     auto mac = [&](int e, f2 wv) {
         if (e & 1) acc1 = pk_fma_tap(1, e == 1, Kp[e >> 1], wv, acc1);
         else acc0 = pk_fma_tap(0, e == 0, Kp[e >> 1], wv, acc0);
     };
-    rows_ready2<5>(ra);
+    rows_ready2<0>(ra);
 #pragma unroll
     for (int i = 0; i < 5; ++i) c[i] = ra[i] + ra[5 + i];
 #pragma unroll
     for (int e = 0; e < 10; ++e) mac(e, ra[e]);
-    window_rows_issue2(wrow[2], wrow[3], rb);    // (into the registers rows 0 and 1 have left)
-    rows_ready2<0>(rb);
+    window_rows_issue2(wrow[2], wrow[3], ra);    // (into the registers rows 0 and 1 have left)
+    rows_ready2<0>(ra);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) c[i] = c[i] + (rb[i] + rb[5 + i]);
+    for (int i = 0; i < 5; ++i) c[i] = c[i] + (ra[i] + ra[5 + i]);
 #pragma unroll
-    for (int e = 0; e < 10; ++e) mac(10 + e, rb[e]);
+    for (int e = 0; e < 10; ++e) mac(10 + e, ra[e]);
+    f2 r4[5];
+    window_row_issue1(wrow[4], r4);
     row_ready1<0>(r4);
 #pragma unroll
     for (int i = 0; i < 5; ++i) c[i] = c[i] + r4[i];
@@ -209,6 +210,11 @@ template <> struct Quad<uint8_t> {
         s[3] = __builtin_amdgcn_ldexpf((float)(so >> 16), -2);
     }
     static constexpr unsigned kBias = 0x00020002u;
+    // a row that is never blended (CopyY, LogoScan.hpp:782-790): the four samples as they are
+    static __device__ __forceinline__ void copy(const Quad& r1, float (&s)[4])
+    {
+        s[0] = (float)(r1.v & 0xFFu); s[1] = (float)((r1.v >> 8) & 0xFFu); s[2] = (float)((r1.v >> 16) & 0xFFu); s[3] = (float)(r1.v >> 24);   // v_cvt_f32_ubyte0..3
+    }
 };
 template <> struct Quad<uint16_t> {
     u2 v;
@@ -223,6 +229,11 @@ template <> struct Quad<uint16_t> {
         }
     }
     static constexpr unsigned kBias = 2u;
+    static __device__ __forceinline__ void copy(const Quad& r1, float (&s)[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = (float)((r1.v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+    }
 };
 
 typedef const __attribute__((address_space(4))) TileDesc* const_tile_ptr;          // constant address space: scalar loads
@@ -240,7 +251,8 @@ __device__ __forceinline__ void fetch_tile(TileDesc& D, const_tile_ptr t)
 // 16 registers -- for kernels that are short of registers.
 // SLIM: the byte offsets of the rows above / below a unit are re-derived at every request (4 more instructions) instead of kept (4
 // registers), and "this row is blended" rides in the sign bit of the unit's LDS offset instead of in a register of its own.
-template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileStager {
+// BLEND = false: a logo whose rows are never blended (field logos: CopyY) -- one row load per unit instead of three, no [1 2 1] sums.
+template <typename pix_t, bool AB_LDS = false, bool SLIM = false, bool BLEND = true> struct TileStager {
     static constexpr int ES = (int)sizeof(pix_t);
     // (wave-uniform)
     int w, h, deint, srow0, srow_step, scol0, pitchB;
@@ -271,7 +283,7 @@ template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileSta
 #pragma unroll
         for (int k = 0; k < kTileUnits; ++k) {
             const TileUnit U = tile_unit(T, lane + 64 * k, w);
-            const bool blend = deint && U.y > 0 && U.y < h - 1;       // DeintY copies the first and the last row (LogoScan.hpp:763-780)
+            const bool blend = BLEND && deint && U.y > 0 && U.y < h - 1;       // DeintY copies the first and the last row (LogoScan.hpp:763-780)
             ulds[k] = SLIM ? (U.lds | (blend ? (int)0x80000000 : 0)) : U.lds;
             if (!SLIM) ubias[k] = blend ? Quad<pix_t>::kBias : 0u;
             ug[k][1] = (srow0 + U.y * srow_step) * pitchB + (scol0 + U.xs) * ES;
@@ -296,7 +308,9 @@ template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileSta
     {
 #pragma unroll
         for (int k = 0; k < kTileUnits; ++k) {
-            if (SLIM) {
+            if (!BLEND) {
+                raw[k][1].load(frame, ug[k][1]);
+            } else if (SLIM) {
                 const int d = (ulds[k] >> 31) & pitchB;           // a blended row: the rows above and below; otherwise the row itself
                 raw[k][0].load(frame, ug[k][1] - d);
                 raw[k][1].load(frame, ug[k][1]);
@@ -313,7 +327,8 @@ template <typename pix_t, bool AB_LDS = false, bool SLIM = false> struct TileSta
         float sv[4];
         const unsigned bias = SLIM ? ((unsigned)(ulds[k] >> 31) & Quad<pix_t>::kBias) : ubias[k];
         const int lds = SLIM ? (ulds[k] & 0x7FFFFFFF) : ulds[k];
-        Quad<pix_t>::blend(raw[k][0], raw[k][1], raw[k][2], bias, sv);
+        if (BLEND) Quad<pix_t>::blend(raw[k][0], raw[k][1], raw[k][2], bias, sv);
+        else Quad<pix_t>::copy(raw[k][1], sv);
         f2* dst = plane + lds;
         if (AB_LDS) {
             const f4* c = reinterpret_cast<const f4*>(abplane + lds);

@@ -279,6 +279,11 @@ int  amtgpu_analyze_batch_host(AmtGpuAnalyze* an, const void* dY, int64_t frame_
 int   amtgpu_analyze_set_mode(AmtGpuAnalyze* an, int mode);
 /* frames of the most recent batch that the guard re-evaluated exactly (synchronises); 0 in exact mode, -1 on error */
 int   amtgpu_analyze_last_refined(AmtGpuAnalyze* an);
+/* Linear modes: (pixel, frame, fade) pairs whose window mean lies within the evaluation's error bound of a bin edge (LogoScan.hpp:304 is
+ * discontinuous there) are listed per wave and settled exactly when the workgroup has finished; a workgroup whose list overflows leaves
+ * its frames to the exact kernel (they are counted by amtgpu_analyze_last_refined).  entries = pairs a wave can list, 16 .. 640,
+ * default 256; fewer frames share a workgroup as the list grows (LDS).  A tuning knob: results do not depend on it. */
+int   amtgpu_analyze_set_fixup_queue(AmtGpuAnalyze* an, int entries);
 /* the linear mode's bound on |score - reference score| for group 0 = p, 1 = t, 2 = b at the given bit depth; 0 in exact mode */
 float amtgpu_analyze_error_bound(AmtGpuAnalyze* an, int group, int bits);
 

@@ -335,3 +335,41 @@ def test_linear_mode_at_its_largest_frame_group(gpu, bits):
     assert an.last_refined() <= N // 20
     er = AMTEraseLogo(ctx, logo, "", 0, 16)
     assert er.calc_fades(e, N).tobytes() == er.calc_fades(l, N).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 10])
+def test_linear_mode_bin_check_list(gpu, bits):
+    """The linear kernel lists the (pixel, frame, fade) pairs whose interpolated mean lies within its error bound of a bin edge and
+    settles them from the frame itself once a workgroup has finished (LogoScan.hpp:304 is discontinuous there).  (1) The length of the
+    list is a tuning knob: records identical for every length that takes all pairs.  (2) A list that is too short makes the workgroup
+    leave its frames to the exact kernel: with 16 entries many workgroups overflow; their frames are counted as refined and carry the
+    exact mode's bytes, every other frame is unchanged.  (3) Without the check the tentative bins leave errors an order of magnitude above the checked
+    kernel's: the check is alive (every second listed pair changes its bin)."""
+    import torch
+    import amt_synth as S
+    from amatsukaze_amd import AMTAnalyzeLogo, Logo
+    W, H, LW, LH, X, Y0, N = 720, 480, 160, 80, 500, 30, 2100
+    data, alpha, alphaUV = S.make_logo(LW, LH, seed=0x10600071)
+    clip = S.make_clip_torch(N, W, H, 0x5EED0071, alpha, alphaUV, X, Y0, gpu["dev"], period=53, fade=6, chroma=False, bits=bits)
+    Yd, ctx = clip["Y"], gpu["ctx"]
+    logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
+    run = lambda an: (lambda o: (an.analyze_device(Yd, bits, o), torch.cuda.synchronize(), o.cpu().numpy())[2])(torch.empty((N, 33), dtype=torch.float32, device=gpu["dev"]))
+    exact = run(AMTAnalyzeLogo(ctx, logo, 0.35))
+    raw = AMTAnalyzeLogo(ctx, logo, 0.35, mode="linear_unguarded")
+    base = run(raw)
+    assert np.abs(base - exact).max() <= 2e-5
+    for entries in (384, 640):
+        raw.set_fixup_queue(entries)
+        assert run(raw).tobytes() == base.tobytes(), entries
+    guarded = AMTAnalyzeLogo(ctx, logo, 0.35, mode="linear")
+    g = run(guarded)
+    assert guarded.last_refined() <= N // 20 and np.abs(g - exact).max() <= 2e-5
+    guarded.set_fixup_queue(16)
+    g16 = run(guarded)
+    r16 = guarded.last_refined()
+    as_exact = (g16 == exact).all(axis=1) | np.isnan(g16).all(axis=1)
+    as_before = (g16 == g).all(axis=1)
+    assert r16 > N // 4 and (as_exact | as_before).all() and as_exact.sum() >= r16, (r16, int(as_exact.sum()), int(as_before.sum()))
+    with pytest.raises(Exception):
+        guarded.set_fixup_queue(641)

@@ -5,6 +5,9 @@ fail HERE, not as a corrupted score somewhere:
   * no scratch and no spills (a spilled tap or window register costs the fade loop 2-3x, and the ablation notes in profiles/ assume none),
   * VGPRs within the occupancy each kernel is designed for,
   * no MFMA (these are per-pixel private 25-tap kernels in a prescribed summation order),
+  * the linear kernel's raw-sample loads are inline assembly with a hand-placed vmcnt wait (the compiler neither counts nor waits for
+    them): no instruction may read a register such a load writes before the next vmcnt wait -- a copy of a loaded value placed behind
+    the load by the register allocator would read stale data (seen while the loop was written),
   * and the one that can corrupt silently: eval_tile_stage.h places `s_waitcnt lgkmcnt(N)` with N > 0 by hand to consume LDS reads in
     issue order while later ones are still in flight.  LDS operations of a wave return in order, scalar memory loads do NOT, and both
     count in lgkmcnt -- a partial wait is only meaningful while no s_load / s_buffer_load is outstanding.  The check walks the
@@ -138,6 +141,75 @@ def partial_waits_with_smem_outstanding(body):
     return hits, len(blocks)
 
 
+def reads_of_registers_in_flight(raw_body):
+    """raw_body: the kernel's lines WITH comments (;;#ASMSTART / ;;#ASMEND mark inline assembly).  Walks the text in order: a buffer_ /
+    global_ load inside an inline-assembly block puts its destination registers "in flight" until the next `s_waitcnt ... vmcnt`; any
+    instruction that names one of them as a source before that is returned.  (Linear scan: the loop's loads are issued at its end and
+    waited for one trip later, so the scan wraps round once.)"""
+    def regs(tok):
+        out = set()
+        for a, b in re.findall(r"v\[(\d+):(\d+)\]", tok):
+            out |= set(range(int(a), int(b) + 1))
+        for a in re.findall(r"\bv(\d+)\b", tok):
+            out.add(int(a))
+        return out
+    hits, pending, inasm = [], {}, False
+    for l in raw_body:
+        if "#ASMSTART" in l:
+            inasm = True
+            continue
+        if "#ASMEND" in l:
+            inasm = False
+            continue
+        t = l.split(";")[0].strip()
+        if not t or t.endswith(":") or t.startswith("."):
+            continue
+        op = t.split()[0]
+        if op == "s_waitcnt" and "vmcnt" in t:
+            pending.clear()
+            continue
+        ops = t[len(op):].split(",")
+        if inasm and re.match(r"(buffer_load|global_load)", op):
+            srcs = ops[1:]
+            for o in srcs:
+                for r in regs(o):
+                    if r in pending:
+                        hits.append((t, f"v{r}", pending[r]))
+            for r in regs(ops[0]):
+                pending[r] = t
+            continue
+        nodst = op.startswith(("ds_write", "buffer_store", "global_store", "scratch_store", "s_", "v_cmp", "v_cmpx"))
+        for o in (ops if nodst else ops[1:]):
+            for r in regs(o):
+                if r in pending:
+                    hits.append((t, f"v{r}", pending[r]))
+    return hits
+
+
+def raw_kernel_bodies(asm):
+    return {m.group(1): m.group(2).splitlines() for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M)}
+
+
+def test_in_flight_scan_sees_a_planted_copy():
+    good = [";;#ASMSTART", "buffer_load_dword v5, v1, s[0:3], 0 offen", ";;#ASMEND", "v_add_f32 v2, v3, v4", ";;#ASMSTART", "s_waitcnt vmcnt(0)", ";;#ASMEND",
+            "v_mov_b32 v6, v5"]
+    bad = [";;#ASMSTART", "buffer_load_dword v5, v1, s[0:3], 0 offen", ";;#ASMEND", "v_mov_b32 v6, v5", ";;#ASMSTART", "s_waitcnt vmcnt(0)", ";;#ASMEND"]
+    assert not reads_of_registers_in_flight(good) and reads_of_registers_in_flight(bad)
+    # a compiler load is not tracked (the compiler waits for its own loads)
+    assert not reads_of_registers_in_flight(["global_load_dword v5, v1, s[0:1]", "s_waitcnt vmcnt(0)", "v_mov_b32 v6, v5"])
+
+
+def test_linear_kernel_reads_no_register_in_flight():
+    asm = compile_asm("eval_linear_kernels.hip")
+    bodies = {k: v for k, v in raw_kernel_bodies(asm).items() if "logo_eval_linear_kernel" in k}
+    assert len(bodies) == 2
+    for kname, body in bodies.items():
+        nasm = sum(1 for i, l in enumerate(body) if re.match(r"\s*buffer_load", l) and i > 0 and "#ASMSTART" in body[i - 1])
+        assert nasm >= 8, f"{kname}: the raw-sample loads are no longer inline assembly ({nasm})"
+        hits = reads_of_registers_in_flight(body)
+        assert not hits, f"{kname}: a register is read while its load is in flight: {hits[:3]}"
+
+
 def scratch_inside_loops(body):
     """scratch instructions between a label and a later branch back to it"""
     lines = [l.strip() for l in body]
@@ -172,20 +244,15 @@ def test_kernel_isa_properties(name):
     seen = set()
     for kname, k in ks.items():
         m = k["meta"]
-        if "logo_eval_linear_kernel16" in kname:
-            # four waves per SIMD leave this kernel one register short: ONE value may be parked before the loops and fetched back after
-            # them -- inside a loop a reload would wait for every load in flight
-            assert m["private_segment_fixed_size"] <= 8 and m["vgpr_spill_count"] <= 1, f"{kname}: scratch / spills {m}"
-            assert not scratch_inside_loops(k["body"]), f"{kname}: scratch access inside a loop"
-        else:
-            assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{kname}: scratch / spills {m}"
-        # (delogo_kernel and the staging / prologue blocks of the generic fused kernel park scalars in VGPR lanes -- v_writelane, no
-        # memory, none inside the fade loop: tolerated there; the tile kernels and the frame metrics must have none)
-        if name not in ("erase_scan_kernels.hip", "eval_fused_kernels.hip"):
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{kname}: scratch / spills {m}"
+        assert not scratch_inside_loops(k["body"]), f"{kname}: scratch access inside a loop"
+        # (delogo_kernel, the staging / prologue blocks of the generic fused kernel and the linear kernel -- whose loop carries more
+        # wave-uniform state than there are scalar registers -- park scalars in VGPR lanes: v_writelane, no memory.  The pair kernel and
+        # the frame metrics must have none)
+        if name not in ("erase_scan_kernels.hip", "eval_fused_kernels.hip", "eval_linear_kernels.hip"):
             assert m["sgpr_spill_count"] == 0, f"{kname}: scalar spills {m}"
         assert not any(re.match(r"^\s*v_(mfma|smfmac)", l) for l in k["body"]), f"{kname}: MFMA in a kernel that must not have any"
-        if "logo_eval_linear_kernel16" not in kname:
-            assert not any("scratch_" in l for l in k["body"]), f"{kname}: scratch instructions"
+        assert not any("scratch_" in l for l in k["body"]), f"{kname}: scratch instructions"
         for sub in sorted(budgets, key=len, reverse=True):          # the longest matching name decides (kernel16 before kernel)
             if sub in kname:
                 assert m["vgpr_count"] + m["agpr_count"] <= budgets[sub], f"{kname}: {m['vgpr_count']} VGPRs (+{m['agpr_count']} AGPRs) > {budgets[sub]}"

@@ -10,13 +10,16 @@ VARIANTS = {"noslp_all": {f: NOSLP for f in ("eval_linear_kernels.hip", "eval_pa
             "lin_maxilp": {"eval_linear_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]},
             "lin_maxmem": {"eval_linear_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]},
             "pair_maxilp": {"eval_pair_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}}
-DEFS = {"lin16_g8_occ2": ["AMT_LIN_G16=8", "AMT_LIN_OCC16=2"], "lin16_g8_occ3": ["AMT_LIN_G16=8"], "lin16_g4": ["AMT_LIN_G16=4"],
-        "stats_copying": ["AMT_STATS_PINGPONG=0"], "lin16_g5": ["AMT_LIN_G16=5"], "lin_prev_occ3_g8": ["AMT_LIN_FLUSH_FIRST=0", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3", "AMT_LIN_G=8", "AMT_LIN_G16=8"], "lin_ff_occ3": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"], "lin_ff_occ4_g7": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=7"],
-        "lin_ff_occ4_g6": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=6"],
-        "lin_ff_occ4_g7_16too": ["AMT_LIN_FLUSH_FIRST=1", "AMT_LIN_OCC=4", "AMT_LIN_G=7", "AMT_LIN_OCC16=4", "AMT_LIN_G16=7"],
-        "pair_early_reads": ["AMT_PAIR_EARLY_READS=1"], "abl_lin_raw_sameframe": ["AMT_LIN_RAW_SAMEFRAME"], "abl_lin_no_gather": ["AMT_LIN_NO_GATHER"], "abl_lin_gather4": ["AMT_LIN_GATHER4"],
-        "abl_lin_no_flush": ["AMT_LIN_NO_FLUSH"], "abl_lin_no_fixup": ["AMT_LIN_NO_FIXUP"], "lin_two_trips": ["AMT_LIN_WINDOW_ONE_TRIP=0"], "lin_ab_lds": ["AMT_LIN_AB_LDS=1"], "lin_g8": ["AMT_LIN_G=8", "AMT_LIN_G16=8"],
-        "lin_g10": ["AMT_LIN_G=10", "AMT_LIN_G16=10"], "lin_g7": ["AMT_LIN_G=7", "AMT_LIN_G16=7"], "lin_g5": ["AMT_LIN_G=5"], "lin_g4": ["AMT_LIN_G=4"]}
+DEFS = {"stats_copying": ["AMT_STATS_PINGPONG=0"],
+        # round 6, linear kernel: the pieces of the gather-free loop, one at a time
+        "lin_acc0": ["AMT_LIN_ACC3=0"], "lin_fix0": ["AMT_LIN_FIXMASK=0"], "lin_split0": ["AMT_LIN_DEINT_SPLIT=0"],
+        "lin_all0": ["AMT_LIN_ACC3=0", "AMT_LIN_FIXMASK=0", "AMT_LIN_DEINT_SPLIT=0"],
+        "lin_g6": ["AMT_LIN_G=6"], "lin_g8": ["AMT_LIN_G=8"], "lin_g5": ["AMT_LIN_G=5"],
+        "abl_lin_raw_sameframe": ["AMT_LIN_RAW_SAMEFRAME"], "abl_lin_no_flush": ["AMT_LIN_NO_FLUSH"], "abl_lin_no_fixup": ["AMT_LIN_NO_FIXUP"],
+        "abl_lin_no_convert": ["AMT_LIN_NO_CONVERT"], "abl_lin_no_eval": ["AMT_LIN_NO_EVAL"],
+        "dbg_lin_drain_all": ["AMT_LIN_DRAIN_ALL"], "dbg_lin_drain_nofix": ["AMT_LIN_DRAIN_ALL", "AMT_LIN_NO_FIXUP"], "dbg_lin_occ3": ["AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"],
+        "dbg_lin_nomean": ["AMT_LIN_DBG_NOMEAN"], "dbg_lin_noadd": ["AMT_LIN_DBG_NOADD"],
+        "dbg_lin_builtin": ["AMT_LIN_BUILTIN_LOADS", "AMT_LIN_NO_FIXUP", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"]}
 for k in DEFS:
     VARIANTS.setdefault(k, {})
 if "--build" in sys.argv:
