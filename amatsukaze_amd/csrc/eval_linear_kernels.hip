@@ -47,6 +47,28 @@ constexpr int kLinAccFrameBytes = 16 * 48;
 // (LogoScan.hpp:244-251, ComputeKernel.cpp:88-98) -- from the frame's samples themselves: s = the sample, or DeintY's (a + 2b + c + 2) / 4
 // (LogoScan.hpp:763-780; an integer sum below 2^24 times 0.25), bg = a*s + b*maxv, the blend, column sums ((r0 + r1) + (r2 + r3)) + r4,
 // hsum256_ps' order, /25.  The uncommon path of the bin select: run once per listed (pixel, frame, fade) after the workgroup's loop.
+// five adjacent samples of a source row, p[0..4], with as few loads as their alignment allows: the 4-byte words that hold them (the
+// listed pairs sit in different frames and rows -- every load instruction of the wave touches up to 64 cache lines, so the number of
+// load INSTRUCTIONS per pair is what the check costs)
+__device__ __forceinline__ void load5(const uint8_t* p, unsigned (&out)[5])
+{
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned* q = reinterpret_cast<const unsigned*>(a & ~3ull);
+    const unsigned sh = ((unsigned)a & 3u) * 8u;
+    const unsigned w0 = q[0], w1 = q[1];
+    const unsigned long long v = (((unsigned long long)w1 << 32) | w0) >> sh;          // bytes 0..3 (and 4 when sh < 32)
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    out[0] = lo & 0xFFu; out[1] = (lo >> 8) & 0xFFu; out[2] = (lo >> 16) & 0xFFu; out[3] = lo >> 24; out[4] = hi & 0xFFu;
+}
+__device__ __forceinline__ void load5(const uint16_t* p, unsigned (&out)[5])
+{
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned* q = reinterpret_cast<const unsigned*>(a & ~3ull);
+    const bool odd = (a & 2ull) != 0;
+    const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
+    if (odd) { out[0] = w0 >> 16; out[1] = w1 & 0xFFFFu; out[2] = w1 >> 16; out[3] = w2 & 0xFFFFu; out[4] = w2 >> 16; }
+    else { out[0] = w0 & 0xFFFFu; out[1] = w0 >> 16; out[2] = w1 & 0xFFFFu; out[3] = w1 >> 16; out[4] = w2 & 0xFFFFu; }
+}
 template <typename pix_t>
 __device__ __forceinline__ float exact_blend_mean_from_frame(const EvalLogoDev* Lp, const pix_t* frame, int pitch, float maxv, int x, int y, float fade)
 {
@@ -55,29 +77,41 @@ __device__ __forceinline__ float exact_blend_mean_from_frame(const EvalLogoDev* 
     const float* const la = Lp->a + (y - 2) * w + (x - 2);
     const float* const lb = Lp->b + (y - 2) * w + (x - 2);
     // the window's source rows: for a deinterlaced logo the rows above and below as well (seven in all), clamped to the logo's own rows
-    // -- the first and the last row are not blended and never look outside
+    // -- the first and the last row are not blended and never look outside.  (The words load5 reads lie inside the frame's rows: the
+    // window's columns x - 2 .. x + 2 are at least two samples from the rectangle's edge on either side.)
     const pix_t* const p0 = frame + (long long)(Lp->imgy + Lp->row0) * pitch + Lp->imgx + (x - 2);
+    unsigned raw[7][5];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const int yy = min(max(y - 3 + r, 0), h - 1);
+        if ((r == 0 || r == 6) && !deint) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) raw[r][i] = 0u;
+        } else {
+            load5(p0 + (long long)yy * step * pitch, raw[r]);
+        }
+    }
     float c[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        unsigned raw[7];
+    for (int i = 0; i < 5; ++i) c[i] = 0.0f;
+    float v[5][5];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int yy = min(max(y - 3 + r, 0), h - 1);
-            raw[r] = (r == 0 || r == 6) && !deint ? 0u : (unsigned)p0[(long long)yy * step * pitch + i];
-        }
-        float v[5];
+    for (int r = 0; r < 5; ++r) {
+        const int yy = y - 2 + r;
+        const bool blend = deint && yy > 0 && yy < h - 1;
+        float av[5], bv[5];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int yy = y - 2 + r;
-            const bool blend = deint && yy > 0 && yy < h - 1;
-            const float sv = blend ? __builtin_amdgcn_ldexpf((float)(((raw[r + 1] << 1) + raw[r]) + (raw[r + 2] + 2u)), -2) : (float)raw[r + 1];
-            const float bmv = lb[r * w + i] * maxv;
-            const float bg = la[r * w + i] * sv + bmv;
-            v[r] = fade_mix(fade, bg, sv);
+        for (int i = 0; i < 5; ++i) { av[i] = la[r * w + i]; bv[i] = lb[r * w + i]; }      // (adjacent: the compiler merges them into wide loads)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float sv = blend ? __builtin_amdgcn_ldexpf((float)(((raw[r + 1][i] << 1) + raw[r][i]) + (raw[r + 2][i] + 2u)), -2) : (float)raw[r + 1][i];
+            const float bmv = bv[i] * maxv;
+            const float bg = av[i] * sv + bmv;
+            v[r][i] = fade_mix(fade, bg, sv);
         }
-        c[i] = ((v[0] + v[1]) + (v[2] + v[3])) + v[4];
     }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = ((v[0][i] + v[1][i]) + (v[2][i] + v[3][i])) + v[4][i];
     return div25(hsum5(c[0], c[1], c[2], c[3], c[4]));
 }
 
