@@ -74,7 +74,8 @@ def build_variant(name: str, defines, extra_flags=(), file_flags=None) -> str:
     for f in SOURCES:
         o = os.path.join(bdir, f + ".o")
         objs.append(o)
-        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(f, []), *file_flags.get(f, []), *extra_flags, *[f"-D{d}" for d in defines], "-x", "hip", "-c",
+        # (-DAMT_INSTRUMENTED_BUILD: csrc/build_knobs.h refuses every knob without it -- the release build() below never sets it)
+        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(f, []), *file_flags.get(f, []), *extra_flags, "-DAMT_INSTRUMENTED_BUILD", *[f"-D{d}" for d in defines], "-x", "hip", "-c",
                os.path.join(CSRC, f), "-o", o]
         procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for f, p in procs:

@@ -1,5 +1,6 @@
 // amt_gpu.hip -- implementation of the C ABI declared in include/amt_gpu.h (part 1: context, ingest,
 // logo model, LogoFrame, AMTAnalyzeLogo).  Parts 2/3 live in amt_gpu_erase_scan.hip / amt_gpu_stats.hip.
+#include "build_knobs.h"
 #include "../../include/amt_gpu.h"
 
 #include <link.h>

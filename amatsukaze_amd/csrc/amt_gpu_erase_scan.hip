@@ -1,4 +1,5 @@
 // amt_gpu_erase_scan.hip -- C ABI part 2: AMTEraseLogo, LogoScan, ScanLogo.
+#include "build_knobs.h"
 #include "../../include/amt_gpu.h"
 
 #include <cfloat>

@@ -1,4 +1,5 @@
 // amt_gpu_ingest.hip -- C ABI part 4: frame assembly (field weave, NV12 split) of decoded pictures resident in HBM.
+#include "build_knobs.h"
 #include "../../include/amt_gpu.h"
 
 #include <vector>

@@ -1,4 +1,5 @@
 // amt_gpu_stats.hip -- C ABI part 3: self-specified whole-frame metrics and their host decisions.
+#include "build_knobs.h"
 #include "../../include/amt_gpu.h"
 
 #include <cstdio>

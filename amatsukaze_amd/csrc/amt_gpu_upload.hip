@@ -8,6 +8,7 @@
 // worker threads, and the ring has four slots so that the CPU fills slots k+1.. while the copy engine drains slot k.  A host that
 // can keep its frame buffers in place (a decoder's frame pool) registers them once (amtgpu_frames_register = hipHostRegister):
 // uploads from inside a registered range skip the ring altogether.
+#include "build_knobs.h"
 #include "../../include/amt_gpu.h"
 
 #if defined(__x86_64__)

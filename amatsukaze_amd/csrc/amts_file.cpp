@@ -18,6 +18,7 @@
 // The plan: AMTSource::OnFrameOutput (:482-566) matches every decoded picture to the frame list by its 33-bit PTS; a frame whose
 // halfDelay is set is woven from the PREVIOUS picture's top field and this picture's bottom field (MakeFrame(prev, cur)), any other
 // frame from one picture -- exactly the (top_index, bottom_index) pairs amtgpu_weave_fields_batch takes.
+#include "build_knobs.h"
 #include "../../include/amt_gpu.h"
 
 #include <algorithm>

@@ -1,4 +1,5 @@
 // decisions.cpp -- see decisions.hpp.  fp32 sums keep the reference's left-to-right order.
+#include "build_knobs.h"
 #include "decisions.hpp"
 
 #include <algorithm>

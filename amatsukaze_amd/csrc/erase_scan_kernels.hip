@@ -3,6 +3,7 @@
 // Both are elementwise / reduction passes over the logo rectangle only (w*h luma + 2*wUV*hUV chroma
 // samples per frame): HBM-bound, a few ops per byte.  One workgroup row = one rectangle row so that a
 // wave reads/writes one contiguous run of the frame; frames and rows give >> 256 workgroups.
+#include "build_knobs.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>

@@ -1,4 +1,5 @@
 // eval_engine.hip -- host side of the evaluation kernel: run slots, band partition, table upload, launches.
+#include "build_knobs.h"
 #include "engine.hpp"
 
 #include <algorithm>

@@ -24,6 +24,7 @@
 //   * per-pixel terms go to an LDS row per fade; one wave (rotating) adds each row front to back -- one lane per
 //     fade, the reference's order -- while the workgroup's next global loads are in flight.  Nothing but the final
 //     per-frame results touches HBM.
+#include "build_knobs.h"
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>

@@ -21,6 +21,7 @@
 // fade) in LDS cells that only it touches.  The summation order of this mode is free (it is not the reference's; the error bound
 // covers any order) but fixed: quads by DPP, tiles in turn, the 16 quads and the four waves in order at the end -- deterministic.
 // No barrier in the loop.
+#include "build_knobs.h"
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>

@@ -23,6 +23,7 @@
 // whatever their mix: profiles/r03_notes.md), so the code around the 101 packed operations of a window is kept short: raw
 // bytes are blended two samples per instruction (16-bit lanes), a tile of at most 64 units is staged in one pass, every
 // address that does not change within a band is kept in a register.
+#include "build_knobs.h"
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <algorithm>
@@ -76,9 +77,6 @@ struct PairLaunch {
     int out_frame_stride, take_abs;
 };
 
-#ifndef AMT_PAIR_EARLY_READS
-#define AMT_PAIR_EARLY_READS 0      /* measured round 5: 2.630 ms either way */
-#endif
 #ifdef AMT_PAIR_OCC
 #define AMT_PAIR_OCC_ATTR __attribute__((amdgpu_waves_per_eu(AMT_PAIR_OCC, AMT_PAIR_OCC)))
 #else
@@ -192,14 +190,6 @@ void logo_eval_pair_kernel(const PairLaunch A)
         st.convert();
 #endif
         AMT_PTICK(0);
-#if AMT_PAIR_EARLY_READS
-        // (the window reads are issued right behind the plane's stores -- a wave's LDS operations complete in order -- so that the next
-        //  iteration's requests below are issued under their latency)
-        f2 W[25];
-        unsigned wrow[5];
-        px.rows(wrow);
-        window_reads(wrow, W);
-#endif
         // ---- 2. the next iteration's raw samples travel during the evaluation (past the last iteration: a repeat nobody reads) ----
         if (band_end && b + 1 < nbands) {
             fetch_tile(T, tiles + (b + 1) * kTileWaves);
@@ -216,20 +206,14 @@ void logo_eval_pair_kernel(const PairLaunch A)
         //  makes them opaque per iteration and the broadcast folds into the multiply's op_sel)
 #pragma unroll
         for (int j = 0; j < 13; ++j) asm volatile("" : "+v"(px.Kp[j]));
-#if !AMT_PAIR_EARLY_READS
         f2 W[25];
         unsigned wrow[5];
         px.rows(wrow);
-#endif
 #ifdef AMT_PAIR_NO_EVAL
         const f2 M = px.Kp[1] + f2{100.0f, 120.0f}, R = px.Kp[0];
         (void)W;
 #else
-#if AMT_PAIR_EARLY_READS
-        const f2 M = window_means_as_rows_land(W);
-#else
-        const f2 M = window_load_means(wrow, W);
-#endif
+        const f2 M = window_load_means(wrow, W);      // (issuing the reads before the next requests instead: 2.630 ms either way, round 5)
         const f2 R = window_corr_exact(px.Kp, W, M);
 #endif
 #ifdef AMT_PAIR_TIMING

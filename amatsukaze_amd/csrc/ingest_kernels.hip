@@ -6,6 +6,7 @@
 // one interleaved UV plane that Copy2 splits into the planar U and V the rest of the pipeline expects.
 // A pure HBM copy: one wave per output row, 16 bytes per lane when rows are 16-byte aligned (AVFrame lines are 32/64-byte
 // aligned, AviSynth's 64), element by element otherwise.
+#include "build_knobs.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>

@@ -1,4 +1,5 @@
 // logo_fit.cpp -- see logo_fit.hpp
+#include "build_knobs.h"
 #include "logo_fit.hpp"
 
 #include <cmath>

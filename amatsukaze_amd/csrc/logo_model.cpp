@@ -1,4 +1,5 @@
 // logo_model.cpp -- see logo_model.hpp.  Host code; fp32 order-sensitive parts go through exact_math.h.
+#include "build_knobs.h"
 #include "logo_model.hpp"
 #include "exact_math.h"
 

@@ -1,4 +1,5 @@
 // stats_decisions.cpp -- see stats_decisions.hpp
+#include "build_knobs.h"
 #include "stats_decisions.hpp"
 
 #include <algorithm>

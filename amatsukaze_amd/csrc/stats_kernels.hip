@@ -20,6 +20,7 @@
 //   2 VERT_SAME  sum |Y_n[y-1] - Y_n[y+1]|                  5 SUM        sum Y_n
 //   6 VERT_PREV  VERT_SAME of that weave                    7 reserved (0)
 // avg(a,c) = (a + c) >> 1 per sample.
+#include "build_knobs.h"
 #include <hip/hip_runtime.h>
 #include <cstdint>
 

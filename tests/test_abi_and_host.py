@@ -541,3 +541,39 @@ def test_decisions_do_not_depend_on_how_the_clip_is_cut_over_threads(lib, thread
                 assert sc[:k.value].tolist() == FS.scene_changes(m, W, H)
     finally:
         lib.amtgpu_host_set_parallelism(0, 0)
+
+
+def test_release_build_defines_no_knob_and_knobs_are_fenced(tmp_path):
+    """The kernels carry ablation macros that compute WRONG results by design, phase timers and shape parameters.  The release library
+    is built with none of them (build.FLAGS / EXTRA_FLAGS carry no -DAMT_), and csrc/build_knobs.h -- included first by every source --
+    turns any of them on the command line into a compile error unless the build says it is an instrumented variant."""
+    import re
+    import subprocess
+    from amatsukaze_amd import build as B
+    flags = list(B.FLAGS) + [f for v in B.EXTRA_FLAGS.values() for f in v]
+    assert not [f for f in flags if f.startswith("-DAMT_")], flags
+    csrc = os.path.join(ROOT, "amatsukaze_amd", "csrc")
+    fence = open(os.path.join(csrc, "build_knobs.h")).read()
+    fenced = set(re.findall(r"defined\((AMT_[A-Z0-9_]+)\)", fence)) - {"AMT_INSTRUMENTED_BUILD"}
+    used = set()
+    for f in os.listdir(csrc):
+        text = open(os.path.join(csrc, f)).read()
+        if f != "build_knobs.h":
+            used |= set(re.findall(r"#\s*(?:ifn?def|if|elif)\b[^\n]*?\b(AMT_[A-Z0-9_]+)", text))
+            used |= set(re.findall(r"defined\((AMT_[A-Z0-9_]+)\)", text))
+        if f in B.SOURCES:
+            first = re.search(r'^#include\s+[<"]([^>"]+)[>"]', text, re.M)
+            assert first and first.group(1) == "build_knobs.h", f"{f}: build_knobs.h must be its first include"
+    # internal helper macros (defined by the sources themselves, never on a command line) are not knobs
+    internal = {"AMT_GPU_H", "AMT_HD", "AMT_TILE_HD", "AMT_HIP", "AMT_TRACE_SCOPE", "AMT_TRACE_CAT", "AMT_TRACE_CAT2", "AMT_TRACE_BLOCK_BEGIN",
+                "AMT_LTICK", "AMT_PTICK", "AMT_PDUMP", "AMT_TICK", "AMT_STATS_LAUNCH", "AMT_LAUNCH", "AMT_PAIR_OCC_ATTR", "AMT_INSTRUMENTED_BUILD"}
+    assert used - internal <= fenced, f"knobs the fence does not know: {sorted(used - internal - fenced)}"
+    # ... and the fence bites: an ablation on the command line of a release-style compile fails, the instrumented spelling passes
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "build_knobs.h"\nint main() { return 0; }\n')
+    cc = ["g++", "-fsyntax-only", "-I", csrc, str(src)]
+    assert subprocess.run(cc, capture_output=True).returncode == 0
+    for knob in ("AMT_LIN_NO_FIXUP", "AMT_PAIR_NO_SUM", "AMT_LIN_G=3", "AMT_FUSED_TIMING", "AMT_STATS_ROWS8=8", "AMT_EXPERIMENT"):
+        r = subprocess.run(cc + ["-D" + knob], capture_output=True, text=True)
+        assert r.returncode != 0 and "build_variant" in r.stderr, knob
+        assert subprocess.run(cc + ["-D" + knob, "-DAMT_INSTRUMENTED_BUILD"], capture_output=True).returncode == 0, knob

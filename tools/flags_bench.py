@@ -11,15 +11,12 @@ VARIANTS = {"noslp_all": {f: NOSLP for f in ("eval_linear_kernels.hip", "eval_pa
             "lin_maxmem": {"eval_linear_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]},
             "pair_maxilp": {"eval_pair_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}}
 DEFS = {"stats_copying": ["AMT_STATS_PINGPONG=0"],
-        # round 6, linear kernel: the pieces of the gather-free loop, one at a time
-        "lin_acc0": ["AMT_LIN_ACC3=0"], "lin_fix0": ["AMT_LIN_FIXMASK=0"], "lin_split0": ["AMT_LIN_DEINT_SPLIT=0"],
-        "lin_all0": ["AMT_LIN_ACC3=0", "AMT_LIN_FIXMASK=0", "AMT_LIN_DEINT_SPLIT=0"],
-        "lin_g6": ["AMT_LIN_G=6"], "lin_g8": ["AMT_LIN_G=8"], "lin_g5": ["AMT_LIN_G=5"],
+        "lin_g6": ["AMT_LIN_G=6"], "lin_g5": ["AMT_LIN_G=5"], "lin_g4": ["AMT_LIN_G=4"], "lin_occ3": ["AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"],
+        # ablations (wrong results by design: what a part of a kernel costs)
         "abl_lin_raw_sameframe": ["AMT_LIN_RAW_SAMEFRAME"], "abl_lin_no_flush": ["AMT_LIN_NO_FLUSH"], "abl_lin_no_fixup": ["AMT_LIN_NO_FIXUP"],
         "abl_lin_no_convert": ["AMT_LIN_NO_CONVERT"], "abl_lin_no_eval": ["AMT_LIN_NO_EVAL"],
-        "dbg_lin_drain_all": ["AMT_LIN_DRAIN_ALL"], "dbg_lin_drain_nofix": ["AMT_LIN_DRAIN_ALL", "AMT_LIN_NO_FIXUP"], "dbg_lin_occ3": ["AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"],
-        "dbg_lin_nomean": ["AMT_LIN_DBG_NOMEAN"], "dbg_lin_noadd": ["AMT_LIN_DBG_NOADD"],
-        "dbg_lin_builtin": ["AMT_LIN_BUILTIN_LOADS", "AMT_LIN_NO_FIXUP", "AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"]}
+        "abl_pair_raw_sameframe": ["AMT_PAIR_RAW_SAMEFRAME"], "abl_pair_no_sum": ["AMT_PAIR_NO_SUM"], "abl_pair_no_gather": ["AMT_PAIR_NO_GATHER"],
+        "abl_pair_no_flush": ["AMT_PAIR_NO_FLUSH"], "abl_pair_no_convert": ["AMT_PAIR_NO_CONVERT"], "abl_pair_no_eval": ["AMT_PAIR_NO_EVAL"]}
 for k in DEFS:
     VARIANTS.setdefault(k, {})
 if "--build" in sys.argv:
