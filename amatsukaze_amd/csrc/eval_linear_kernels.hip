@@ -168,6 +168,22 @@ template <int N, typename Q> __device__ __forceinline__ void vm_wait_raw(Q (&raw
                  : "n"(N) : "memory");
 }
 
+// {s.x, s.y} * {v.y, v.y} + {v.x, v.x}: one packed multiply-add for a PAIR of fades, the multiplier and the addend broadcast out of the
+// two halves of one register pair by the instruction's op_sel (no copies).  Every vector instruction costs the SIMD the same four
+// cycles, packed or not (profiles/r06_notes.md): what can be said for two fades at once is said once.
+__device__ __forceinline__ f2 pk_fma_hi_lo_s(f2 s, f2 v)      // s: a scalar register pair (two fades)
+{
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "s"(s), "v"(v));
+    return r;
+}
+__device__ __forceinline__ f2 pk_fma_hi_lo_v(f2 a, f2 v)
+{
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(v));
+    return r;
+}
+
 // One wave's staging state (eval_tile_stage.h TileStager, SLIM form) with the loads above.  BLEND = false: a field logo, whose rows are
 // the source rows themselves (CopyY): one row load per unit instead of three, no [1 2 1] sums.
 template <typename pix_t, bool BLEND> struct LinStager {
@@ -369,13 +385,18 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
 #else
 #define AMT_LTICK(k) do { } while (0)
 #endif
-    // the fades, wave-uniform (scalar registers)
+    // the fades, wave-uniform: scalar register PAIRS {fade 2j, fade 2j + 1} (operands of the packed multiply-adds) and the last one
+    static_assert(NF % 2 == 1, "the fades are walked in pairs plus the last one");
+    constexpr int NP = (NF - 1) / 2;
+    f2 fdp[NP];
     float fd[NF];
     {
         typedef const __attribute__((address_space(4))) float* const_float_ptr;
         const const_float_ptr fp = (const_float_ptr)(A.fades + A.fade0);
 #pragma unroll
         for (int f = 0; f < NF; ++f) fd[f] = fp[f];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) fdp[j] = f2{fd[2 * j], fd[2 * j + 1]};
     }
     float* const myacc = wacc + wave * G * (kLinAccFrameBytes / 4);
     for (int i = lane; i < G * (kLinAccFrameBytes / 4); i += 64) myacc[i] = 0.0f;
@@ -452,18 +473,23 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
         const float dy = y1 - y0;
         const float y0d = y0 + ydq;                                 // (the window's half-width rides in the multiply-add's addend: one rounding
                                                                     //  for the sum, one for the FMA -- the two the bound counted for FMA and add)
+        const f2 YD = f2{y0d, dy};
         float emin = 1.0f;
-        float binf[NF];                                            // the fade's bin, 0..31
+        f2 binp[NP];                                               // the bins of fades 2j and 2j + 1, 0..31
         // Fade 0 blends to s and fade 1 to bg exactly (0 * x + y == y), and M holds their means in the reference's own order (column
         // sums, hsum, /25: window_eval_streamed): those two bins are the reference's without any test.  (The caller guarantees that the
         // first fade is 0 and the last is 1.)  It matters: mean(s) is an integer / 25 and sits exactly ON a bin edge once in 200 pixels.
+        const float binl = __builtin_amdgcn_fmed3f(__builtin_floorf(y1), 0.0f, 31.0f);          // the last fade's
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const bool end = f == 0 || f == NF - 1;
-            const float y = end ? (f == 0 ? y0 : y1) : __builtin_fmaf(fd[f], dy, y0d);
-            if (!end) emin = __builtin_fminf(emin, __builtin_amdgcn_fractf(y));
-            binf[f] = __builtin_amdgcn_fmed3f(__builtin_floorf(y), 0.0f, 31.0f);       // (int)clamp(mean, 0, 255) >> 3; a NaN mean gives bin 0 like the reference's (int)NaN = INT_MIN
+        for (int j = 0; j < NP; ++j) {
+            const f2 yy = pk_fma_hi_lo_s(fdp[j], YD);               // {fade 2j, fade 2j + 1}: fade * dy + y0d
+            const float ya = j == 0 ? y0 : yy.x;                      // (fade 0: the exact mean's own bin; the packed lane is not used)
+            if (j != 0) emin = __builtin_fminf(emin, __builtin_amdgcn_fractf(ya));
+            emin = __builtin_fminf(emin, __builtin_amdgcn_fractf(yy.y));
+            // (int)clamp(mean, 0, 255) >> 3; a NaN mean gives bin 0 like the reference's (int)NaN = INT_MIN
+            binp[j] = f2{__builtin_amdgcn_fmed3f(__builtin_floorf(ya), 0.0f, 31.0f), __builtin_amdgcn_fmed3f(__builtin_floorf(yy.y), 0.0f, 31.0f)};
         }
+        auto bin_of = [&](int f) -> float { return f == NF - 1 ? binl : ((f & 1) ? binp[f >> 1].y : binp[f >> 1].x); };
         // A mean within bin_eps of a bin edge (3e-4 of all (pixel, fade) pairs; one wave iteration in five has one): the term below is
         // formed with the TENTATIVE bin floor(y), and the pair is put on the wave's list {slot, frame, fade, tentative bin; x}.  When the
         // workgroup has finished, every listed pair is looked at with all threads at once: the mean evaluated exactly as the reference
@@ -483,7 +509,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
                     if (m != 0) {
                         const unsigned pos = (unsigned)qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         if (flag && pos < (unsigned)A.qcap)
-                            myqueue[pos] = u2{code0 | ((unsigned)f << 23) | ((unsigned)binf[f] << 27), __builtin_bit_cast(unsigned, __builtin_fmaf(fd[f], dRq, R0q))};
+                            myqueue[pos] = u2{code0 | ((unsigned)f << 23) | ((unsigned)bin_of(f) << 27), __builtin_bit_cast(unsigned, __builtin_fmaf(fd[f], dRq, R0q))};
                         qn += __builtin_popcountll(m);
                     }
                 }
@@ -517,27 +543,45 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
             // them to its 16 bytes of the quad's cell: ONE 16-byte read-modify-write per iteration for the whole wave (a 16-byte LDS store
             // costs 13 cycles of the CU's store path whatever its exec mask: three of them by lane 0 alone were a fifth of the loop's LDS time)
             f4 mine;
+            const f2 RR = f2{R0, dR};
+            float term[NF + 1];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f2 resp = pk_fma_hi_lo_v(binp[j], PQ);        // {Q * bin + P} of the two fades
+                const f2 x = pk_fma_hi_lo_s(fdp[j], RR);            // {fade * dR + R0}
+                const f2 md = f2{__builtin_amdgcn_fmed3f(x.x, -__builtin_fabsf(resp.x), __builtin_fabsf(resp.x)),
+                                 __builtin_amdgcn_fmed3f(x.y, -__builtin_fabsf(resp.y), __builtin_fabsf(resp.y))};
+                const f2 rc = f2{__builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fabsf(resp.x), floorResp)),
+                                 __builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fabsf(resp.y), floorResp))};
+                const f2 tt = md * rc;
+                term[2 * j] = tt.x; term[2 * j + 1] = tt.y;
+            }
+            {
+                const float resp = __builtin_fabsf(__builtin_fmaf(PQ.y, binl, PQ.x));
+                const float x = __builtin_fmaf(fd[NF - 1], dR, R0);
+                term[NF - 1] = __builtin_amdgcn_fmed3f(x, -resp, resp) * __builtin_amdgcn_rcpf(__builtin_fmaxf(resp, floorResp));
+                term[NF] = 0.0f;
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                float term[4];
+                float tq[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = 4 * q + r;
                     if (f < NF) {
-                        const float resp = __builtin_fabsf(__builtin_fmaf(PQ.y, binf[f], PQ.x));
-                        const float x = __builtin_fmaf(fd[f], dR, R0);
-                        float t = __builtin_amdgcn_fmed3f(x, -resp, resp) * __builtin_amdgcn_rcpf(__builtin_fmaxf(resp, floorResp));
+                        float t = term[f];
                         t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
                         t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
-                        term[r] = t;
-                    } else term[r] = 0.0f;
+                        asm volatile("" : "+v"(t));       // (left alone the add sinks behind the selects below and its DPP operand stays a v_mov_b32_dpp: one more instruction per fade)
+                        tq[r] = t;
+                    } else tq[r] = 0.0f;
                 }
-                if (q == 0) mine = f4{term[0], term[1], term[2], term[3]};
+                if (q == 0) mine = f4{tq[0], tq[1], tq[2], tq[3]};
                 else {
                     const bool me = (lane & 3) == q;
-                    mine = f4{me ? term[0] : mine[0], me ? term[1] : mine[1], me ? term[2] : mine[2], me ? term[3] : mine[3]};
+                    mine = f4{me ? tq[0] : mine[0], me ? tq[1] : mine[1], me ? tq[2] : mine[2], me ? tq[3] : mine[3]};
                 }
-                __builtin_amdgcn_sched_barrier(0);          // (four fades at a time: left alone the scheduler computes all eleven terms first -- eleven registers too many)
+                __builtin_amdgcn_sched_barrier(0);          // (four fades at a time: left alone the scheduler forms all eleven sums first -- eleven registers too many)
             }
             if ((lane & 3) != 3) {
                 const lds_quad cell = (lds_quad)(unsigned long long)(myacc_base + (unsigned)g0 * (unsigned)kLinAccFrameBytes + (unsigned)(lane >> 2) * 48u + (unsigned)(lane & 3) * 16u);

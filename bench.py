@@ -55,7 +55,7 @@ STRONG_FRAMES = 107892                 # BASELINE configs[3]: 60 min at 29.97 fp
 SCANLOGO_MAX_FRAMES = 20000            # ScanLogo's numMaxFrames (LogoScan.hpp:885)
 SCANLOGO_FLAT_EVERY = 4                # one frame in four passes AddFrame's border test: 26 9xx of 107 892 > numMaxFrames, so the stream-order
                                        # quota closes the stream early (round 5: one in eight, 13 486 accepted -- the quota was never reached)
-PMC_TRAFFIC = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r06_pmc_traffic.json")
 EVAL = "logo_eval_fused_kernel"
 
 
@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU batch (BASELINE configs[1]: 10k)")
     ap.add_argument("--strong-frames", type=int, default=STRONG_FRAMES, help="frames of the sharded all-frames scan (configs[3])")
     ap.add_argument("--strong-steps", type=int, default=20)
+    ap.add_argument("--scanlogo-max-frames", type=int, default=SCANLOGO_MAX_FRAMES,
+                    help="numMaxFrames of the ScanLogo runs (LogoScan.hpp:885: the first so many valid frames in stream order); small values let a "
+                         "short dry run reach the quota")
     ap.add_argument("--no-strong", action="store_true", help="skip the attached strong-scaling scan measurement")
     ap.add_argument("--cpu-frames", type=int, default=300, help="distinct frames of the CPU baseline sample (configs[0]: 300; 0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="repeat the CPU sample until this much CPU work is timed")
@@ -647,7 +650,7 @@ def main():
         torch.cuda.empty_cache()
         # ---- the "full LogoScan" of the same configuration: ScanLogo (LogoScan.hpp:917-1079) over the sharded stream -- an all-gather of
         #      per-rank valid counts hands out the numMaxFrames quota in stream order (:885), three exact int64 all-reduces ----
-        sl = sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT, verify=not args.no_verify)
+        sl = sharded_scanlogo(ctx, dev, alpha, alphaUV, rank, world, f0, nloc, NT, max_frames=args.scanlogo_max_frames, verify=not args.no_verify)
         if out is not None:
             out["scanlogo"] = sl
         return out
@@ -1387,7 +1390,7 @@ class _RectView:
         self.strideY, self.strideUV, self.pitchY, self.pitchUV = LH * PITCH_Y, (LH // 2) * PITCH_UV, PITCH_Y, PITCH_UV
 
 
-def config_scanlogo(ctx, dev, logos_np, alpha, alphaUV, args, NT=STRONG_FRAMES, max_frames=SCANLOGO_MAX_FRAMES):
+def config_scanlogo(ctx, dev, logos_np, alpha, alphaUV, args, NT=STRONG_FRAMES, max_frames=None):
     """BASELINE configs[3]'s 'full LogoScan': the exported ScanLogo (LogoScan.hpp:1083-1098, 917-1079) over the 60-minute stream at
     N = 1 -- border test + accumulation over all frames (the first numMaxFrames valid ones), two ReMakeLogo rounds, .lgd written --
     and the .lgd of the WHOLE stream compared with the CPU oracle's ScanLogo (bytes)."""
@@ -1395,6 +1398,7 @@ def config_scanlogo(ctx, dev, logos_np, alpha, alphaUV, args, NT=STRONG_FRAMES, 
     import torch
     import amt_synth as S
     from amatsukaze_amd import ScanLogo
+    max_frames = max_frames or args.scanlogo_max_frames
     t0 = time.perf_counter()
     c = S.make_clip_torch(NT, W, H, 0x5EED0004, alpha, alphaUV, IMGX, IMGY, dev, period=900, fade=12, pitchY=PITCH_Y, pitchUV=PITCH_UV,
                           rows=(IMGY, IMGY + LH), flat_every=SCANLOGO_FLAT_EVERY)

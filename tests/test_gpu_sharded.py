@@ -229,15 +229,23 @@ def test_bench_eight_rank_control_flow_dry_run():
         assert r.returncode == 0, r.stderr[-2000:]
         return _bench_lines(r)[1]
 
-    strong = ["--scaling", "strong", "--strong-frames", "4099", "--strong-steps", "1"]
+    # (numMaxFrames 512 of ~1 025 valid frames in 4 099: the stream-order quota of the sharded ScanLogo, LogoScan.hpp:885, closes the stream
+    #  in the fifth rank's shard -- ranks 0-3 keep all their valid frames, rank 4 a part, ranks 5-7 none)
+    strong = ["--scaling", "strong", "--strong-frames", "4099", "--strong-steps", "1", "--scanlogo-max-frames", "512"]
     s8, s1 = run(strong, 8), run(strong, 1)
     assert s8["n_gpus"] == 8 and s8["collectives"]["world_size_observed"] == 8
-    assert s8["strong_scan"]["verified"]["sharded_equals_single_launch"] and s8["strong_scan"]["verified"]["equals_cpu_oracle"]
+    v8 = s8["strong_scan"]["verified"]
+    assert v8["sharded_equals_single_launch"] and v8["equals_cpu_oracle"] and v8["frames"] == 4099      # every record of every rank's shard
     assert s8["strong_scan"]["records_sha256"] == s1["strong_scan"]["records_sha256"]
     assert s8["strong_scan"]["scanlogo"]["lgd_sha256"] == s1["strong_scan"]["scanlogo"]["lgd_sha256"]
+    for s_ in (s8, s1):                                   # ... and the whole stream's .lgd against the CPU oracle's, quota reached
+        sv = s_["strong_scan"]["scanlogo"]["verified"]
+        assert sv["lgd_equals_cpu_oracle"] and sv["quota_hit"] and sv["valid_frames"] == 512 and sv["frames"] == 4099
     e2e = ["--workload", "e2e10", "--e2e-frames", "1500", "--e2e-chunk", "96"]
     e8, e1 = run(e2e, 8), run(e2e + ["--e2e-chunk", "512"], 1)
     assert e8["n_gpus"] == 8 and e8["e2e10"]["verified"]["ok"] and e1["e2e10"]["verified"]["ok"]
+    for e_ in (e8, e1):                                   # every frame of every rank's share against the CPU oracle
+        assert e_["e2e10"]["verified"]["whole_stream"] and e_["e2e10"]["verified"]["frames_compared_with_cpu_oracle"] == 1500
     assert e8["e2e10"]["decisions_sha256"] == e1["e2e10"]["decisions_sha256"]
     weak = run(["--steps", "1", "--warmup", "1", "--frames", "256", "--no-ingest", "--cpu-frames", "0", "--no-alt-mode", "--no-configs", "--no-strong",
                 "--exact-steps", "0"], 8)

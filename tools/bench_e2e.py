@@ -303,7 +303,7 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
     #      mask-pixel evaluation + 6 per rectangle pixel per evaluation; HBM traffic from the committed PMC passes over this very workload) ----
     import json
     try:
-        pmc16 = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_pmc_traffic16.json")))
+        pmc16 = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_pmc_traffic16.json")))
     except Exception:
         pmc16 = {}
     an_tab = [logos[0].mask_tables(k, E.maskratio)["count"] for k in (0, 1, 2)]
@@ -328,7 +328,7 @@ def run(E, nt=SHARE_FRAMES, chunk=4096, verify=True, mode="linear", scaling="str
         roof16[name + (" (16-bit samples)" if "linear" in name or "pair" in name else "<16-bit>")] = {"bound": kind, "achieved": rate / (1e12 if kind == "fp32-valu" else 1e9), "unit": "TFLOP/s" if kind == "fp32-valu" else "GB/s",
                         "peak": peak / (1e12 if kind == "fp32-valu" else 1e9), "frac": rate / peak, "launches": k["launches"], "total_ms": k["total_ms"],
                         "algorithmic_bytes_per_frame": algb, "traffic_bytes_per_frame": tr,
-                        "traffic_source": "profiles/r05_pmc_traffic16.json" if tr else None}
+                        "traffic_source": "profiles/r06_pmc_traffic16.json" if tr else None}
     return {
         "workload": f"BASELINE configs[4]: end-to-end logo scan + AMTAnalyzeLogo + CalcFade + AMTEraseLogo + CM/KFM frame metrics and decisions on "
                     f"{nt} frames ({nt / 29.97 / 3600:.2f} h) of 1920x1080i 10-bit (16-bit containers), frames sharded over {world} GPU(s) by contiguous "
