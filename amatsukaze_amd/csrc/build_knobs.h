@@ -22,7 +22,7 @@
     defined(AMT_TILE_WAVES) || defined(AMT_TILE_G) || defined(AMT_PAIR_OCC) || defined(AMT_FUSED_OCC) || defined(AMT_FUSED_BG_LDS) || defined(AMT_LISTED_FADE_CHUNK) || \
     defined(AMT_STATS_ROWS) || defined(AMT_STATS_ROWS8) || defined(AMT_STATS_RUN) || defined(AMT_STATS_COLB) || defined(AMT_STATS_LEAN) || defined(AMT_STATS_PINGPONG) || \
     defined(AMT_STATS_DEAL) || defined(AMT_STATS_NT) || defined(AMT_STATS_OCC) || defined(AMT_STATS_WAVES) || defined(AMT_STATS_LDS_BYTES) || \
-    defined(AMT_DELOGO_ROWS) || defined(AMT_DELOGO_FRAMES) || defined(AMT_SCAN_ACC_FIXED32)
+    defined(AMT_DELOGO_ROWS) || defined(AMT_DELOGO_FRAMES) || defined(AMT_SCAN_ACC_FIXED32) || defined(AMT_WG_PLAIN_MAP)
 #error "a shape / tuning macro of the kernels is defined on the command line: the release library is built with the defaults in the sources (instrumented variants: amatsukaze_amd/build.py build_variant)"
 #endif
 #endif

@@ -353,7 +353,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     float* const wacc = lds + kLinWaves * kTileCap * 2;            // [kLinWaves][G][48 lanes][4] a wave's running sums (kLinAccFrameBytes per frame)
 
     const int G = A.G;
-    const int logo = blockIdx.x / A.ngroups;
+    const int logo = blockIdx.x / A.ngroups;                       // (logo-major on purpose: eval_tiles.hpp, wg_map_shared_rows)
     const int grp = blockIdx.x - logo * A.ngroups;
     const int F0 = grp * G;
     const int gcount = min(G, A.nframes - F0);
@@ -624,7 +624,7 @@ __device__ __forceinline__ void logo_eval_linear_body(const LinLaunch& A)
     if (lane == 0) qcount[wave] = qn;
     __syncthreads();
 #ifdef AMT_LIN_TIMING
-    if (lane == 0 && blockIdx.x == gridDim.x / 6 && wave < 4) {      // a workgroup of logo 0 (the deint logo)
+    if (lane == 0 && logo == 0 && grp == A.ngroups / 2 && wave < 4) {      // a workgroup of logo 0 (the deint logo)
         long long* tb = reinterpret_cast<long long*>(A.out + (long long)A.nframes * A.out_frame_stride);      // host reserves room
         for (int k = 0; k < 8; ++k) tb[wave * 8 + k] = tacc[k];
     }

@@ -72,7 +72,7 @@ struct PairLaunch {
     long long frame_stride;      // elements
     int pitch;                   // elements
     float maxv;
-    int nframes, G, ngroups;
+    int nframes, G, ngroups, nlogos;
     float* out;
     int out_frame_stride, take_abs;
 };
@@ -94,7 +94,7 @@ void logo_eval_pair_kernel(const PairLaunch A)
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = clock64();
 #define AMT_PTICK(k) do { const long long t_ = clock64(); tacc[k] += t_ - tprev; tprev = t_; } while (0)
-#define AMT_PDUMP() do { if (lane == 0 && blockIdx.x == gridDim.x / 2) { \
+#define AMT_PDUMP() do { if (lane == 0 && logo == 0 && grp == A.ngroups / 2) { \
         long long* tb = reinterpret_cast<long long*>(A.out + (long long)A.nframes * A.out_frame_stride);   /* the host reserves room */ \
         for (int k = 0; k < 8; ++k) tb[wave * 8 + k] = tacc[k]; \
         tb[16 * 8 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_REG_HW_ID: SIMD id in bits 5:4 */ } } while (0)
@@ -103,8 +103,9 @@ void logo_eval_pair_kernel(const PairLaunch A)
 #define AMT_PDUMP() do { } while (0)
 #endif
     const int G = A.G;
-    const int logo = blockIdx.x / A.ngroups;
-    const int grp = blockIdx.x - logo * A.ngroups;
+    const WgMap wm = wg_map_shared_rows((int)blockIdx.x, A.nlogos, A.ngroups);
+    if (wm.grp >= A.ngroups) return;                               // (the grid is whole blocks of eight groups; a whole workgroup leaves: no barrier is missed)
+    const int logo = wm.logo, grp = wm.grp;
     const int F0 = grp * G;
     const int gcount = min(G, A.nframes - F0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -258,11 +259,11 @@ hipError_t launch_logo_eval_pair(hipStream_t st, int bits, const EvalLogoDev* dl
     PairLaunch A;
     A.logos = dlogos; A.tls = dtls; A.Y = dY; A.frame_map = dframe_map; A.frame_stride = frame_stride_elems; A.pitch = pitch;
     A.maxv = (float)((1 << bits) - 1);
-    A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G;
+    A.nframes = nframes; A.G = G; A.ngroups = (nframes + G - 1) / G; A.nlogos = nlogos;
     A.out = dout; A.out_frame_stride = out_frame_stride; A.take_abs = take_abs;
     const size_t lds = ((size_t)kTileWaves * kTileCap * 2 + (size_t)2 * 2 * G * kPairRowPitch) * sizeof(float);
     if (G < 1 || 2 * G > 64 || lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((long long)A.ngroups * nlogos));
+    dim3 grid((unsigned)wg_grid_shared_rows(A.ngroups, nlogos));
     if (bits <= 8) hipLaunchKernelGGL(logo_eval_pair_kernel<uint8_t>, grid, dim3(kPairThreads), lds, st, A);
     else hipLaunchKernelGGL(logo_eval_pair_kernel<uint16_t>, grid, dim3(kPairThreads), lds, st, A);
     return hipGetLastError();

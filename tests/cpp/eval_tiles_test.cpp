@@ -124,6 +124,24 @@ int main(int argc, char** argv)
             replay(c.name, from_mask(mask, c.w, c.h), c.w, c.h);
         }
     }
+    // the scan kernel's workgroup -> (logo, frame group) map (eval_tiles.hpp): every pair exactly once, a group's logos on ONE XCD
+    // (workgroup id mod 8) and back to back in that XCD's dispatch order, ids of the padding past the last group
+    for (int nlogos = 1; nlogos <= 5; ++nlogos)
+        for (int ngroups : {1, 2, 7, 8, 9, 63, 64, 1250, 1251}) {
+            const long long grid = wg_grid_shared_rows(ngroups, nlogos);
+            std::vector<int> hit((size_t)nlogos * ngroups, 0), xcd((size_t)ngroups, -1), first((size_t)ngroups, -1);
+            CHECK(grid % kXcds == 0 && grid >= (long long)nlogos * ngroups && grid < (long long)nlogos * (ngroups + kXcds), "wg map: grid %lld", grid);
+            for (int bid = 0; bid < grid; ++bid) {
+                const WgMap m = wg_map_shared_rows(bid, nlogos, ngroups);
+                CHECK(m.logo >= 0 && m.logo < nlogos && m.grp >= 0, "wg map: range");
+                if (m.grp >= ngroups) continue;
+                ++hit[(size_t)m.logo * ngroups + m.grp];
+                if (xcd[m.grp] < 0) { xcd[m.grp] = bid % kXcds; first[m.grp] = bid; }
+                CHECK(xcd[m.grp] == bid % kXcds, "wg map: group %d on two XCDs", m.grp);
+                CHECK(bid == first[m.grp] + m.logo * kXcds, "wg map: group %d logo %d not back to back on its XCD", m.grp, m.logo);
+            }
+            for (int v : hit) CHECK(v == 1, "wg map: a (logo, group) pair %d times", v);
+        }
     if (failures) { fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
     printf("ok\n");
     return 0;

@@ -12,6 +12,7 @@ VARIANTS = {"noslp_all": {f: NOSLP for f in ("eval_linear_kernels.hip", "eval_pa
             "pair_maxilp": {"eval_pair_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}}
 DEFS = {"stats_copying": ["AMT_STATS_PINGPONG=0"],
         "lin_g6": ["AMT_LIN_G=6"], "lin_g5": ["AMT_LIN_G=5"], "lin_g4": ["AMT_LIN_G=4"], "lin_occ3": ["AMT_LIN_OCC=3", "AMT_LIN_OCC16=3"],
+        "wg_plain_map": ["AMT_WG_PLAIN_MAP"],
         # ablations (wrong results by design: what a part of a kernel costs)
         "abl_lin_raw_sameframe": ["AMT_LIN_RAW_SAMEFRAME"], "abl_lin_no_flush": ["AMT_LIN_NO_FLUSH"], "abl_lin_no_fixup": ["AMT_LIN_NO_FIXUP"],
         "abl_lin_no_convert": ["AMT_LIN_NO_CONVERT"], "abl_lin_no_eval": ["AMT_LIN_NO_EVAL"],
