@@ -22,7 +22,7 @@ static void replay(const char* name, const std::vector<uint32_t>& pos, int w, in
     const TilePlan P = build_tile_plan(pos, count, w, h);
     std::vector<int> seen(count, 0);
     int m_next = 0;
-    long staged = 0;
+    long staged = 0, read_cycles = 0, read_tiles = 0;
     CHECK(P.tiles.size() == P.bands.size() * kTileWaves && P.sinfo.size() == P.bands.size() * kTileBandPix, "%s: table sizes", name);
     for (size_t b = 0; b < P.bands.size(); ++b) {
         const TileBandDesc& B = P.bands[b];
@@ -49,12 +49,34 @@ static void replay(const char* name, const std::vector<uint32_t>& pos, int w, in
                 }
             }
             staged += (long)T.nrows * T.ncol4 * 4;
+            // LDS cycles of a window read (lanes 0-31, then 32-63: distinct addresses on a bank pair serialise), with and without the lanes
+            // that carry no pixel: those must read a window one of their half's pixels reads (a broadcast, no cycle of their own)
+            if (T.npix > 0) {
+                int cyc[2] = {0, 0};
+                for (int idle = 0; idle < 2; ++idle)
+                    for (int hf = 0; hf < 2; ++hf) {
+                        std::vector<int> seen_at[32];
+                        int worst = 1;
+                        for (int l = hf * 32; l < hf * 32 + 32; ++l) {
+                            const uint32_t si = P.sinfo[(b * kTileWaves + wv) * kTileLanes + l];
+                            if (!idle && !(si >> 31)) continue;
+                            std::vector<int>& at = seen_at[si & 31];
+                            if (std::find(at.begin(), at.end(), (int)(si & 0xFFFu)) == at.end()) at.push_back((int)(si & 0xFFFu));
+                            worst = std::max(worst, (int)at.size());
+                        }
+                        cyc[idle] += worst;
+                    }
+                CHECK(cyc[0] == cyc[1], "%s: band %zu tile %d: lanes without a pixel cost LDS cycles (%d -> %d)", name, b, wv, cyc[0], cyc[1]);
+                read_cycles += cyc[1]; ++read_tiles;
+            }
+            int nvalid = 0;
             for (int l = 0; l < kTileLanes; ++l) {
                 const size_t slot = (b * kTileWaves + wv) * kTileLanes + l;
                 const uint32_t si = P.sinfo[slot];
                 const bool valid = (si >> 31) != 0;
                 const int m = P.slot_pixel[slot];
-                CHECK(valid == (l < T.npix) && valid == (m >= 0), "%s: slot validity", name);
+                CHECK(valid == (m >= 0), "%s: slot validity", name);
+                nvalid += valid;
                 const int woff = (int)(si & 0xFFFu), ridx = (int)((si >> 12) & 0xFFFu);
                 CHECK(woff + 4 * T.tp + 4 < kTileCap || !valid || woff + 4 * T.tp + 4 < kTileCap, "%s: window past the plane", name);
                 if (!valid) { CHECK(woff + 4 * std::max(T.tp, 4) + 4 < kTileCap, "%s: idle lane window outside the plane", name); continue; }
@@ -69,12 +91,14 @@ static void replay(const char* name, const std::vector<uint32_t>& pos, int w, in
                               name, b, wv, l, r, c);
                     }
             }
+            CHECK(nvalid == T.npix, "%s: band %zu tile %d: %d lanes carry a pixel, the tile says %d", name, b, wv, nvalid, T.npix);
         }
         for (int i = 0; i < B.npix; ++i) CHECK(row_seen[i] == 1, "%s: band %zu row slot %d written %d times", name, b, i, row_seen[i]);
     }
     CHECK(m_next == count, "%s: bands cover %d of %d pixels", name, m_next, count);
     for (int m = 0; m < count; ++m) CHECK(seen[m] == 1, "%s: pixel %d evaluated %d times", name, m, seen[m]);
-    printf("%-28s %6d px  %3zu bands  %.2f staged samples per mask pixel\n", name, count, P.bands.size(), count ? (double)staged / count : 0.0);
+    printf("%-28s %6d px  %3zu bands  %.2f staged samples per mask pixel  %.2f LDS cycles per window read (2 = none lost to bank conflicts)\n", name, count,
+           P.bands.size(), count ? (double)staged / count : 0.0, read_tiles ? (double)read_cycles / read_tiles : 0.0);
 }
 
 static std::vector<uint32_t> from_mask(const std::vector<uint8_t>& mask, int w, int h)
