@@ -95,3 +95,26 @@ def test_round5_detail_compacts_to_the_committed_line():
     assert line["verified"]["ok"] is True and line["verified"]["frames"] == line["config"]["frames_per_gpu"] == 10000
     assert line["roofline"]["bound"] in ("hbm", "fp32-valu") and 0 < line["roofline"]["frac"] < 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+
+
+def test_round6_detail_compacts_to_the_committed_line():
+    """profiles/r06_bench.json is the line bench.py printed, profiles/r06_bench_detail.json the detail of the same run: the builder reproduces
+    the line exactly, and the line carries what round 6 was about -- the mode the value is in, and full-size verification of configs[3] / [4]"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail.json")))
+    printed = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench.json")).read().strip().splitlines()[-1])
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert line == printed
+    cfg = line["config"]
+    assert cfg["analysis_mode"] == "linear" and cfg["library_default_mode"] == "exact" and "exact_mode" in cfg["value_is_in_mode"]
+    assert not cfg["workload"].endswith("...") and "configs[1]" in cfg["workload"]
+    assert line["exact_mode"]["value"] < line["value"]
+    assert line["verified"]["ok"] is True and line["verified"]["frames"] == cfg["frames_per_gpu"] == 10000
+    ss = line["strong_scan"]
+    assert ss["verified_ok"] is True and ss["verified_frames"] == ss["frames_total"] == 107892
+    assert ss["lgd_equals_cpu_oracle"] is True and ss["scanlogo_quota_hit"] is True
+    sl = line["configs"]["scanlogo_60min"]
+    assert sl["verified_frames"] == sl["frames"] == 107892 and sl["quota_hit"] is True
+    e2e = line["e2e10"]
+    assert e2e["verified_ok"] is True and e2e["verified_whole_stream"] is True and e2e["verified_frames"] == e2e["frames_total"]
+    assert line["roofline"]["traffic_source"].startswith("profiles/r06_") and 0 < line["roofline"]["frac"] < 1
