@@ -8,8 +8,14 @@
 // evaluation order by rounding only (bounded by EvalEngine::linear_error_bound(), ~1e-6 typical), which is inside the 1e-4
 // the north star allows for the float scores; the INTEGER decisions taken from them are protected separately:
 //   * the bin select is discontinuous: when the interpolated mean lies within `bin_eps` (the bound on its distance from the exactly
-//     evaluated mean) of a bin edge, that fade's mean is re-computed in the reference's exact order (blend, column sums, hsum, /25)
-//     and the bin comes from the exact value;
+//     evaluated mean) of a bin edge, the (pixel, frame, fade) is LISTED (a per-wave queue in LDS) and the loop carries on with the
+//     tentative bin; after the loop every listed pair gets its mean re-computed from the frame in the reference's exact order (blend,
+//     column sums, hsum, /25), the bin from the exact value and, where that differs, the correction t(exact bin) - t(tentative bin);
+//     a queue that overflows marks the workgroup's frames for the exact kernel (LinLaunch::force);
+//   * the scale of a term is COMPUTED, not looked up: CreateLogoMask's table value for (pixel, bin) is |P + Q*bin| up to rounding (the
+//     composite of a flat level is affine in the level), so t = med3(x, -r, r) * rcp(max(r, L)) with r = |fma(Q, bin, P)| -- the
+//     deviation from the reference's table-driven clamp(x*scale, -1, 1)*scale2 is evaluated per (pixel, bin) on the host and is part of
+//     the error bound (EvalEngine::ensure_linear);
 //   * argmin over fades (CalcFade2, :1288-1314): analysis_mark_kernel lists every frame whose best / second-best margin is
 //     below twice the error bound, and the exact kernel (eval_fused_kernels.hip) re-evaluates just those frames.
 //

@@ -373,3 +373,37 @@ def test_linear_mode_bin_check_list(gpu, bits):
     assert r16 > N // 4 and (as_exact | as_before).all() and as_exact.sum() >= r16, (r16, int(as_exact.sum()), int(as_before.sum()))
     with pytest.raises(Exception):
         guarded.set_fixup_queue(641)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 10])
+def test_linear_mode_flat_frames_on_bin_edges(gpu, bits):
+    """The worst input for the linear kernel's bin check: frames without a logo whose every sample is the same multiple of 8 gray levels
+    (black frames at 16, the CM boundaries of real broadcasts) -- the window mean of `s` sits exactly ON an edge of CorrelationScore's
+    bins (LogoScan.hpp:304) at every mask pixel, and wherever the logo is weak the blends' means stay there.  Whatever the lists hold or
+    overflow, the guarded mode must hand out the exact mode's decisions: scores within 1e-4, fades identical; a short list (16 entries) only
+    moves frames to the exact kernel."""
+    import torch
+    import amt_synth as S
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, Logo
+    W, H, LW, LH, X, Y0 = 720, 480, 160, 80, 500, 30
+    sh = bits - 8
+    levels = [8 * k for k in range(0, 32)] + [16, 16, 16, 235, 128, 17, 15, 255]
+    N = len(levels) * 2
+    data, alpha, alphaUV = S.make_logo(LW, LH, seed=0x10600072)
+    clip = S.make_clip_torch(N, W, H, 0x5EED0072, alpha, alphaUV, X, Y0, gpu["dev"], period=7, fade=2, chroma=False, bits=bits)
+    Yd, ctx = clip["Y"], gpu["ctx"]
+    for i, lv in enumerate(levels):
+        Yd[2 * i].fill_(lv << sh)                                  # (odd frames keep the synthetic picture, logo coming and going)
+    logo = Logo.from_planes(ctx, data, LW, LH, W, H, X, Y0)
+    run = lambda an: (lambda o: (an.analyze_device(Yd, bits, o), torch.cuda.synchronize(), o.cpu().numpy())[2])(torch.empty((N, 33), dtype=torch.float32, device=gpu["dev"]))
+    exact = run(AMTAnalyzeLogo(ctx, logo, 0.35))
+    er = AMTEraseLogo(ctx, logo, "", maxfade=16)
+    fe = er.calc_fades(exact, N).tobytes()
+    guarded = AMTAnalyzeLogo(ctx, logo, 0.35, mode="linear")
+    for entries in (256, 16, 640):
+        guarded.set_fixup_queue(entries)
+        g = run(guarded)
+        assert np.isfinite(g).all() and np.abs(g - exact).max() <= 1e-4, (entries, float(np.abs(g - exact).max()))
+        assert er.calc_fades(g, N).tobytes() == fe, entries
+        assert 0 <= guarded.last_refined() <= N
