@@ -426,10 +426,20 @@ class AMTEraseLogo:
                                                                    first, n, _p(out)))
         return out
 
-    def erase_device_fades(self, clip: DeviceClip, d_fades):
-        """Delogo with fades that are already on the device (calc_fades_device's output).  async"""
-        self.ctx.check(self.ctx.lib.amtgpu_erase_batch_dfades(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV,
-                                                              clip.pitchY, clip.pitchUV, clip.bits, clip.num_frames, _p(d_fades)))
+    def erase_device_fades(self, clip: DeviceClip, d_fades, dst: "DeviceClip | None" = None):
+        """Delogo with fades that are already on the device (calc_fades_device's output).  async
+        dst: a batch of the same geometry that already holds a copy of clip's frames -- the writable copy AMTEraseLogo::GetFrameT takes
+        (env->MakeWritable, LogoScan.hpp:1346-1347): Delogo reads clip and writes dst's rectangle, clip stays intact.  None: in place."""
+        if dst is None:
+            self.ctx.check(self.ctx.lib.amtgpu_erase_batch_dfades(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), clip.strideY, clip.strideUV,
+                                                                  clip.pitchY, clip.pitchUV, clip.bits, clip.num_frames, _p(d_fades)))
+            return
+        same = ("strideY", "strideUV", "pitchY", "pitchUV", "bits", "num_frames")
+        if any(getattr(clip, k) != getattr(dst, k) for k in same):
+            raise ValueError("erase_device_fades: source and destination batches differ in geometry")
+        self.ctx.check(self.ctx.lib.amtgpu_erase_batch_dfades_to(self.h, _p(clip.Y), _p(clip.U), _p(clip.V), _p(dst.Y), _p(dst.U), _p(dst.V),
+                                                                 clip.strideY, clip.strideUV, clip.pitchY, clip.pitchUV, clip.bits,
+                                                                 clip.num_frames, _p(d_fades)))
 
     def erase(self, clip: DeviceClip, fades):
         fades = np.ascontiguousarray(fades, np.float32)

@@ -113,6 +113,7 @@ SIGNATURES = {
     "amtgpu_erase_get_rect": (c_i, [c_p, c_p]),
     "amtgpu_erase_calc_fades_device": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_erase_batch_dfades": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "amtgpu_erase_batch_dfades_to": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_erase_rect_batch_dfades": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "amtgpu_analyze_get_rect": (c_i, [c_p, c_p]),
     "amtgpu_logoframe_get_rows": (c_i, [c_p, c_p]),

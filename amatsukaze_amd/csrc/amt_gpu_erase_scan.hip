@@ -18,8 +18,9 @@ struct EraseGeom {
     int imgx, imgy, cx, cy;
     int uvparity;
 };
-hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
-                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades, int zero_identity);
+hipError_t launch_delogo(hipStream_t st, int bits, const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV, long long strideY,
+                         long long strideUV, int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades,
+                         int zero_identity);
 hipError_t launch_ingest_rows(hipStream_t st, const void* src, long long src_stride, void* dst, long long dst_stride, unsigned long long chunk,
                               long long nchunks);
 hipError_t launch_calc_fades(hipStream_t st, const float* danalysis, int analysis_first, int analysis_count, int num_frames, int first,
@@ -131,9 +132,12 @@ int amtgpu_erase_calc_fades(AmtGpuErase* er, const float* analysis, int num_fram
     });
 }
 
+// sY / sU / sV: the planes Delogo READS (null = dY / dU / dV: in place)
 static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV, int pitchY, int pitchUV,
-                         int bits, int nframes, const float* fades, bool rect_only, const float* d_fades = nullptr)
+                         int bits, int nframes, const float* fades, bool rect_only, const float* d_fades = nullptr,
+                         const void* sY = nullptr, const void* sU = nullptr, const void* sV = nullptr)
 {
+    if (!sY) { sY = dY; sU = dU; sV = dV; }
     if (bits < 8 || bits > 16) throw std::runtime_error("[AMTEraseLogo] Unsupported pixel format");
     if (er->mode != 0) throw std::runtime_error("[AMTEraseLogo] only mode 0 is supported (debug overlay modes are out of scope)");
     if (nframes <= 0) return;
@@ -173,7 +177,7 @@ static void erase_launch(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t 
     // 12-bit clip's out-of-range container values.  At 8 and 16 bits every container value is in range: only there are fade-0
     // frames skipped.
     const bool skip_fade0 = er->zeroIdentity && (bits == 8 || bits == 16);
-    AMT_HIP(launch_delogo(er->ctx->stream, bits, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
+    AMT_HIP(launch_delogo(er->ctx->stream, bits, sY, sU, sV, dY, dU, dV, strideY / es, strideUV / es, pitchY, pitchUV, er->dPlanes.get(), g,
                           nframes, dfades, skip_fade0 ? 1 : 0));
     er->ctx->prof_end(sp);
 }
@@ -205,6 +209,16 @@ int amtgpu_erase_rect_batch_dfades(AmtGpuErase* er, void* dY, void* dU, void* dV
     return guard(er->ctx, [&] {
         if (!d_fades && nframes > 0) throw std::runtime_error("[AMTEraseLogo] null device fades");
         erase_launch(er, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, nframes, nullptr, true, d_fades);
+    });
+}
+
+int amtgpu_erase_batch_dfades_to(AmtGpuErase* er, const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV, int64_t strideY,
+                                 int64_t strideUV, int pitchY, int pitchUV, int bits, int nframes, const float* d_fades)
+{
+    return guard(er->ctx, [&] {
+        if (!d_fades && nframes > 0) throw std::runtime_error("[AMTEraseLogo] null device fades");
+        if (nframes > 0 && (!sY || !sU || !sV || !dY || !dU || !dV)) throw std::runtime_error("[AMTEraseLogo] null plane");
+        erase_launch(er, dY, dU, dV, strideY, strideUV, pitchY, pitchUV, bits, nframes, nullptr, false, d_fades, sY, sU, sV);
     });
 }
 

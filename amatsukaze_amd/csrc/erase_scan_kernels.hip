@@ -70,7 +70,7 @@ __device__ __forceinline__ float delogo_px(float s, float a, float b, float maxv
 
 template <typename pix_t>
 __global__ __launch_bounds__(kDelogoThreads)
-void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restrict__ V, long long strideY,
+void delogo_kernel(const pix_t* sY, const pix_t* sU, const pix_t* sV, pix_t* Y, pix_t* U, pix_t* V, long long strideY,
                    long long strideUV, int pitchY, int pitchUV, const float* __restrict__ planes, EraseGeom g,
                    float maxv, const float2* __restrict__ fades, int pairY, int pairUV, int nframes, int quadY, int quadUV,
                    int zero_identity)
@@ -93,7 +93,8 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
     for (int r = blockIdx.x * kDelogoRows + wv; r < rend; r += kDelogoThreads / 64) {
         // the row's geometry and logo coefficients are the same for every frame of the group: the logo planes are
         // 8 B per sample against 2 B of frame traffic, so they are read once and kept in registers
-        pix_t* row0;
+        pix_t* row0;             // the row in the destination batch
+        const pix_t* srow0;      // ... in the source batch (the same pointer for the in-place call)
         const float *A, *B;
         int roww, paired, quad, y, pl;
         long long stride;
@@ -101,12 +102,14 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
             y = r; pl = 0;
             roww = g.w; paired = pairY; quad = quadY; stride = strideY;
             row0 = Y + (long long)(g.imgy + y) * pitchY + g.imgx;
+            srow0 = sY + (long long)(g.imgy + y) * pitchY + g.imgx;
             A = planes + (size_t)y * g.w; B = planes + ysz + (size_t)y * g.w;
         } else {
             pl = (r - g.h) >= g.hUV ? 2 : 1;
             y = r - g.h - (pl - 1) * g.hUV;
             roww = g.wUV; paired = pairUV; quad = quadUV; stride = strideUV;
             row0 = (pl == 2 ? V : U) + (long long)(g.cy + y) * pitchUV + g.cx;
+            srow0 = (pl == 2 ? sV : sU) + (long long)(g.cy + y) * pitchUV + g.cx;
             const float* base = planes + 2 * ysz + (size_t)(pl - 1) * 2 * csz;
             A = base + (size_t)y * g.wUV; B = base + csz + (size_t)y * g.wUV;
         }
@@ -134,7 +137,7 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
                 typename PixQuad<pix_t>::type v[kDelogoFrames];          // all live frames' loads in flight before the first use
 #pragma unroll
                 for (int k = 0; k < kDelogoFrames; ++k)
-                    if (live[k]) v[k] = *reinterpret_cast<const quad_t*>(row0 + (long long)(f0 + k) * stride + x);
+                    if (live[k]) v[k] = *reinterpret_cast<const quad_t*>(srow0 + (long long)(f0 + k) * stride + x);
 #pragma unroll
                 for (int k = 0; k < kDelogoFrames; ++k) {
                     if (!live[k]) continue;
@@ -153,7 +156,7 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
                 pair_t v[kDelogoFrames];                                 // all frames' loads in flight before the first use
 #pragma unroll
                 for (int k = 0; k < kDelogoFrames; ++k)
-                    v[k] = *reinterpret_cast<const pair_t*>(row0 + (long long)min(f0 + k, f1 - 1) * stride + x);
+                    v[k] = *reinterpret_cast<const pair_t*>(srow0 + (long long)min(f0 + k, f1 - 1) * stride + x);
 #pragma unroll
                 for (int k = 0; k < kDelogoFrames; ++k) {
                     const int f = f0 + k;
@@ -173,16 +176,16 @@ void delogo_kernel(pix_t* __restrict__ Y, pix_t* __restrict__ U, pix_t* __restri
                     bool skip;
                     const float fade = fade_of(fades[f], skip);
                     if (skip) continue;
-                    pix_t* p = row0 + (long long)f * stride + x;
-                    *p = (pix_t)delogo_px((float)*p, a, b, maxv, fade);
+                    row0[(long long)f * stride + x] = (pix_t)delogo_px((float)srow0[(long long)f * stride + x], a, b, maxv, fade);
                 }
             }
         }
     }
 }
 
-hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV, long long strideY, long long strideUV,
-                         int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades, int zero_identity)
+hipError_t launch_delogo(hipStream_t st, int bits, const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV, long long strideY,
+                         long long strideUV, int pitchY, int pitchUV, const float* dplanes, EraseGeom g, int nframes, const float2* dfades,
+                         int zero_identity)
 {
     if (nframes <= 0) return hipSuccess;
     const int rows = g.h + 2 * g.hUV;
@@ -192,17 +195,17 @@ hipError_t launch_delogo(hipStream_t st, int bits, void* dY, void* dU, void* dV,
     auto even = [](long long v) { return (v & 1) == 0; };
     // a pair access needs 2*es alignment of every row start and an even width (plane bases come from hipMalloc /
     // AviSynth's 64-byte aligned planes; a caller handing odd byte offsets falls back to single samples)
-    const int pairY = even(g.w) && even(g.imgx) && even(pitchY) && even(strideY) && ((uintptr_t)dY % (2 * es) == 0);
+    const int pairY = even(g.w) && even(g.imgx) && even(pitchY) && even(strideY) && ((uintptr_t)dY % (2 * es) == 0) && ((uintptr_t)sY % (2 * es) == 0);
     const int pairUV = even(g.wUV) && even(g.cx) && even(pitchUV) && even(strideUV) && ((uintptr_t)dU % (2 * es) == 0) &&
-                       ((uintptr_t)dV % (2 * es) == 0);
+                       ((uintptr_t)dV % (2 * es) == 0) && ((uintptr_t)sU % (2 * es) == 0) && ((uintptr_t)sV % (2 * es) == 0);
     // four samples per lane where a row is a multiple of 4 wide (coefficient rows are then 16-byte aligned float4s)
     const int quadY = pairY && g.w % 4 == 0;
     const int quadUV = pairUV && g.wUV % 4 == 0;
     if (bits <= 8)
-        hipLaunchKernelGGL(delogo_kernel<uint8_t>, grid, block, 0, st, (uint8_t*)dY, (uint8_t*)dU, (uint8_t*)dV, strideY,
+        hipLaunchKernelGGL(delogo_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)sY, (const uint8_t*)sU, (const uint8_t*)sV, (uint8_t*)dY, (uint8_t*)dU, (uint8_t*)dV, strideY,
                            strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes, quadY, quadUV, zero_identity);
     else
-        hipLaunchKernelGGL(delogo_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)dY, (uint16_t*)dU, (uint16_t*)dV, strideY,
+        hipLaunchKernelGGL(delogo_kernel<uint16_t>, grid, block, 0, st, (const uint16_t*)sY, (const uint16_t*)sU, (const uint16_t*)sV, (uint16_t*)dY, (uint16_t*)dU, (uint16_t*)dV, strideY,
                            strideUV, pitchY, pitchUV, dplanes, g, maxv, dfades, pairY, pairUV, nframes, quadY, quadUV, zero_identity);
     return hipGetLastError();
 }

@@ -77,6 +77,11 @@ def parse_args():
     ap.add_argument("--no-ingest", action="store_true", help="skip the PCIe-inclusive (streamed) measurement")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-erase", action="store_true")
+    ap.add_argument("--erase-in-place", action="store_true",
+                    help="rounds 1-5: AMTEraseLogo rewrites the resident frames in place and the step puts the rectangles back afterwards (bench "
+                         "housekeeping inside the timed region, ~0.4 ms).  Default: Delogo reads the resident frames and writes the rectangle into a "
+                         "second resident batch that holds a copy of them -- the writable copy AMTEraseLogo::GetFrameT takes (env->MakeWritable, "
+                         "LogoScan.hpp:1346-1347; amtgpu_erase_batch_dfades_to): the same reads and writes, nothing to put back")
     ap.add_argument("--no-alt-mode", action="store_true", help="do not time the other analysis mode after the timed region (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the attached measurements of BASELINE configs[2], the 10-bit format and ScanLogo")
     ap.add_argument("--exact-steps", type=int, default=40, help="timed steps of the same pass with the exact (bit-identical) analysis, reported as exact_mode")
@@ -703,8 +708,12 @@ def main():
     d_fades = torch.empty((N, 2), dtype=torch.float32, device=dev)
     an_ready = torch.cuda.Event()
     last = {}
-    # AMTEraseLogo rewrites the logo rectangle in place; every frame is erased ONCE in a real run, so the step puts the rectangles
-    # back (48 KB per frame, device to device) instead of analysing frames that were already erased by the previous step
+    # AMTEraseLogo::GetFrameT takes a writable copy of the frame and rewrites its logo rectangle (LogoScan.hpp:1346-1347).  Default:
+    # `wclip` IS that copy -- a second resident batch; Delogo reads dclip and writes wclip's rectangle, so dclip stays what every
+    # step analyses.  --erase-in-place (rounds 1-5; always with host-side fades): the erase rewrites dclip itself and the step puts the
+    # rectangles back (48 KB per frame, device to device: housekeeping inside the timed region) instead of analysing erased frames.
+    to_copy = not args.erase_in_place and args.fades == "device" and not args.no_erase
+    wclip = DeviceClip(dclip.Y.clone(), dclip.U.clone(), dclip.V.clone(), W, H, 8) if to_copy else None
     rect = (dclip.Y[:, IMGY:IMGY + LH, IMGX:IMGX + LW].clone(), dclip.U[:, IMGY // 2:(IMGY + LH) // 2, IMGX // 2:(IMGX + LW) // 2].clone(),
             dclip.V[:, IMGY // 2:(IMGY + LH) // 2, IMGX // 2:(IMGX + LW) // 2].clone())
 
@@ -741,7 +750,7 @@ def main():
         if not args.no_erase:
             if args.fades == "device":
                 eraser.calc_fades_device(d_analysis, N, out=d_fades)     # a12 CalcFade / CalcFade2 on the device: no host round trip
-                eraser.erase_device_fades(dclip, d_fades)                # a12 Delogo, in place
+                eraser.erase_device_fades(dclip, d_fades, dst=wclip)     # a12 Delogo: into the writable copy (or in place: wclip None)
                 last["fades"] = None                                     # (read back from d_fades where needed, outside the timed region)
             else:
                 an_ready.synchronize()                                   # the host decides while the scan / metrics kernels run
@@ -750,8 +759,8 @@ def main():
                 last["fades"] = fades
             if MCU:
                 cur.wait_stream(sL)
-            if restore:
-                restore_rectangles()                                 # bench housekeeping (inside the timed region, ~0.3 ms)
+            if restore and not to_copy:
+                restore_rectangles()                                 # bench housekeeping (inside the timed region, ~0.4 ms)
         elif MCU:
             cur.wait_stream(sL)
         if world > 1 and collective:
@@ -815,8 +824,11 @@ def main():
         phases["frame_metrics"], _ = timed(lambda: stats.run_device(dclip.Y, d_stats))
         phases["host_calc_fades"], fd = timed(lambda: eraser.calc_fades(h_analysis.numpy(), N))
         phases["device_calc_fades"], _ = timed(lambda: eraser.calc_fades_device(d_analysis, N, out=d_fades))
-        phases["erase"], _ = timed(lambda: eraser.erase(dclip, fd))
-        phases["restore_rectangles_bench_housekeeping"], _ = timed(restore_rectangles)
+        if to_copy:
+            phases["erase_into_the_writable_copy"], _ = timed(lambda: eraser.erase_device_fades(dclip, d_fades, dst=wclip))
+        else:
+            phases["erase"], _ = timed(lambda: eraser.erase(dclip, fd))
+            phases["restore_rectangles_bench_housekeeping"], _ = timed(restore_rectangles)
         phases = {k: round(v, 3) for k, v in phases.items()}
         phases["note"] = ("each call fenced with a device synchronise (so launch latency is inside every figure); the timed steps use "
                           + ("the device CalcFade: the whole step is stream-ordered, the host only enqueues" if args.fades == "device" else
@@ -829,6 +841,9 @@ def main():
         del clip
         clip = gen()                                                 # stays resident: the pristine frames the oracle is fed
         dclip.Y.copy_(clip["Y"]); dclip.U.copy_(clip["U"]); dclip.V.copy_(clip["V"])
+        if to_copy:
+            wclip.Y.copy_(clip["Y"]); wclip.U.copy_(clip["U"]); wclip.V.copy_(clip["V"])
+        eclip = wclip if to_copy else dclip                          # where the erased frames are
         d_exact = None
         if args.analysis_mode == "linear":
             # the whole batch through the exact kernel (bit-identical to the reference) BEFORE the step erases the frames: the
@@ -849,9 +864,11 @@ def main():
         # within 1e-4 (linear-guarded); the oracle on every host core (tools/bench_verify.py)
         verified = BV.verify_range(torch, OracleLogos(logos_np), 8, N, 0, N,
                                    lambda lo, hi: (clip["Y"][lo:hi], clip["U"][lo:hi], clip["V"][lo:hi]),
-                                   lambda lo, hi: (dclip.Y[lo:hi], dclip.U[lo:hi], dclip.V[lo:hi]),
+                                   lambda lo, hi: (eclip.Y[lo:hi], eclip.U[lo:hi], eclip.V[lo:hi]),
                                    lf.evalResults, h_analysis.numpy(), last.get("fades"), d_stats.cpu().numpy().astype(np.uint64),
                                    tol=1e-4 if args.analysis_mode == "linear" else 0.0, erase=not args.no_erase)
+        if to_copy and not (torch.equal(dclip.Y, clip["Y"]) and torch.equal(dclip.U, clip["U"]) and torch.equal(dclip.V, clip["V"])):
+            raise SystemExit("bench verification FAILED: the erase into the writable copy touched its source frames")
         del clip
         verified["analysis_mode"] = args.analysis_mode
         verified["analysis_compare"] = ("bytes" if args.analysis_mode == "exact" else
@@ -1054,6 +1071,8 @@ def main():
                        "value_is_in_mode": ("linear-guarded (opt-in; identical fades and erased frames, scores within 1e-4): see exact_mode.value for the library default"
                                             if args.analysis_mode == "linear" else "exact (the library default)"),
                        "calc_fade": args.fades,
+                       "erase": ("none" if args.no_erase else "into a resident writable copy (MakeWritable's frame)" if to_copy else
+                                 "in place, rectangles put back inside the step"),
                        "device_partition": ({"metrics_cus": MCU, "logo_cus": NCU - MCU, "how": "two contexts on CU-range streams (amtgpu_stream_create_cu_range): the "
                                              "frame metrics run beside the analysis + scan; erase waits for both"} if MCU else None),
                        "frames_per_gpu": N, "logo": f"{LW}x{LH}@({IMGX},{IMGY})", "maskratio": MASKRATIO,

@@ -34,7 +34,8 @@ extern "C" {
                                    * 4: amtgpu_logoframe_decide_host returns -1 (was 0) when the text buffer is too small and refuses
                                    *    num_candidates > num_logos; additions: amtgpu_logoframe_dump_result, amtgpu_host_set_parallelism
                                    * 5: amtgpu_logoframe_decide_host is back to 1 / 0 like every other entry point (a too-small text buffer
-                                   *    is 0 with *text_len > cap: `if (!call) fail;` written against ABI <= 3 is right again) */
+                                   *    is 0 with *text_len > cap: `if (!call) fail;` written against ABI <= 3 is right again); additions:
+                                   *    amtgpu_analyze_set_fixup_queue, amtgpu_erase_batch_dfades_to */
 #define AMTGPU_NUM_FADE 11            /* LogoAnalyzeFrame p/t/b[11]  (LogoScan.hpp:1100-1103) */
 #define AMTGPU_ANALYZE_FLOATS 33      /* floats per source frame in an analysis record */
 
@@ -319,6 +320,14 @@ int  amtgpu_erase_batch_dfades(AmtGpuErase* er, void* dY, void* dU, void* dV, in
                                int pitchY, int pitchUV, int bits, int nframes, const float* d_fades);
 int  amtgpu_erase_rect_batch_dfades(AmtGpuErase* er, void* dY, void* dU, void* dV, int64_t strideY, int64_t strideUV,
                                     int pitchY, int pitchUV, int bits, int nframes, const float* d_fades);
+/* amtgpu_erase_batch_dfades from a SOURCE batch into a DESTINATION batch of the same geometry (strides, pitches, bit depth) that already
+ * holds a copy of the source frames -- the writable copy AMTEraseLogo::GetFrameT takes before it calls Delogo (env->MakeWritable,
+ * LogoScan.hpp:1346-1347): Delogo reads the source's rectangle and writes the destination's.  The source stays intact for its other
+ * consumers (the frame metrics, the scan, the next pass over the same frames); what Delogo leaves alone -- every sample outside the
+ * rectangle, frames whose fades are {0, 0} (see amtgpu_erase_get_rect), an odd last chroma row in field mode -- is NOT written, it is
+ * the copy's.  sY == dY (all three) is amtgpu_erase_batch_dfades.  async (ABI 5) */
+int  amtgpu_erase_batch_dfades_to(AmtGpuErase* er, const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,
+                                  int64_t strideY, int64_t strideUV, int pitchY, int pitchUV, int bits, int nframes, const float* d_fades);
 /* out5 = {imgx, imgy, w, h, fade0_is_identity}: the rectangle Delogo rewrites; the last word is 1 when a frame whose two fades
  * are 0 comes back unchanged (every a*s + b*maxv of this logo is finite), i.e. the host may skip the call for such frames --
  * of an 8- or 16-bit clip: at 10 / 12 bits Delogo's min(tmp + 0.5, maxv) (LogoScan.hpp:1258) still clamps container values

@@ -116,3 +116,34 @@ def test_stream_ordered_analyse_decide_erase(gpu, bits):
     assert d_f.cpu().numpy().tobytes() == fades.tobytes()
     assert torch.equal(dc.Y, host_clip.Y) and torch.equal(dc.U, host_clip.U) and torch.equal(dc.V, host_clip.V)
     assert np.abs(fades).sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 10, 16])
+def test_erase_into_a_writable_copy(gpu, bits):
+    """amtgpu_erase_batch_dfades_to: Delogo reads the SOURCE batch and writes the rectangle into a destination that already holds a copy
+    of the frames (AMTEraseLogo::GetFrameT's env->MakeWritable, LogoScan.hpp:1346-1347).  The destination equals the in-place result
+    byte for byte, the source is untouched, and a second call on the same pair changes nothing (the bench's steps rely on that instead of
+    restoring the rectangles)."""
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, DeviceClip
+    torch = gpu["torch"]
+    cs = make_case(gpu, SMALL, bits=bits, pitch_pad=32)
+    src = cs["dclip"]
+    n = src.num_frames
+    an = AMTAnalyzeLogo(gpu["ctx"], cs["logo"], 0.35)
+    er = AMTEraseLogo(gpu["ctx"], cs["logo"], "", 0, 16)
+    d_rec = torch.empty((n, 33), dtype=torch.float32, device=gpu["dev"])
+    an.analyze_device(src.Y, bits, d_rec)
+    d_f = er.calc_fades_device(d_rec, n)
+    inplace = DeviceClip(src.Y.clone(), src.U.clone(), src.V.clone(), src.width, src.height, bits)
+    er.erase_device_fades(inplace, d_f)
+    keep = [src.Y.clone(), src.U.clone(), src.V.clone()]
+    dst = DeviceClip(src.Y.clone(), src.U.clone(), src.V.clone(), src.width, src.height, bits)
+    for _ in range(2):
+        er.erase_device_fades(src, d_f, dst=dst)
+        gpu["ctx"].synchronize()
+        assert torch.equal(dst.Y, inplace.Y) and torch.equal(dst.U, inplace.U) and torch.equal(dst.V, inplace.V)
+        assert torch.equal(src.Y, keep[0]) and torch.equal(src.U, keep[1]) and torch.equal(src.V, keep[2])
+    assert not torch.equal(dst.Y, src.Y) and float(d_f.abs().sum()) > 0
+    with pytest.raises(ValueError):
+        er.erase_device_fades(src, d_f, dst=DeviceClip(src.Y[:-1].clone(), src.U[:-1].clone(), src.V[:-1].clone(), src.width, src.height, bits))
