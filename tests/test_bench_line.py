@@ -109,6 +109,8 @@ def test_round6_detail_compacts_to_the_committed_line():
     assert cfg["analysis_mode"] == "linear" and cfg["library_default_mode"] == "exact" and "exact_mode" in cfg["value_is_in_mode"]
     assert not cfg["workload"].endswith("...") and "configs[1]" in cfg["workload"]
     assert line["exact_mode"]["value"] < line["value"]
+    # the erase writes a resident copy of the frames; rounds 1-5's step (in place + rectangles put back) is reported next to it
+    assert "writable copy" in cfg["erase"] and line["in_place_erase_step"]["value"] < line["value"]
     assert line["verified"]["ok"] is True and line["verified"]["frames"] == cfg["frames_per_gpu"] == 10000
     ss = line["strong_scan"]
     assert ss["verified_ok"] is True and ss["verified_frames"] == ss["frames_total"] == 107892
