@@ -407,3 +407,47 @@ def test_linear_mode_flat_frames_on_bin_edges(gpu, bits):
         assert np.isfinite(g).all() and np.abs(g - exact).max() <= 1e-4, (entries, float(np.abs(g - exact).max()))
         assert er.calc_fades(g, N).tobytes() == fe, entries
         assert 0 <= guarded.last_refined() <= N
+
+
+@pytest.mark.parametrize("bits", [8, 10])
+@pytest.mark.parametrize("corner", ["top_left", "bottom_right"])
+def test_logo_in_a_frame_corner_unpadded_planes(gpu, corner, bits):
+    """The rectangle at the very first / the very last samples of planes WITHOUT row padding (pitch == width): the tiles' staging units, the
+    [1 2 1] rows above and below, the linear kernel's exact-mean loads (aligned words around five samples) and Delogo's paired accesses
+    all touch the first / last bytes of the batch.  Scan records, exact analysis records and erased planes are the oracle's bytes; the
+    linear-guarded records are within 1e-4 with identical fades."""
+    import ctypes as C
+    from amatsukaze_amd import AMTAnalyzeLogo, AMTEraseLogo, LogoFrame
+    W, H, LW, LH, N = 352, 240, 96, 48, 9
+    X, Y0 = (0, 0) if corner == "top_left" else (W - LW, H - LH)
+    cfg = dict(W=W, H=H, LW=LW, LH=LH, IMGX=X, IMGY=Y0, N=N, period=4, fade=2, flat=3)
+    cs = make_case(gpu, cfg, bits=bits, pitch_pad=0)
+    ctx, orc, clip = gpu["ctx"], cs["orc"], cs["clip"]
+    Y, U, V = clip["Y"].copy(), clip["U"].copy(), clip["V"].copy()
+    assert Y.shape[2] == W
+    d, t, b = oracle_eval_logos(orc, cs["lo"])
+    # scan
+    lf = LogoFrame(ctx, [cs["logo"]], 0.35)
+    lf.scanFrames(cs["dclip"])
+    want_scan = np.zeros(N * 2, np.float32)
+    orc.lib.orc_logoframe_scan((C.c_void_p * 1)(d), 1, _ptr(Y), Y.strides[0], Y.shape[2], bits, W, H, N, _ptr(want_scan))
+    assert lf.evalResults.reshape(-1).tobytes() == want_scan.tobytes()
+    # analysis: exact bytes, linear-guarded within tolerance
+    want = np.zeros(N * 33, np.float32)
+    orc.lib.orc_analyze_frames(d, t, b, _ptr(Y), Y.strides[0], Y.shape[2], bits, N, _ptr(want))
+    got = AMTAnalyzeLogo(ctx, cs["logo"], 0.35).analyze(cs["dclip"])
+    assert got.reshape(-1).tobytes() == want.tobytes()
+    lin = AMTAnalyzeLogo(ctx, cs["logo"], 0.35, mode="linear")
+    lin.set_fixup_queue(16)                                    # (short lists: more pairs go through the exact-mean loads' neighbours)
+    gl = lin.analyze(cs["dclip"])
+    assert (np.abs(gl.reshape(-1) - want) <= 1e-4 * np.maximum(1.0, np.abs(want))).all()
+    er = AMTEraseLogo(ctx, cs["logo"], "", 0, 16)
+    fades = er.calc_fades(got, N)
+    assert er.calc_fades(gl, N).tobytes() == fades.tobytes()
+    # erase
+    er.erase(cs["dclip"], fades)
+    for i in range(N):
+        orc.lib.orc_erase_frame(cs["lo"], _ptr(Y[i]), _ptr(U[i]), _ptr(V[i]), Y.shape[2], U.shape[2], bits, float(fades[i, 0]), float(fades[i, 1]))
+    view = (lambda x: x.cpu().numpy().view(np.uint16)) if bits > 8 else (lambda x: x.cpu().numpy())
+    assert np.array_equal(view(cs["dclip"].Y), Y) and np.array_equal(view(cs["dclip"].U), U) and np.array_equal(view(cs["dclip"].V), V)
+    assert np.abs(fades).sum() > 0
