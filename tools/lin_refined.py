@@ -1,9 +1,11 @@
-"""How many frames of the bench batch the guard hands to the exact kernel, and the linear kernel's time (python tools/lin_refined.py [frames])."""
+"""How many frames of the bench batch the guard hands to the exact kernel, and the linear kernel's time
+(python tools/lin_refined.py [frames [queue entries ...]])."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tools')
 import amt_synth as S, bench
 from amatsukaze_amd import AMTAnalyzeLogo, Context, Logo
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+QS = [int(a) for a in sys.argv[2:]] or [64, 128, 192, 256, 384, 512, 768, 1024]
 dev = torch.device('cuda', 0); torch.cuda.init()
 ctx = Context(0)
 logos_np, alpha, alphaUV = bench.make_logos()
@@ -16,7 +18,7 @@ ctx.profile(True)
 for _ in range(3): an.analyze_device(clip["Y"], 8, out)
 torch.cuda.synchronize()
 print("refined", an.last_refined(), {k: round(ms / c, 4) for k, (c, ms) in ctx.profile_report().items() if c})
-for q in (64, 128, 192, 256, 384, 512, 768, 1024):
+for q in QS:
     an.set_fixup_queue(q)
     an.analyze_device(clip["Y"], 8, out); torch.cuda.synchronize()
     ctx.profile(False); ctx.profile(True)
